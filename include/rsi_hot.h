@@ -1,0 +1,134 @@
+/* rsi_hot.h -- C ABI of the MI355X-native RSI read-depth CNV hot path (librsi_hot.so).
+ *
+ * The reference (yhwu/rsicnv) has no plugin / FFI interface; its hot path sits behind a seam of
+ * free functions operating on `Array<int>& RD` plus `rsi::` globals, called from main's
+ * per-chromosome loop (rsi.cpp:2189-2217).  One rsi_hot_run() call replaces, for one chromosome:
+ *
+ *   load_data_from_text, after its parse loop        loaddata.cpp:478-486, 519-531
+ *     GC mask + get_noseq_regions                    loaddata.cpp:481-486, 243-273; readref.cpp:88
+ *     checkgccontent / adjustgccontent               gccontent.cpp:95, 43
+ *     apply_cap                                      loaddata.cpp:229
+ *   concatenate_data                                 loaddata.cpp:48      (rsi.cpp:2200)
+ *   rsi::RDmedian = _median(RD); rsi::RDsd = ...     rsi.cpp:2202-2203    (wufunctions.cpp:364, 766)
+ *   detectcnv                                        rsi.cpp:1795         (rsi.cpp:2206)
+ *   sd_filters                                       rsi.cpp:1753         (rsi.cpp:2208)
+ *
+ * Conventions: inputs are borrowed for the call; results are owned by the rsi_result and freed
+ * by rsi_result_free; every entry point returns RSI_OK or a negative rsi_status and leaves a
+ * message for rsi_hot_last_error().  There is NO CPU fallback: without a HIP device
+ * rsi_hot_create() fails with RSI_ERR_NO_DEVICE.  One context per host thread / GPU; contexts are
+ * independent (no shared mutable globals), so chromosomes can be processed concurrently.
+ */
+#ifndef RSI_HOT_H
+#define RSI_HOT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rsi_status {
+  RSI_OK = 0,
+  RSI_ERR_NO_DEVICE = -1,    /* no HIP device / extension unusable: the product never falls back */
+  RSI_ERR_BAD_ARG = -2,
+  RSI_ERR_HIP = -3,          /* a HIP runtime call failed */
+  RSI_ERR_TOO_SMALL = -4,    /* chromosome shorter than 20*202 bases under GC adjust (gccontent.cpp:66-71) */
+  RSI_ERR_UNSUPPORTED = -5,  /* e.g. negative depth, Lmax beyond the LDS tile, N-run list overflow */
+  RSI_ERR_INTERNAL = -6
+} rsi_status;
+
+/* rsi:: statics that the path reads (rsi.h:54-122, defaults rsi.cpp:34-98). */
+typedef struct rsi_params {
+  int32_t m;          /* -m      bin size, forced odd by the caller as rsi.cpp:2061-2064 does */
+  int32_t gcadjust;   /* !-NOGC  */
+  int32_t trans;      /* 0 = NBN (-NB, default), 1 = MED (-MED), 2 = ALL (-ALL) */
+  int32_t merge;      /* !-nomerge */
+  int32_t maxchkbp;   /* -maxchkbp */
+  int32_t debug;      /* -debug */
+  double cap;         /* -cap */
+  double epsilon;     /* -e */
+  double threshold;   /* -threshold */
+  double chklen;      /* -reflen */
+  double minmlen;
+  double buffer;
+  double p;
+} rsi_params;
+
+/* POD mirror of cnv_st (rsi.h:8-51); qscore is the SCORE column of cnv_format1 (rsi.cpp:583-615). */
+typedef struct rsi_call {
+  int32_t start, end;   /* 0-based indices on the reference (N regions re-inserted), inclusive */
+  int32_t type;         /* 0 DEL, 1 DUP, 2 UNKNOWN (rsi.h:4-6) */
+  int32_t geno, status, length, qscore, pad;
+  double score, p1, cnvmed, cnvsd, cnviqr, refmed, refsd, refiqr;
+} rsi_call;
+
+/* Per-chromosome scalars the reference keeps in rsi:: globals or prints to its log. */
+typedef struct rsi_chrom_stats {
+  int64_t n;            /* chromosome length */
+  int64_t n_compact;    /* after N-region removal (rsi::end) */
+  int64_t nbins;
+  int32_t n_noncode;    /* padded N regions */
+  int32_t Lmax;         /* scan length actually used */
+  double gc_rdmean;     /* "RD mean before GC adjust" (gccontent.cpp:154) */
+  double cap_median;    /* median used by apply_cap (loaddata.cpp:233) */
+  double RDmedian, RDsd;
+  double nb_mad, nb_r, nb_tmin;
+  double tmedian1, tsigma1, tlamda1;   /* first scan pass */
+  double tmedian2, tsigma2, tlamda2;   /* second scan pass */
+  int32_t trim_escapes; /* trim walks that left the array (the reference aborts there, App. A Q12) */
+  int32_t inexact_sums; /* bins whose value breaks the exact-window-sum precondition */
+  double t_device_ms;   /* wall time of the call, inputs already on the device */
+  double t_kernels_ms;  /* sum of HIP-event times around the per-base kernels */
+} rsi_chrom_stats;
+
+typedef struct rsi_ctx rsi_ctx;
+typedef struct rsi_result rsi_result;
+
+/* Reference defaults (rsi.cpp:34-98). */
+void rsi_default_params(rsi_params* p);
+
+/* Context on HIP device `device`.  Returns NULL on failure; *status receives the reason. */
+rsi_ctx* rsi_hot_create(int device, int* status);
+void rsi_hot_destroy(rsi_ctx* ctx);
+const char* rsi_hot_last_error(const rsi_ctx* ctx);   /* ctx may be NULL: last global error */
+
+/* One chromosome, inputs in host memory: depth[n] raw per-base depth, fasta[n] sequence bytes. */
+int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const uint8_t* fasta, int64_t n,
+                rsi_result** out);
+/* Same, inputs already resident in device memory (HBM); they are not modified. */
+int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n,
+                       rsi_result** out);
+
+/* Results.  which: 0 = calls after sd_filters (what write_cnv_to_file prints),
+ *                  1 = detectcnv output before sd_filters,
+ *                  2 = bin-space segments after the scan (rsicnvnbn / rsicnvmed output),
+ *                  3 = bin-space segments after areblockscnv + sort. */
+int rsi_result_ncalls(const rsi_result* r, int which);
+const rsi_call* rsi_result_calls(const rsi_result* r, int which);
+const rsi_chrom_stats* rsi_result_stats(const rsi_result* r);
+/* Padded N regions as (start,end) inclusive pairs; returns the number of regions. */
+int rsi_result_noncode(const rsi_result* r, int32_t* pairs, int cap);
+/* One output row exactly as cnv_format1 prints it (rsi.cpp:581-631), without the newline. */
+int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* buf, int cap);
+void rsi_result_free(rsi_result* r);
+
+/* Intermediates for the parity tests (copied device -> host on demand while the context still
+ * holds the chromosome: valid until the next rsi_hot_run* on the same context).
+ * int32 names: "rd_gc" (after GC adjust, n), "rd_concat" (capped + compacted, n_compact),
+ *              "binmedint", "status1", "status1f", "status2" (nbins each)
+ * f32   names: "binnb", "binmed" (nbins)
+ * i64   names: "binsum" (nbins)
+ * Returns the element count (also when out == NULL), or a negative rsi_status. */
+int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t cap);
+int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t cap);
+int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t cap);
+
+/* Timing hooks for bench.py: per-kernel HIP-event times (ms) of the last run, by kernel name.
+ * names/ms receive up to cap entries; returns the number of timed launches. */
+int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap);
+/* Enable (1) / disable (0) per-kernel event timing (adds an event pair per launch). */
+void rsi_hot_set_timing(rsi_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
