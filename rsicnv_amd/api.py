@@ -1,0 +1,195 @@
+"""ctypes binding of librsi_hot.so (include/rsi_hot.h) -- the drop-in for the reference's
+per-chromosome hot path (rsi.cpp:2189-2212).
+
+The library is the product: there is no Python or CPU fallback.  `load_library()` raises if the
+shared object is missing, and `RsiHot()` raises if no HIP device can be opened.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsi_hot.so")
+
+RSI_OK = 0
+STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3: "RSI_ERR_HIP",
+                -4: "RSI_ERR_TOO_SMALL", -5: "RSI_ERR_UNSUPPORTED", -6: "RSI_ERR_INTERNAL"}
+
+# every symbol include/rsi_hot.h and include/rsi_synth.h declare
+EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
+           "rsi_hot_run_device", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
+           "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
+           "rsi_hot_kernel_times", "rsi_hot_set_timing", "rsi_synth_generate_host", "rsi_synth_generate_device"]
+
+
+class RsiParams(C.Structure):
+    _fields_ = [("m", C.c_int32), ("gcadjust", C.c_int32), ("trans", C.c_int32), ("merge", C.c_int32),
+                ("maxchkbp", C.c_int32), ("debug", C.c_int32), ("cap", C.c_double), ("epsilon", C.c_double),
+                ("threshold", C.c_double), ("chklen", C.c_double), ("minmlen", C.c_double),
+                ("buffer", C.c_double), ("p", C.c_double)]
+
+
+class RsiCall(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("type", C.c_int32), ("geno", C.c_int32),
+                ("status", C.c_int32), ("length", C.c_int32), ("qscore", C.c_int32), ("pad", C.c_int32),
+                ("score", C.c_double), ("p1", C.c_double), ("cnvmed", C.c_double), ("cnvsd", C.c_double),
+                ("cnviqr", C.c_double), ("refmed", C.c_double), ("refsd", C.c_double), ("refiqr", C.c_double)]
+
+
+class RsiChromStats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_compact", C.c_int64), ("nbins", C.c_int64), ("n_noncode", C.c_int32),
+                ("Lmax", C.c_int32), ("gc_rdmean", C.c_double), ("cap_median", C.c_double), ("RDmedian", C.c_double),
+                ("RDsd", C.c_double), ("nb_mad", C.c_double), ("nb_r", C.c_double), ("nb_tmin", C.c_double),
+                ("tmedian1", C.c_double), ("tsigma1", C.c_double), ("tlamda1", C.c_double), ("tmedian2", C.c_double),
+                ("tsigma2", C.c_double), ("tlamda2", C.c_double), ("trim_escapes", C.c_int32),
+                ("inexact_sums", C.c_int32), ("t_device_ms", C.c_double), ("t_kernels_ms", C.c_double)]
+
+
+CALL_FIELDS = [f[0] for f in RsiCall._fields_ if f[0] != "pad"]
+WHICH = {"calls": 0, "calls_raw": 1, "segs": 2, "blocks": 3}
+
+_lib = None
+
+
+def load_library():
+    """dlopen librsi_hot.so; raises (never falls back) when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -f rsicnv_amd/csrc/Makefile` "
+                           "(or __graft_entry__.build()); rsicnv_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.rsi_default_params.argtypes = [C.POINTER(RsiParams)]
+    L.rsi_hot_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.rsi_hot_create.restype = C.c_void_p
+    L.rsi_hot_destroy.argtypes = [C.c_void_p]
+    L.rsi_hot_last_error.argtypes = [C.c_void_p]
+    L.rsi_hot_last_error.restype = C.c_char_p
+    L.rsi_hot_run.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.rsi_hot_run_device.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.rsi_result_ncalls.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_result_calls.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_result_calls.restype = C.POINTER(RsiCall)
+    L.rsi_result_stats.argtypes = [C.c_void_p]
+    L.rsi_result_stats.restype = C.POINTER(RsiChromStats)
+    L.rsi_result_noncode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+    L.rsi_result_format_row.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.rsi_result_free.argtypes = [C.c_void_p]
+    for nm, ct in (("rsi_hot_fetch_i32", C.c_int32), ("rsi_hot_fetch_f32", C.c_float), ("rsi_hot_fetch_i64", C.c_int64)):
+        f = getattr(L, nm)
+        f.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(ct), C.c_int64]
+        f.restype = C.c_int64
+    L.rsi_hot_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.rsi_hot_set_timing.argtypes = [C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+def make_params(m=101, gcadjust=1, trans=0, merge=1, maxchkbp=100000, debug=0, cap=4.0, epsilon=1.5,
+                threshold=-1.0, chklen=2.5, minmlen=3.01, buffer=0.05, p=0.05):
+    """rsi:: defaults (rsi.cpp:34-98); m is forced odd as get_parameters does (rsi.cpp:2061-2064).
+    trans: 0 NBN (-NB), 1 MED (-MED), 2 ALL (-ALL)."""
+    if m % 2 != 1:
+        m += 1
+    return RsiParams(m, gcadjust, trans, merge, maxchkbp, debug, cap, epsilon, threshold, chklen, minmlen, buffer, p)
+
+
+class RsiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Result:
+    """Owned copy of one chromosome's results (the C object is freed on construction)."""
+
+    def __init__(self, lib, handle):
+        self.lists = {}
+        for name, w in WHICH.items():
+            k = lib.rsi_result_ncalls(handle, w)
+            arr = lib.rsi_result_calls(handle, w)
+            self.lists[name] = [{f: getattr(arr[i], f) for f in CALL_FIELDS} for i in range(k)]
+        st = lib.rsi_result_stats(handle).contents
+        self.stats = {f[0]: getattr(st, f[0]) for f in RsiChromStats._fields_}
+        k = lib.rsi_result_noncode(handle, None, 0)
+        pairs = (C.c_int32 * max(2 * k, 2))()
+        lib.rsi_result_noncode(handle, pairs, k)
+        self.noncode = np.array(pairs[:2 * k], dtype=np.int32)
+        self.rows = []
+        buf = C.create_string_buffer(1024)
+        for i in range(len(self.lists["calls"])):
+            lib.rsi_result_format_row(handle, i, b"%CHROM%", buf, 1024)
+            self.rows.append(buf.value.decode())
+        lib.rsi_result_free(handle)
+
+    def calls(self, which="calls"):
+        return self.lists[which]
+
+    def format_rows(self, chrom):
+        return [r.replace("%CHROM%", chrom) for r in self.rows]
+
+
+class RsiHot:
+    """One context = one GPU + one stream (rsi_hot_create)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        st = C.c_int(0)
+        self.ctx = self.lib.rsi_hot_create(device, C.byref(st))
+        if not self.ctx:
+            raise RsiError(st.value, self.lib.rsi_hot_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rsi_hot_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != RSI_OK:
+            raise RsiError(rc, self.lib.rsi_hot_last_error(self.ctx).decode())
+
+    def set_timing(self, on=True):
+        self.lib.rsi_hot_set_timing(self.ctx, 1 if on else 0)
+
+    def run(self, params, depth, fasta):
+        """depth: int32[n] raw per-base depth, fasta: uint8[n] sequence bytes (host arrays)."""
+        d = np.ascontiguousarray(depth, dtype=np.int32)
+        f = np.ascontiguousarray(fasta, dtype=np.uint8)
+        if d.shape != f.shape or d.ndim != 1:
+            raise ValueError("depth and fasta must be 1-D arrays of the same length")
+        out = C.c_void_p()
+        self._check(self.lib.rsi_hot_run(self.ctx, C.byref(params), d.ctypes.data, f.ctypes.data, d.size, C.byref(out)))
+        return Result(self.lib, out)
+
+    def run_device(self, params, d_depth_ptr, d_fasta_ptr, n):
+        """Inputs already in HBM (raw device pointers, 16-byte aligned)."""
+        out = C.c_void_p()
+        self._check(self.lib.rsi_hot_run_device(self.ctx, C.byref(params), C.c_void_p(d_depth_ptr), C.c_void_p(d_fasta_ptr),
+                                                n, C.byref(out)))
+        return Result(self.lib, out)
+
+    def fetch(self, name):
+        for fn, ct, dt in ((self.lib.rsi_hot_fetch_i32, C.c_int32, np.int32), (self.lib.rsi_hot_fetch_f32, C.c_float, np.float32),
+                           (self.lib.rsi_hot_fetch_i64, C.c_int64, np.int64)):
+            n = fn(self.ctx, name.encode(), None, 0)
+            if n >= 0:
+                out = np.zeros(n, dtype=dt)
+                k = fn(self.ctx, name.encode(), out.ctypes.data_as(C.POINTER(ct)), n)
+                if k < 0:
+                    raise RsiError(int(k), self.lib.rsi_hot_last_error(self.ctx).decode())
+                return out
+        raise KeyError(name)
+
+    def kernel_times(self):
+        names = (C.c_char_p * 4096)()
+        ms = (C.c_float * 4096)()
+        k = self.lib.rsi_hot_kernel_times(self.ctx, names, ms, 4096)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(k, 4096))]

@@ -1,0 +1,467 @@
+// host_calls.cpp -- candidate tests, boundary refinement, merge and final filters on the host
+// (SURVEY.md 8a rows A15-A19).  Reference lines are cited per function (paths relative to
+// /root/reference/src).  Compiled with -ffp-contract=off: the statistics below decide which
+// candidates survive, so they have to round like the reference's x86-64 build.
+#include "host_calls.h"
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "hostmath.h"
+
+namespace rsih {
+
+// ------------------------------------------------------------------------------------------
+double normal_cdf(double x) {
+  // erf / erfc rational approximations of Cephes ndtr as used by alglib
+  // (alglib/specialfunctions.cpp:3152-3302); numerators/denominators highest power first.
+  static const double kErfNum[7] = {0.007547728033418631287834, -0.288805137207594084924010, 14.3383842191748205576712,
+                                    38.0140318123903008244444, 3017.82788536507577809226, 7404.07142710151470082064,
+                                    80437.3630960840172832162};
+  static const double kErfDen[7] = {0.0, 1.00000000000000000000000, 38.0190713951939403753468, 658.070155459240506326937,
+                                    6379.60017324428279487120, 34216.5257924628539769006, 80437.3630960840172826266};
+  static const double kErfcNum[9] = {0.0, 0.5641877825507397413087057563, 9.675807882987265400604202961,
+                                     77.08161730368428609781633646, 368.5196154710010637133875746,
+                                     1143.262070703886173606073338, 2320.439590251635247384768711,
+                                     2898.0293292167655611275846, 1826.3348842295112592168999};
+  static const double kErfcDen[9] = {1.0, 17.14980943627607849376131193, 137.1255960500622202878443578,
+                                     661.7361207107653469211984771, 2094.384367789539593790281779,
+                                     4429.612803883682726711528526, 6089.5424232724435504633068,
+                                     4958.82756472114071495438422, 1826.3348842295112595576438};
+  auto horner = [](const double* c, int n, double t) { double a = c[0]; for (int i = 1; i < n; ++i) a = c[i] + t * a; return a; };
+  const double z = x / 1.41421356237309504880;
+  const double sign = z > 0 ? 1.0 : (z < 0 ? -1.0 : 0.0);
+  const double az = fabs(z);
+  double erf_z;
+  if (az < 0.5) {
+    const double t = az * az;
+    erf_z = sign * 1.1283791670955125738961589031 * az * horner(kErfNum, 7, t) / horner(kErfDen, 7, t);
+  } else if (az >= 10) {
+    erf_z = sign;
+  } else {
+    const double erfc_az = exp(-(az * az)) * horner(kErfcNum, 9, az) / horner(kErfcDen, 9, az);
+    erf_z = sign * (1 - erfc_az);
+  }
+  return 0.5 * (erf_z + 1);
+}
+
+// ------------------------------------------------------------------------------------------
+DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream)
+    : d_(d_ptr), n_(n), stream_(stream), pages_((size_t)((n + kMask) >> kBits) + 1) {}
+
+void DepthPager::fetch(int64_t p0, int64_t p1) {
+  const int64_t lo = p0 << kBits;
+  int64_t hi = ((p1 + 1) << kBits);
+  if (hi > n_) hi = n_;
+  if (hi <= lo) { for (int64_t p = p0; p <= p1; ++p) if (!pages_[p]) pages_[p].reset(new int32_t[(size_t)1 << kBits]()); return; }
+  std::vector<int32_t> tmp((size_t)(hi - lo));
+  (void)hipMemcpyAsync(tmp.data(), d_ + lo, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
+  (void)hipStreamSynchronize(stream_);
+  fetched_ += (hi - lo) * (int64_t)sizeof(int32_t);
+  for (int64_t p = p0; p <= p1; ++p) {
+    if (pages_[p]) continue;
+    pages_[p].reset(new int32_t[(size_t)1 << kBits]());
+    const int64_t a = p << kBits, b = std::min(a + (1 << kBits), hi);
+    if (b > a) memcpy(pages_[p].get(), tmp.data() + (a - lo), (size_t)(b - a) * sizeof(int32_t));
+  }
+}
+
+void DepthPager::prefetch(int64_t lo, int64_t hi) {
+  if (lo < 0) lo = 0;
+  if (hi > n_ - 1) hi = n_ - 1;
+  if (hi < lo) return;
+  const int64_t p_lo = lo >> kBits, p_hi = hi >> kBits;
+  for (int64_t p = p_lo; p <= p_hi;) {
+    if (pages_[p]) { ++p; continue; }
+    int64_t q = p;
+    while (q + 1 <= p_hi && !pages_[q + 1]) ++q;
+    fetch(p, q);
+    p = q + 1;
+  }
+}
+
+namespace {
+
+struct VecView {   // bin-space arrays
+  const std::vector<int>* v;
+  int64_t size() const { return (int64_t)v->size(); }
+  int operator[](int64_t i) const { return (*v)[(size_t)i]; }
+  void prefetch(int64_t, int64_t) const {}
+};
+struct PagedView {
+  DepthPager* p;
+  int64_t size() const { return p->size(); }
+  int operator[](int64_t i) const { return (*p)[i]; }
+  void prefetch(int64_t lo, int64_t hi) const { p->prefetch(lo, hi); }
+};
+
+// ---- isitcnv (rsi.cpp:101-172): statistics of the candidate against its neighbourhood ----
+void judge(const CallerInput& in, const std::vector<int>& ref, const std::vector<int>& body, Candidate& c) {
+  const int width = (int)body.size();
+  const int nwin = (int)ref.size() - width;
+  std::vector<float> winmean(nwin > 0 ? (size_t)nwin : 0);
+  double acc = 0;
+  for (int i = 0; i < width; ++i) acc += ref[i];
+  if (nwin > 0) winmean[0] = (float)(acc / double(width));
+  for (int i = 1; i < nwin; ++i) {
+    acc = acc - ref[i - 1] + ref[i - 1 + width];
+    winmean[i] = (float)(acc / double(width));
+  }
+  const Quantiles qr = grid_quantiles(winmean.data(), winmean.size());
+  double spread = sqrt(variance_pop(winmean.data(), winmean.size()));
+  if (spread < 1E-3) spread = qr.med / 40.0 + 1E-3;
+  const Quantiles qc = grid_quantiles(body.data(), body.size());
+  c.length = c.end - c.start + 1;
+  c.cnvmed = qc.med;
+  c.cnvsd = sqrt(variance_pop(body.data(), body.size()));
+  c.cnviqr = qc.uqt - qc.lqt;
+  c.refmed = qr.med;
+  c.refiqr = qr.uqt - qr.lqt;
+  c.refsd = c.refiqr / 1.349;
+  c.geno = 1;
+  c.status = 1;
+  const int observed = c.cnvmed > in.RDmedian ? kDup : kDel;
+  if (c.type == kUnknown) c.type = observed;
+  if (c.type != observed) { c.status = -9; return; }   // "basic assignment error"
+  if (c.type == kDel) {
+    double level = std::min(qr.med, in.RDmedian);
+    level = std::max(level, 0.8 * in.RDmedian);
+    const double nu = (3.0 * c.cnvmed - 2.0 * level) / spread;
+    c.p1 = normal_cdf(nu);
+    if (nu > 0) { c.status = -9; c.geno = 0; }
+  } else {
+    const double level = std::max(qr.med, in.RDmedian);
+    const double nu = (2.5 * c.cnvmed - 3.0 * level) / spread / 1.5;
+    c.p1 = 1.0 - normal_cdf(nu);
+    if (nu < 0) { c.status = -9; c.geno = 0; }
+  }
+}
+
+// ---- isitcnvwrap (rsi.cpp:175-287): collect the reference neighbourhood around list[ci] ----
+template <class View>
+void test_candidate(const CallerInput& in, const View& A, std::vector<Candidate>& list, int ci) {
+  const rsi_params& P = in.P;
+  const int64_t N = A.size();
+  const int count = (int)list.size();
+  const Candidate me = list[ci];
+  const int kind = me.type;
+  const int body_len = me.end - me.start + 1;
+  const int span_all = (int)in.ncompact;   // rsi::end - rsi::start + 1
+  int d = body_len;
+  if (N == span_all) { if (d < P.m * P.minmlen) d = (int)(P.m * P.minmlen); }
+  if (N < span_all / 2) { if (d < P.minmlen) d = (int)P.minmlen + 1; }
+  const int capacity = (int)(P.chklen * d * 2);
+  std::vector<int> ref((size_t)capacity, 0);
+  const double too_high = in.RDmedian * 3.0, too_low = in.RDmedian * 0.15;
+  auto skip_value = [&](int v) { return (kind == kDel && v > too_high) || (kind == kDup && v < too_low); };
+  const int margin = int(body_len * P.buffer + 1);
+  A.prefetch((int64_t)me.start - margin - 3LL * capacity / 5 - 64, (int64_t)me.end + margin + 3LL * capacity / 5 + 64);
+
+  // left side, filled from slot `fill` downwards
+  int pos = me.start - margin;
+  int nb = ci - 1;
+  while (pos > 0 && nb > 0 && pos < list[nb].start) --nb;
+  while (nb > 0 && list[nb].status == -9) --nb;
+  int fill = (int)(P.chklen * d - 1);
+  if (N - me.end < P.chklen * d) fill = capacity - 1 - (int)N + me.end;
+  const int top = fill;
+  while (pos > 2 && fill >= 0) {
+    --pos;
+    const int v = A[pos];
+    if (skip_value(v)) continue;
+    if (nb >= 0 && pos >= list[nb].start && pos <= list[nb].end) {   // jump over another candidate
+      pos = list[nb].start - 1;
+      --nb;
+      while (nb > 0 && list[nb].status == -9) --nb;
+      continue;
+    }
+    ref[fill--] = v;
+  }
+  int used;
+  if (fill >= 0) {   // ran out of sequence: close the gap at the front
+    used = 0;
+    for (int s = fill + 1; s <= top; ++s) ref[used++] = ref[s];
+  } else {
+    used = top + 1;
+  }
+  // right side, appended
+  pos = me.end + margin;
+  nb = ci + 1;
+  while (pos < N - 2 && nb < count && pos > list[nb].end) ++nb;
+  while (nb < count - 1 && list[nb].status == -9) ++nb;
+  while (pos < N - 2 && used < 2 * P.chklen * d) {
+    ++pos;
+    const int v = A[pos];
+    if (skip_value(v)) continue;
+    if (nb < count && pos >= list[nb].start && pos <= list[nb].end) {
+      pos = list[nb].end + 1;
+      ++nb;
+      while (nb < count - 1 && list[nb].status == -9) ++nb;
+      continue;
+    }
+    if (used >= capacity) break;
+    ref[used++] = v;
+  }
+  if (used < capacity) ref.resize((size_t)used);
+
+  std::vector<int> body((size_t)body_len);
+  for (int i = 0; i < body_len; ++i) body[i] = A[me.start + i];
+  const int total = (int)ref.size() + (int)body.size();
+  const int budget = P.maxchkbp * 10;
+  if (total > budget) {   // thin both proportionally (rsi.cpp:264-282)
+    const int nref = (int)((double)ref.size() / (double)total * (double)budget);
+    const int nbody = (int)((double)body.size() / (double)total * (double)budget);
+    std::vector<int> thin((size_t)nref);
+    for (int i = 0; i < nref; ++i) thin[i] = ref[(size_t)(int)(double(i) / double(nref) * double(ref.size()))];
+    ref.swap(thin);
+    thin.assign((size_t)nbody, 0);
+    for (int i = 0; i < nbody; ++i) thin[i] = body[(size_t)(int)(double(i) / double(nbody) * double(body.size()))];
+    body.swap(thin);
+  }
+  judge(in, ref, body, list[ci]);
+}
+
+// ---- get_continuous_segments (rsi.cpp:291-327): runs of equal-sign marks, last run not emitted ----
+void marked_runs(const std::vector<int>& marks, std::vector<Candidate>& out) {
+  out.clear();
+  bool open = false;
+  int first = 0, last = 0;
+  for (int i = 0; i < (int)marks.size(); ++i) {
+    if (marks[i] == 0) continue;
+    if (!open) { first = last = i; open = true; continue; }
+    if ((double)marks[i] * (double)marks[last] > 0 && (i - last) <= 1) { last = i; continue; }
+    Candidate c; c.start = first; c.end = last;
+    out.push_back(c);
+    first = last = i;
+  }
+}
+
+// ---- multisegments (rsi.cpp:368-410): nested level sets of a rejected segment ----
+void nested_levels(const Candidate& seg, const std::vector<int>& status, std::vector<Candidate>& out) {
+  out.clear();
+  const int len = seg.end - seg.start + 1;
+  int lo = status[seg.start], hi = status[seg.start];
+  for (int i = 0; i < len; ++i) { lo = std::min(lo, status[seg.start + i]); hi = std::max(hi, status[seg.start + i]); }
+  std::vector<int> member((size_t)len);
+  std::vector<Candidate> runs;
+  for (int level = lo; level < hi; ++level) {
+    if (level == 0) continue;
+    bool present = false;
+    for (int i = 0; i < len; ++i) {
+      const int s = status[seg.start + i];
+      member[i] = 0;
+      if (s == 0) continue;
+      if (s == level) present = true;
+      if (level < 0 && s < 0 && s >= level) member[i] = 1;
+      if (level > 0 && s > 0 && s <= level) member[i] = 1;
+    }
+    if (!present) continue;
+    marked_runs(member, runs);
+    for (Candidate& r : runs) {
+      r.start = std::max(r.start + seg.start, seg.start);
+      r.end = std::min(r.end + seg.start, seg.end);
+      out.push_back(r);
+    }
+  }
+}
+
+// ---- sortcnvstartposition (rsi.cpp:549-577): stable by start (arrayindex_tp is a stable gnome sort) ----
+void order_by_start(std::vector<Candidate>& L) {
+  for (Candidate& c : L) if (c.start > c.end) std::swap(c.start, c.end);
+  std::stable_sort(L.begin(), L.end(), [](const Candidate& a, const Candidate& b) { return a.start < b.start; });
+}
+
+// ---- optimize_with_derivative (rsi.cpp:889-944) ----
+template <class View>
+void sharpen_edges(const View& A, Candidate& c) {
+  const int len = c.end - c.start + 1;
+  const int reach = std::max(250, len / 4);
+  const int from = c.start - reach, to = c.end + reach;
+  if (from < 2 * len) return;
+  if (to > A.size() - 2 * len) return;
+  A.prefetch((int64_t)from - len - 1, (int64_t)to + len + 1);
+  std::vector<double> step;
+  step.reserve((size_t)(to - from));
+  double diff = 0.0;
+  for (int k = from - len; k < from; ++k) diff += A[k];
+  for (int k = from; k < from + len; ++k) diff -= A[k];
+  step.push_back(diff);
+  for (int i = from + 1; i < to; ++i) {
+    diff = diff - A[i - 1 - len] + A[i - 1] + A[i - 1] - A[i - 1 + len];
+    step.push_back(diff);
+  }
+  const int nstep = (int)step.size();
+  int best = -1; double ext = 0;
+  for (int i = 0; i < 2 * reach; ++i) {
+    if (c.type == kDel && step[i] > ext) { ext = step[i]; best = i; }
+    if (c.type == kDup && step[i] < ext) { ext = step[i]; best = i; }
+  }
+  if (best > 0) c.start = from + best;
+  best = -1; ext = 0;
+  for (int i = nstep - 2 * reach; i < nstep; ++i) {
+    if (c.type == kDel && step[i] < ext) { ext = step[i]; best = i; }
+    if (c.type == kDup && step[i] > ext) { ext = step[i]; best = i; }
+  }
+  if (best > 0) c.end = to - nstep + best;
+}
+
+template <class View>
+double range_mean(const View& A, int lo, int hi) {   // mean_tp, wufunctions.cpp:666-690
+  A.prefetch(lo, hi);
+  double s = 0;
+  for (int i = lo; i <= hi; ++i) s += (double)A[i];
+  return s / double(hi - lo + 1);
+}
+
+void drop_deleted(std::vector<Candidate>& L) {
+  std::vector<Candidate> keep;
+  for (const Candidate& c : L) if (c.status != -9) keep.push_back(c);
+  L.swap(keep);
+}
+
+// ---- mergesegments (rsi.cpp:694-885) ----
+template <class View>
+void merge_neighbours(const CallerInput& in, const View& A, std::vector<Candidate>& L) {
+  const rsi_params& P = in.P;
+  std::vector<Candidate> T;
+  // overlapping neighbours of one type
+  for (int i = 0; i + 1 < (int)L.size(); ++i) {
+    if (L[i].type != L[i + 1].type) continue;
+    if (!(std::max(L[i].start, L[i + 1].start) < std::min(L[i].end, L[i + 1].end))) continue;
+    Candidate joined = L[i];
+    joined.start = std::min(L[i].start, L[i + 1].start);
+    joined.end = std::max(L[i].end, L[i + 1].end);
+    T = L; T[i] = joined; T[i + 1] = joined; T[i + 1].status = -9;
+    test_candidate(in, A, T, i);
+    if (T[i].geno == 0) {   // the union fails: test each on its own
+      T = L; T[i + 1].status = -9;
+      test_candidate(in, A, T, i);
+      T[i].status = -9; T[i + 1].status = 0;
+      test_candidate(in, A, T, i + 1);
+      if (T[i + 1].p1 < T[i].p1) T[i] = T[i + 1];
+      if (T[i].p1 > P.p) { L[i].status = -9; L[i + 1].status = -9; }
+    }
+    if (T[i].geno == 0) continue;
+    L[i] = T[i]; L[i].status = -9;
+    L[i + 1] = T[i]; L[i + 1].status = 0;
+  }
+  drop_deleted(L);
+  if (!P.merge) return;
+  // nearby neighbours of one type
+  for (int i = 0; i + 1 < (int)L.size(); ++i) {
+    if (L[i].type != L[i + 1].type) continue;
+    if (L[i].geno == 0 || L[i + 1].geno == 0) continue;
+    const int gap = L[i + 1].start - L[i].end;
+    const int w1 = L[i].end - L[i].start, w2 = L[i + 1].end - L[i + 1].start;
+    if (gap > w1 * P.chklen * 0.7 && gap > w2 * P.chklen * 0.7) continue;
+    const double m1 = range_mean(A, L[i].start, L[i].end), m2 = range_mean(A, L[i + 1].start, L[i + 1].end);
+    const double both = (m1 * w1 + m2 * w2) / (w1 + w2);
+    const double across = range_mean(A, L[i].start, L[i + 1].end);
+    if (L[i].type == kDel && across > both + 1.5 * L[i + 1].refsd + 1.5 * L[i].refsd) continue;
+    if (L[i].type == kDup && across < both - 1.5 * L[i + 1].refsd - 1.5 * L[i].refsd) continue;
+    Candidate joined = L[i];
+    joined.end = L[i + 1].end;
+    T = L; T[i] = joined; T[i + 1] = joined; T[i + 1].status = -9;
+    test_candidate(in, A, T, i);
+    if (T[i].geno == 0) continue;
+    L[i] = T[i]; L[i + 1] = T[i]; L[i].status = -9;
+  }
+  drop_deleted(L);
+}
+
+// ---- expand_coordinate (rsi.cpp:1524-1551): compacted index -> reference index ----
+int to_reference(const std::vector<Region>& noncode, int p) {
+  int removed = 0;
+  for (const Region& r : noncode) {
+    const int grown = removed + (r.end - r.start + 1);
+    if (p < r.end + 1 - grown) break;
+    removed = grown;
+  }
+  return p + removed;
+}
+
+}  // namespace
+
+// ---- areblockscnv (rsi.cpp:415-546) ----
+void test_block_segments(const CallerInput& in, const std::vector<int>& status, std::vector<Candidate>& segs) {
+  const VecView bins{in.binmedint};
+  std::vector<Candidate> T = segs;
+  for (int i = 0; i < (int)T.size(); ++i) test_candidate(in, bins, T, i);
+  for (int i = 0; i < (int)T.size(); ++i) {
+    if (T[i].status != -9) continue;
+    if (T[i].type == kDel && T[i].cnvmed < 0.7 * T[i].refmed) { T[i].geno = 1; T[i].p1 = in.P.p; continue; }
+    if (T[i].type == kDup && T[i].cnvmed > 1.3 * T[i].refmed) { T[i].geno = 1; T[i].p1 = in.P.p; continue; }
+    const Candidate original = T[i];
+    Candidate chosen = T[i];
+    std::vector<Candidate> levels;
+    nested_levels(chosen, status, levels);
+    for (int j = (int)levels.size() - 1; j >= 0; --j) {
+      levels[j].type = chosen.type;
+      T[i] = levels[j];
+      test_candidate(in, bins, T, i);
+      levels[j] = T[i];
+    }
+    for (int j = (int)levels.size() - 1; j >= 0; --j) {
+      if (levels[j].geno == 0) continue;
+      if (chosen.geno == 0) chosen = levels[j];
+      if (levels[j].length > chosen.length) chosen = levels[j];
+    }
+    if (chosen.geno == 0) chosen = original;
+    T[i] = chosen;
+  }
+  segs.swap(T);
+}
+
+// ---- detectcnv after the block tests (rsi.cpp:1860-1931), then sd_filters (rsi.cpp:1753-1792) ----
+void call_from_segments(const CallerInput& in, std::vector<Candidate> segs, DepthPager& depth,
+                        std::vector<Candidate>& blocks, std::vector<Candidate>& raw, std::vector<Candidate>& kept) {
+  const rsi_params& P = in.P;
+  const PagedView bases{&depth};
+  const int m = P.m, np = (int)in.ncompact;
+  order_by_start(segs);
+  blocks = segs;
+  std::vector<Candidate> L;
+  for (Candidate c : segs) {
+    if (c.geno == 0 || c.start == c.end) continue;
+    c.start = c.start * m + m / 2;   // bins -> bases (rsi.cpp:1868-1872)
+    c.end = c.end * m + m / 2;
+    if (c.start < 0) c.start = 0;
+    if (c.end > np - 1) c.end = np - 1;
+    c.length = c.end - c.start + 1;
+    L.push_back(c);
+  }
+  for (int pass = 0; pass < 2; ++pass) for (Candidate& c : L) sharpen_edges(bases, c);
+  order_by_start(L);
+  merge_neighbours(in, bases, L);
+  order_by_start(L);
+  raw.clear();
+  for (int i = 0; i < (int)L.size(); ++i) {
+    const double nbins = double(L[i].end - L[i].start + 1) / double(m);
+    test_candidate(in, bases, L, i);
+    L[i].score = (L[i].cnvmed - in.RDmedian) * sqrt(nbins);
+    const int r1 = to_reference(*in.noncode, L[i].start), r2 = to_reference(*in.noncode, L[i].end);
+    for (const Region& g : *in.noncode) if (std::max(r1, g.start) <= std::min(r2, g.end)) L[i].status = -9;
+    if (L[i].status != -9) raw.push_back(L[i]);
+  }
+  for (Candidate& c : raw) { c.start = to_reference(*in.noncode, c.start); c.end = to_reference(*in.noncode, c.end); }
+
+  kept.clear();
+  const int minlen = std::max(m * 2, 500);
+  const double sd = in.RDsd / 1.2;
+  for (const Candidate& c : raw) {
+    const int span = abs(c.end - c.start);
+    bool keep = !(span < 1000);
+    if (c.type == kDel) {
+      if (c.p1 > 0.2 || c.refsd > 0.6 * sd || c.cnvsd > 1.3 * sd) keep = false;
+      if (c.cnvsd * in.RDmedian > 2.5 * c.cnvmed * sd) keep = false;
+      if (c.cnvmed < 0.66 * std::min(in.RDmedian, c.refmed) && c.cnvsd < sd && span > 800) keep = true;
+    }
+    if (c.type == kDup) {
+      if (c.p1 > 0.05 || c.refsd > 0.6 * sd) keep = false;
+      if (c.cnvsd * in.RDmedian > 2.0 * c.cnvmed * sd) keep = false;
+    }
+    if (span < minlen) keep = false;
+    if (keep) kept.push_back(c);
+  }
+}
+
+}  // namespace rsih

@@ -1,0 +1,123 @@
+// kernels.h -- launch wrappers of the gfx950 kernels behind librsi_hot.so.
+// Every wrapper enqueues on `stream` and returns without synchronising.  Pointers are device
+// pointers unless the name says otherwise.  Kernel list and the roofline that bounds each one:
+// DESIGN.md section 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsik {
+
+constexpr int kGcLevels = 202;        // window GC count 0..201 (gccontent.cpp:102, 115)
+constexpr int kHistValues = 65536;    // directly indexed integer histogram range
+constexpr int kResClasses = 32;       // 31 MAD residues (rsi.cpp:1130) + 1 class for the tail
+constexpr int kTileBases = 4096;      // bases per workgroup tile in the streaming kernels
+
+// ---- K1: FASTA bytes -> GC bitmask + N bitmask (loaddata.cpp:481-483; readref.cpp:95) ----
+// gcbits/nbits hold nwords = n/64 + 1 words, bit j of word w <-> base 64*w + j, zero beyond n.
+void launch_fasta_classify(const uint8_t* fasta, int64_t n, uint64_t* gcbits, uint64_t* nbits, int64_t nwords,
+                           hipStream_t stream);
+// ---- K1b: run boundaries of the N bitmask -> unordered list of (pos << 1 | is_end) ----
+void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
+                          hipStream_t stream);
+
+// ---- K2: GC table accumulation (checkgccontent pass 1, gccontent.cpp:105-145) ----
+struct GcAccum {
+  unsigned long long sum[kGcLevels];   // sum of depth per window GC count
+  unsigned long long cnt[kGcLevels];
+  unsigned long long possum, poscnt;   // over depth > 0
+  unsigned int negatives;              // depth < 0 seen (unsupported)
+  unsigned int pad;
+};
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, hipStream_t stream);
+
+// ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
+// table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
+// adjust=0 copies depth through unchanged (the -NOGC path only needs the histogram).
+// hist[kHistValues] counts output values < kHistValues; *big counts the rest, *vmax their maximum.
+struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int negatives; };
+void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
+// Tail quirks of the 20-slice write-back, fixes out[] and hist[] in place.
+void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+                          int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
+
+// ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
+// (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;
+//  median_transfer rsi.cpp:1363; bin sums + MAD subsamples rsi.cpp:1127-1157)
+struct BinAccum {
+  unsigned long long sum;        // sum of capped compacted values
+  unsigned long long sq_lo;      // sum of (v*v) & 0xffffffff
+  unsigned long long sq_hi;      // sum of (v*v) >> 32
+  unsigned long long big;        // values >= kHistValues (not in the histograms)
+  unsigned int vmax;
+  unsigned int pad;
+};
+// cbreak[k]: compacted index where region k is cut out; cum[k]: bases removed before compacted
+// index cbreak[k] (cum[nreg] = total).  res_hist: [kHistValues][kResClasses] counts of value by
+// class (compacted index mod 31, or 31 for the tail beyond 31*floor(n'/31)).
+void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
+                            int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
+                            uint32_t* res_hist, BinAccum* acc, hipStream_t stream);
+
+// ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
+// raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =
+// min over bins as float bits (values are >= 0).
+void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, double r, float* raw,
+                   uint32_t* rawmin_bits, hipStream_t stream);
+// x = (float)(raw - tmin); x = (float)(x / med_nbt * med); bins 0..2 <- lev[0..2]
+void launch_nb_scale(float* x, int64_t nb, double tmin, double med_nbt, double med, float lev0, float lev1, float lev2,
+                     hipStream_t stream);
+void launch_i32_to_f32(const int32_t* in, float* out, int64_t nb, hipStream_t stream);
+
+// ---- K6: 0.01-grid histogram quantiles of float arrays (partition_stat_tp, wufunctions.cpp:364) ----
+struct MinMaxF { uint32_t min_bits, max_bits; unsigned int nonfinite; unsigned int pad; };   // non-negative floats
+// min/max over x[i] (or |x[i]-center| rounded to float when use_abs), restricted to mask[i]==0 when mask != NULL
+void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
+                       hipStream_t stream);
+// hist[(size_t)((v - ymin)/0.01 + 0.5)] += 1, same selection as above; hist has np entries
+void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin,
+                     uint32_t* hist, uint32_t np, hipStream_t stream);
+
+// ---- K7: RSI scan (rsistatus, rsi.cpp:1191-1259; runmeantp wufunctions.cpp:573-647) ----
+struct ScanParams {
+  int64_t nb;
+  int32_t Lmax;
+  int32_t pad;
+  double tmedian;
+  double lim_del;    // 0.75 * RDmedian
+  double lim_dup;    // 1.25 * RDmedian
+};
+// thr_del[L], thr_dup[L] (L = 1..Lmax, index L): a window of length L is a DEL hit iff
+// sum <= thr_del[L], a DUP hit iff sum >= thr_dup[L] (host-derived, see scan_thresholds()).
+// first_del / first_dup: smallest L that marks the bin, 0xffffffff when none.  counters[0] = trim
+// escapes, counters[1] = values breaking the exact-sum precondition.
+void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del,
+                     const double* thr_dup, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
+                     hipStream_t stream);
+// histogram of first_del over L (hist[L], L <= Lmax)
+void launch_level_hist(const uint32_t* first, const uint32_t* exclude, uint32_t exclude_max, int64_t nb, int32_t Lmax,
+                       uint32_t* hist, hipStream_t stream);
+// status[j] = -first_del[j] if first_del[j] <= ldel; else +first_dup[j] if <= ldup; else 0
+void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, uint32_t ldel, uint32_t ldup,
+                           int64_t nb, int32_t* status, hipStream_t stream);
+
+// ---- K9/K10: marked runs and max-score sub-segment (get_continuous_segments rsi.cpp:291;
+//      get_rsi_segments rsi.cpp:1060) ----
+// run starts/ends appended unordered: list entries (start << 32 | end), count
+void launch_find_runs(const int32_t* status, int64_t nb, uint64_t* runs, uint32_t* count, uint32_t cap,
+                      hipStream_t stream);
+struct BestSeg { double score; int32_t start; int32_t len; };
+struct SegItem { int32_t run; int32_t len; int32_t Lbeg; int32_t Lend; };   // lengths [Lbeg, Lend) of one run
+// exact double prefix of every run into scratch + poff[run] (len+1 entries), one workgroup per run
+void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, int nruns, const int64_t* poff,
+                       double* scratch, hipStream_t stream);
+// one workgroup per work item; out[item] = best (score, offset, L) of that item under the
+// reference's visiting order (larger score, then smaller L, then smaller offset)
+void launch_best_items(const void* items, int nitems, const int64_t* poff, const double* scratch, double tmedian, BestSeg* out,
+                       hipStream_t stream);
+// edge trimming of filterstatus (rsi.cpp:1023-1044): one thread per run
+void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, int nruns,
+                      double delthr, double addthr, hipStream_t stream);
+
+}  // namespace rsik

@@ -1,0 +1,828 @@
+// pipeline.hip -- the per-chromosome pipeline behind include/rsi_hot.h: device workspace, kernel
+// sequencing with the global-reduction barriers of the path (GC table -> cap median -> chromosome
+// median/MAD -> NB minimum -> scan thresholds), the small host decisions between kernels, and the
+// C ABI.  There is no CPU fallback anywhere in this file: every array-sized computation is a
+// kernel from kernels_base.hip / kernels_bin.hip; the host only walks device-built histograms and
+// runs the candidate stages (host_calls.cpp).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/rsi_hot.h"
+#include "host_calls.h"
+#include "hostmath.h"
+#include "kernels.h"
+
+using namespace rsik;
+using rsih::Candidate;
+using rsih::Region;
+
+namespace {
+
+std::string g_last_error;
+
+struct DevBuf {   // grow-only device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct KernelTime { const char* name; hipEvent_t a, b; };
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct rsi_result {
+  std::vector<rsi_call> lists[4];
+  std::vector<int32_t> noncode;   // pairs
+  rsi_chrom_stats stats;
+  rsi_params params;
+};
+
+struct rsi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool timing = false;
+  std::vector<KernelTime> ktimes;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+  // workspace
+  DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
+  DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del, first_dup;
+  DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
+  // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
+  int64_t n = 0, ncompact = 0, nb = 0;
+  bool have_gc = false, have_nb = false, have_med = false;
+  int last_scan_med = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);                          \
+      g_last_error = ctx->err;                                                                \
+      return RSI_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+int fail(rsi_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_last_error = msg;
+  return code;
+}
+
+// offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
+constexpr size_t kOffGcAcc = 0;                                   // GcAccum
+constexpr size_t kOffValAux = 4096;                               // ValueHistAux
+constexpr size_t kOffBinAcc = 4352;                               // BinAccum
+constexpr size_t kOffMinMax = 4608;                               // MinMaxF
+constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
+constexpr size_t kOffRawMin = 5120;                               // uint32
+constexpr size_t kOffTable = 5376;                                // double[202]
+constexpr size_t kOffLevelHist = 8192;                            // uint32[4096]
+constexpr size_t kOffBreaks = 8192 + 16384;                       // int64 cbreak[4096], cum[4097]
+constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
+constexpr int kMaxRegions = 4096;
+constexpr uint32_t kMaxTransitions = 1u << 16;
+constexpr uint32_t kMaxRunEntries = 1u << 20;
+constexpr int kMaxL = 2048;
+
+struct Timer {   // optional HIP-event bracket around one launch
+  rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  Timer(rsi_ctx* c, const char* nm) : ctx(c), name(nm) {
+    if (!ctx->timing) return;
+    auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~Timer() { if (a) { (void)hipEventRecord(b, ctx->stream); ctx->ktimes.push_back({name, a, b}); } }
+};
+
+// Device-built integer histogram -> rsih::Quantiles
+bool int_quantiles(const std::vector<uint64_t>& h, uint64_t total, rsih::Quantiles& q) {
+  return rsih::hist_quantiles_int(h.data(), h.size(), total, q);
+}
+
+struct ScanOut {
+  double tmedian1 = 0, tsigma1 = 0, tlamda1 = 0, tmedian2 = 0, tsigma2 = 0, tlamda2 = 0;
+  int Lmax = 0;
+  std::vector<int> status2;
+  std::vector<Candidate> segs;
+  uint32_t escapes = 0, inexact = 0;
+};
+
+// 0.01-grid median of the selected values of a device float array (partition_stat_tp semantics)
+int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, int use_abs, double center,
+                double* med, uint64_t* count) {
+  uint8_t* small = ctx->small.as<uint8_t>();
+  MinMaxF init{0xffffffffu, 0u, 0u, 0u};
+  HIPCHK(hipMemcpyAsync(small + kOffMinMax, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  { Timer t(ctx, "minmax_f32"); launch_minmax_f32(d_x, d_mask, nb, use_abs, center, reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->stream); }
+  MinMaxF mm;
+  HIPCHK(hipMemcpyAsync(&mm, small + kOffMinMax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (mm.min_bits == 0xffffffffu) { *count = 0; *med = 0; return RSI_OK; }
+  if (mm.nonfinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
+  auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
+  const double ymin = unkey(mm.min_bits), ymax = unkey(mm.max_bits);
+  if ((ymax - ymin) < 0.01)
+    return fail(ctx, RSI_ERR_UNSUPPORTED, "degenerate transform: all selected bins within 0.01 (the reference returns their mean)");
+  const size_t np = (size_t)((ymax - ymin) / 0.01 + 2);
+  if (np > (64u << 20)) return fail(ctx, RSI_ERR_UNSUPPORTED, "transformed bin range too wide for the 0.01 grid");
+  HIPCHK(ctx->hist_f.ensure(np * 4));
+  HIPCHK(hipMemsetAsync(ctx->hist_f.p, 0, np * 4, ctx->stream));
+  { Timer t(ctx, "hist_f32"); launch_hist_f32(d_x, d_mask, nb, use_abs, center, ymin, ctx->hist_f.as<uint32_t>(), (uint32_t)np, ctx->stream); }
+  std::vector<uint32_t> h(np);
+  HIPCHK(hipMemcpyAsync(h.data(), ctx->hist_f.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  uint64_t total = 0;
+  for (uint32_t c : h) total += c;
+  *count = total;
+  *med = rsih::hist_median_grid(h.data(), np, total, ymin);
+  return RSI_OK;
+}
+
+// Per-L thresholds on the exact window sum equivalent to the reference's score tests
+// (rsi.cpp:1204-1205, 1234-1235 with runmeantp's float mean, wufunctions.cpp:625-627).
+void scan_thresholds(double tmedian, double tlamda, int Lmax, std::vector<double>& del, std::vector<double>& dup) {
+  del.assign((size_t)Lmax + 1, -1.0);
+  dup.assign((size_t)Lmax + 1, INFINITY);
+  for (int L = 1; L <= Lmax; ++L) {
+    const double dL = (double)L, sq = sqrt(dL);
+    auto score = [&](double sum) { const float meanf = (float)(sum / dL); return ((double)meanf - tmedian) * sq; };
+    del[L] = rsih::last_true([&](double s) { return !(score(s) > -tlamda); });
+    dup[L] = rsih::first_true([&](double s) { return !(score(s) < tlamda); });
+  }
+}
+
+// Collect (pos << 1 | is_end) boundary entries from the device into sorted [start, end] pairs.
+int fetch_pairs(rsi_ctx* ctx, const uint64_t* d_list, const uint32_t* d_count, uint32_t cap, std::vector<Region>& out,
+                bool end_exclusive) {
+  uint32_t cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  out.clear();
+  if (cnt == 0) return RSI_OK;
+  if (cnt > cap) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
+  std::vector<uint64_t> raw(cnt);
+  HIPCHK(hipMemcpyAsync(raw.data(), d_list, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int64_t> s, e;
+  for (uint64_t v : raw) ((v & 1) ? e : s).push_back((int64_t)(v >> 1));
+  if (s.size() != e.size()) return fail(ctx, RSI_ERR_INTERNAL, "unbalanced run boundaries");
+  std::sort(s.begin(), s.end());
+  std::sort(e.begin(), e.end());
+  for (size_t i = 0; i < s.size(); ++i) out.push_back({(int)s[i], (int)(e[i] - (end_exclusive ? 1 : 0))});
+  return RSI_OK;
+}
+
+// Marked runs of a device status array in the reference's sense (last run not emitted, Q11).
+int marked_runs_device(rsi_ctx* ctx, const int32_t* d_status, int64_t nb, std::vector<Region>& runs) {
+  uint8_t* small = ctx->small.as<uint8_t>();
+  uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
+  HIPCHK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+  { Timer t(ctx, "find_runs"); launch_find_runs(d_status, nb, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, ctx->stream); }
+  int rc = fetch_pairs(ctx, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, runs, false);
+  if (rc != RSI_OK) return rc;
+  if (!runs.empty()) runs.pop_back();
+  return RSI_OK;
+}
+
+int upload_runs(rsi_ctx* ctx, const std::vector<Region>& runs, int32_t** d_start, int32_t** d_end) {
+  const size_t k = runs.size();
+  HIPCHK(ctx->run_se.ensure(k * 8 + 64));
+  std::vector<int32_t> se(2 * k);
+  for (size_t i = 0; i < k; ++i) { se[i] = runs[i].start; se[k + i] = runs[i].end; }
+  HIPCHK(hipMemcpyAsync(ctx->run_se.p, se.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // se goes out of scope
+  *d_start = ctx->run_se.as<int32_t>();
+  *d_end = ctx->run_se.as<int32_t>() + k;
+  return RSI_OK;
+}
+
+// One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status
+int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
+              double tlamda, int Lmax, int32_t* d_status, uint32_t* escapes, uint32_t* inexact) {
+  uint8_t* small = ctx->small.as<uint8_t>();
+  std::vector<double> del, dup;
+  scan_thresholds(tmedian, tlamda, Lmax, del, dup);
+  HIPCHK(ctx->thr.ensure((size_t)(Lmax + 1) * 16));
+  double* d_del = ctx->thr.as<double>();
+  double* d_dup = d_del + (Lmax + 1);
+  HIPCHK(hipMemcpyAsync(d_del, del.data(), (size_t)(Lmax + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_dup, dup.data(), (size_t)(Lmax + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* d_counters = reinterpret_cast<uint32_t*>(small + kOffCounters);
+  HIPCHK(hipMemsetAsync(d_counters, 0, 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->first_del.p, 0xff, (size_t)nb * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->first_dup.p, 0xff, (size_t)nb * 4, ctx->stream));
+  ScanParams sp;
+  sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
+  sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
+  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, ctx->first_del.as<uint32_t>(), ctx->first_dup.as<uint32_t>(), d_counters, ctx->stream); }
+  // which L does each sweep stop at? (portion > 0.2 after marking with L, rsi.cpp:1225, 1255)
+  uint32_t* d_lh = reinterpret_cast<uint32_t*>(small + kOffLevelHist);
+  std::vector<uint32_t> lh((size_t)Lmax + 1);
+  auto stop_level = [&](uint32_t& level) {
+    uint64_t cum = 0;
+    level = (uint32_t)Lmax;
+    for (int L = 1; L <= Lmax; ++L) {
+      cum += lh[L];
+      if (double((int)cum) / double((int)nb) > 0.2) { level = (uint32_t)L; break; }
+    }
+  };
+  uint32_t ldel = 0, ldup = 0;
+  HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
+  { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_del.as<uint32_t>(), nullptr, 0, nb, Lmax, d_lh, ctx->stream); }
+  HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  stop_level(ldel);
+  HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
+  { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_dup.as<uint32_t>(), ctx->first_del.as<uint32_t>(), ldel, nb, Lmax, d_lh, ctx->stream); }
+  HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t cnts[2];
+  HIPCHK(hipMemcpyAsync(cnts, d_counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  stop_level(ldup);
+  *escapes += cnts[0];
+  *inexact = cnts[1];
+  { Timer t(ctx, "resolve_status"); launch_resolve_status(ctx->first_del.as<uint32_t>(), ctx->first_dup.as<uint32_t>(), ldel, ldup, nb, d_status, ctx->stream); }
+  return RSI_OK;
+}
+
+// rsicnvnbn (rsi.cpp:1262-1360) / rsicnvmed (rsi.cpp:1402-1501) around the device scan
+int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, int64_t nb, double RDmedian,
+             double factor, int LmaxBase, float t0, float t2, ScanOut& out) {
+  const int32_t* d_medint = ctx->binmed.as<int32_t>();
+  double tmedian, tsigma, tlamda, target, dev, absmed;
+  uint64_t cnt;
+  int rc, cal_max;
+  if (!use_med) {
+    if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
+  } else {
+    tmedian = RDmedian;
+  }
+  if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
+  tsigma = absmed / 0.6745;
+  tlamda = factor * tsigma;
+  if (!use_med) {
+    target = (t2 - t0) * sqrt(2.5);                 // float difference, as RDtrans[2]-RDtrans[0]
+    tlamda = std::max(tlamda, target);
+    const double dnb = fabsf(t2 - t0) + 0.0001;
+    const double q = tlamda * 2 / dnb;
+    cal_max = (int)(q * q);
+    dev = tsigma * 3.0;
+  } else {
+    target = tmedian * sqrt(2.0);
+    tlamda = std::max(tlamda, target);
+    if (P.threshold > 0) tlamda = tmedian * P.threshold;
+    const double q = tlamda * 4 / (tmedian + 0.001);
+    cal_max = (int)(q * q);
+    dev = tmedian * 0.6;
+  }
+  int Lmax = LmaxBase;
+  if (Lmax < cal_max) Lmax = cal_max;
+  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond the LDS tile limit (2048)");
+  if (Lmax > nb) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length (the reference exits in runmean)");
+  out.tmedian1 = tmedian; out.tsigma1 = tsigma; out.tlamda1 = tlamda; out.Lmax = Lmax;
+
+  int32_t* d_st1 = ctx->status1.as<int32_t>();
+  int32_t* d_st1f = ctx->status1f.as<int32_t>();
+  int32_t* d_st2 = ctx->status2.as<int32_t>();
+  if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc;
+
+  // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
+  // definition (App. A Q13) -> host; the edge trimming runs on the device, one thread per run ----
+  std::vector<float> hT((size_t)nb);
+  std::vector<int> hst((size_t)nb);
+  HIPCHK(hipMemcpyAsync(hT.data(), d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hst.data(), d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  {
+    int lo = hst[0], hi = hst[0];
+    for (int64_t i = 0; i < nb; ++i) { lo = std::min(lo, hst[i]); hi = std::max(hi, hst[i]); }
+    const int nl = hi - lo + 1;
+    std::vector<float> lsum((size_t)nl, 0.0f);
+    std::vector<int> lcnt((size_t)nl, 0);
+    for (int64_t i = 0; i < nb; ++i) { lsum[hst[i] - lo] += hT[i]; ++lcnt[hst[i] - lo]; }
+    for (int l = 0; l < nl; ++l) if (lcnt[l] != 0) lsum[l] /= (double)lcnt[l];
+    if (lo <= 0 && -lo < nl) {
+      const float m0 = lsum[-lo];
+      int leveldel = lo, leveladd = hi;
+      for (int l = 0; l < nl; ++l) if (lsum[l] < m0 - dev) { leveldel = l + lo; break; }
+      for (int l = nl - 1; l >= 0; --l) if (lsum[l] > m0 + dev) { leveladd = l + lo; break; }
+      if (!(leveldel > 0 || leveladd < 0 || leveldel > leveladd)) {
+        std::vector<Region> runs;
+        if ((rc = marked_runs_device(ctx, d_st1, nb, runs)) != RSI_OK) return rc;
+        if (!runs.empty()) {
+          int32_t *d_rs, *d_re;
+          if ((rc = upload_runs(ctx, runs, &d_rs, &d_re)) != RSI_OK) return rc;
+          Timer t(ctx, "trim_runs");
+          launch_trim_runs(d_T, d_st1f, d_rs, d_re, (int)runs.size(), (double)m0 - dev, (double)m0 + dev, ctx->stream);
+        }
+      }
+    }
+  }
+  // ---- second-pass parameters on the unmarked bins (rsi.cpp:1307-1319 / 1457-1469) ----
+  double tmed2;
+  uint64_t k = 0;
+  if ((rc = grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k)) != RSI_OK) return rc;
+  if (k > (uint64_t)(nb / 2)) {
+    tmedian = tmed2;
+    if ((rc = grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
+    tsigma = absmed / 0.6745;
+    tlamda = factor * tsigma;
+    tlamda = std::max(tlamda, target);
+  }
+  out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
+  if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc;
+
+  // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
+  out.status2.resize((size_t)nb);
+  HIPCHK(hipMemcpyAsync(out.status2.data(), d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<Region> runs;
+  if ((rc = marked_runs_device(ctx, d_st2, nb, runs)) != RSI_OK) return rc;   // synchronises
+  out.segs.clear();
+  if (runs.empty()) return RSI_OK;
+  int32_t *d_rs, *d_re;
+  if ((rc = upload_runs(ctx, runs, &d_rs, &d_re)) != RSI_OK) return rc;
+  std::vector<int64_t> poff(runs.size() + 1, 0);
+  std::vector<SegItem> items;
+  const int64_t kPairsPerItem = 1 << 21;
+  for (size_t r = 0; r < runs.size(); ++r) {
+    const int len = runs[r].end - runs[r].start + 1;
+    poff[r + 1] = poff[r] + len + 1;
+    int L = 1;
+    while (L <= len) {   // chunks of lengths with about kPairsPerItem (L, offset) pairs
+      int64_t pairs = 0; int Le = L;
+      while (Le <= len && pairs < kPairsPerItem) { pairs += len - Le + 1; ++Le; }
+      items.push_back({(int32_t)r, (int32_t)len, (int32_t)L, (int32_t)Le});
+      L = Le;
+    }
+  }
+  HIPCHK(ctx->scratch.ensure((size_t)poff.back() * 8 + (runs.size() + 1) * 8));
+  double* d_scratch = ctx->scratch.as<double>();
+  int64_t* d_poff = reinterpret_cast<int64_t*>(d_scratch + poff.back());
+  HIPCHK(ctx->items.ensure(items.size() * sizeof(SegItem)));
+  HIPCHK(ctx->best.ensure(items.size() * sizeof(BestSeg)));
+  HIPCHK(hipMemcpyAsync(d_poff, poff.data(), poff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->items.p, items.data(), items.size() * sizeof(SegItem), hipMemcpyHostToDevice, ctx->stream));
+  { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, d_rs, d_re, (int)runs.size(), d_poff, d_scratch, ctx->stream); }
+  { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
+  std::vector<BestSeg> best(items.size());
+  HIPCHK(hipMemcpyAsync(best.data(), ctx->best.p, items.size() * sizeof(BestSeg), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<BestSeg> per_run(runs.size(), BestSeg{-1.0, 0, 0});
+  for (size_t i = 0; i < items.size(); ++i) {   // items of a run are in increasing L: strict > keeps the earliest
+    BestSeg& b = per_run[(size_t)items[i].run];
+    if (best[i].score > b.score) b = best[i];
+  }
+  for (size_t r = 0; r < runs.size(); ++r) {
+    Candidate c;
+    const int len = runs[r].end - runs[r].start + 1;
+    double sc = per_run[r].score;
+    if (sc > 0) { c.start = runs[r].start + per_run[r].start; c.end = c.start + per_run[r].len - 1; }
+    else { c.start = runs[r].start; c.end = runs[r].start + len - 1; sc = 0; }
+    const rsih::Quantiles q = rsih::grid_quantiles(out.status2.data() + c.start, (size_t)(c.end - c.start + 1));
+    if (q.med > 0) { c.type = rsih::kDup; c.score = sc; } else { c.type = rsih::kDel; c.score = -sc; }
+    if (fabs(c.score) < tlamda * 0.5) continue;   // rsi.cpp:1343-1346
+    out.segs.push_back(c);
+  }
+  return RSI_OK;
+}
+
+void to_call(const Candidate& c, rsi_call* o) {
+  memset(o, 0, sizeof(*o));
+  o->start = c.start; o->end = c.end; o->type = c.type; o->geno = c.geno; o->status = c.status; o->length = c.length;
+  const double q1 = c.p1 < 1.0E-10 ? 99 : -10.0 * log(c.p1) / log(10.0);   // cnv_format1, rsi.cpp:583-585
+  o->qscore = (int)q1;
+  o->score = c.score; o->p1 = c.p1; o->cnvmed = c.cnvmed; o->cnvsd = c.cnvsd; o->cnviqr = c.cnviqr;
+  o->refmed = c.refmed; o->refsd = c.refsd; o->refiqr = c.refiqr;
+}
+
+int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n,
+                    rsi_result* res) {
+  const rsi_params& P = *Pp;
+  const double t_begin = now_ms();
+  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
+  if (P.m < 1 || (P.m % 2) != 1) return fail(ctx, RSI_ERR_BAD_ARG, "m must be odd (the reference forces it, rsi.cpp:2061-2064)");
+  if (P.m > 3000) return fail(ctx, RSI_ERR_UNSUPPORTED, "bin size above 3000 is not supported by the bin kernel");
+  if (((uintptr_t)d_depth & 15) || ((uintptr_t)d_fasta & 15)) return fail(ctx, RSI_ERR_BAD_ARG, "device inputs must be 16-byte aligned");
+  if (P.gcadjust && n / 20 <= 201)
+    return fail(ctx, RSI_ERR_TOO_SMALL, "size of RDA should be much larger than bin size (gccontent.cpp:66-71)");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->ktimes.clear();
+  ctx->event_next = 0;
+  ctx->n = n; ctx->ncompact = 0; ctx->nb = 0; ctx->have_gc = ctx->have_nb = ctx->have_med = false;
+  rsi_chrom_stats& S = res->stats;
+  memset(&S, 0, sizeof(S));
+  S.n = n;
+  res->params = P;
+  hipStream_t st = ctx->stream;
+  const int64_t nwords = n / 64 + 1;
+
+  HIPCHK(ctx->small.ensure(kSmallBytes));
+  HIPCHK(ctx->gcbits.ensure((size_t)nwords * 8));
+  HIPCHK(ctx->nbits.ensure((size_t)nwords * 8));
+  HIPCHK(ctx->ntrans.ensure((size_t)kMaxTransitions * 8));
+  HIPCHK(ctx->hist_val.ensure((size_t)kHistValues * 4));
+  uint8_t* small = ctx->small.as<uint8_t>();
+  HIPCHK(hipMemsetAsync(small, 0, kOffTable, st));
+
+  // ---- A1: GC mask, N runs (K1, K1b) ----
+  uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
+  { Timer t(ctx, "fasta_classify"); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
+  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, st); }
+  std::vector<Region> nruns;
+  int rc = fetch_pairs(ctx, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, nruns, true);
+  if (rc != RSI_OK) return rc;
+  std::vector<Region> noncode;   // get_noseq_regions, loaddata.cpp:243-273: pad, clamp, re-merge
+  {
+    const int dx = std::max(50, P.m / 4);
+    for (const Region& r : nruns) {
+      Region g{std::max(0, r.start - dx), (int)std::min<int64_t>(n - 1, (int64_t)r.end + dx)};
+      if (!noncode.empty() && g.start <= noncode.back().end + 1) noncode.back().end = std::max(noncode.back().end, g.end);
+      else noncode.push_back(g);
+    }
+  }
+  if ((int)noncode.size() > kMaxRegions) return fail(ctx, RSI_ERR_UNSUPPORTED, "more than 4096 N regions");
+  S.n_noncode = (int)noncode.size();
+  res->noncode.clear();
+  for (const Region& r : noncode) { res->noncode.push_back(r.start); res->noncode.push_back(r.end); }
+
+  // ---- A2/A3: GC table and rescale (K2, K3) ----
+  const int32_t* d_src = d_depth;
+  const bool want_cap = P.cap > 1;
+  if (P.gcadjust || want_cap) HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
+  ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
+  if (P.gcadjust) {
+    GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
+    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, st); }
+    GcAccum acc;
+    HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (acc.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
+    double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112
+    if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
+    double table[kGcLevels];
+    for (int g = 0; g < kGcLevels; ++g) {                     // gccontent.cpp:141-145
+      table[g] = acc.cnt[g] > 0 ? (double)acc.sum[g] / double(acc.cnt[g]) : rdmean;
+      if (table[g] < 1) table[g] = rdmean;
+    }
+    S.gc_rdmean = rdmean;
+    double* d_table = reinterpret_cast<double*>(small + kOffTable);
+    HIPCHK(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
+    { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+    { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+    HIPCHK(hipStreamSynchronize(st));   // table[] leaves scope
+    d_src = ctx->rd_gc.as<int32_t>();
+    ctx->have_gc = true;
+  } else if (want_cap) {
+    Timer t(ctx, "value_hist");
+    launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
+  }
+
+  // ---- A4: cap from the median of the uncompacted array (loaddata.cpp:229-240, Q15) ----
+  int32_t capval = 0x7fffffff;
+  if (want_cap) {
+    std::vector<uint32_t> h32(kHistValues);
+    ValueHistAux aux;
+    HIPCHK(hipMemcpyAsync(h32.data(), ctx->hist_val.p, (size_t)kHistValues * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&aux, d_aux, sizeof(aux), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
+    std::vector<uint64_t> h(h32.begin(), h32.end());
+    uint64_t inrange = 0;
+    for (uint64_t c : h) inrange += c;
+    if (inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
+    if ((uint64_t)n / 2 > inrange) return fail(ctx, RSI_ERR_UNSUPPORTED, "median depth above 65535");
+    rsih::Quantiles q;
+    int_quantiles(h, (uint64_t)n, q);
+    S.cap_median = q.med;
+    capval = (int32_t)(q.med * P.cap);   // RD[i] = RDmedian*cap, truncated (loaddata.cpp:238)
+  }
+
+  // ---- A5-A9: cap + compaction + bins + statistics (K4) ----
+  std::vector<int64_t> cbreak(noncode.size()), cum(noncode.size() + 1, 0);
+  for (size_t k = 0; k < noncode.size(); ++k) {
+    cbreak[k] = (int64_t)noncode[k].start - cum[k];
+    cum[k + 1] = cum[k] + (noncode[k].end - noncode[k].start + 1);
+  }
+  const int64_t ncompact = n - cum.back();
+  const int64_t nb = ncompact / P.m;
+  S.n_compact = ncompact; S.nbins = nb;
+  ctx->ncompact = ncompact; ctx->nb = nb;
+  if (ncompact <= 0 || nb < 8) return fail(ctx, RSI_ERR_TOO_SMALL, "nothing left after removing N regions");
+  int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
+  int64_t* d_cum = d_cbreak + 4100;
+  if (!noncode.empty()) HIPCHK(hipMemcpyAsync(d_cbreak, cbreak.data(), cbreak.size() * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(ctx->rdc.ensure((size_t)(ncompact + 4) * 4));
+  HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
+  HIPCHK(ctx->binsum.ensure((size_t)nb * 8));
+  HIPCHK(ctx->hist_res.ensure((size_t)kHistValues * kResClasses * 4));
+  const size_t res_vals = want_cap && capval < kHistValues - 1 ? (size_t)std::max(capval, 0) + 1 : (size_t)kHistValues;
+  HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, res_vals * kResClasses * 4, st));
+  BinAccum* d_bacc = reinterpret_cast<BinAccum*>(small + kOffBinAcc);
+  { Timer t(ctx, "cap_compact_bin"); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, st); }
+  BinAccum bacc;
+  std::vector<uint32_t> hres(res_vals * kResClasses);
+  HIPCHK(hipMemcpyAsync(&bacc, d_bacc, sizeof(bacc), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(hres.data(), ctx->hist_res.p, hres.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));   // also covers cbreak/cum going out of use
+  if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");
+  // chromosome median / SD (rsi.cpp:2202-2203)
+  std::vector<uint64_t> hall(res_vals, 0);
+  for (size_t v = 0; v < res_vals; ++v) for (int c = 0; c < kResClasses; ++c) hall[v] += hres[v * kResClasses + c];
+  rsih::Quantiles qall;
+  if (!int_quantiles(hall, (uint64_t)ncompact, qall)) return fail(ctx, RSI_ERR_INTERNAL, "empty depth histogram");
+  const double RDmedian = qall.med;
+  {
+    const double s1 = (double)bacc.sum;
+    const unsigned __int128 sq = ((unsigned __int128)bacc.sq_hi << 32) + bacc.sq_lo;
+    const double s2 = (double)sq;
+    const double mean = s1 / double((int)ncompact);
+    S.RDsd = sqrt(s2 / double((int)ncompact) - mean * mean);
+  }
+  S.RDmedian = RDmedian;
+  const double t_base_end = now_ms();
+  (void)t_base_end;
+
+  std::vector<Candidate> blocks, raw, kept, segs_all;
+  if (!(RDmedian < 5)) {   // rsi.cpp:1809-1812
+    // ---- A9: MAD of the 31 interleaved subsamples from their value histograms (rsi.cpp:1127-1143) ----
+    double mads[31];
+    const uint64_t sublen = (uint64_t)(ncompact / 31);
+    if (sublen == 0) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer than 31 bases");
+    for (int j = 0; j < 31; ++j) {
+      std::vector<uint64_t> hd(res_vals + 1, 0);
+      for (size_t v = 0; v < res_vals; ++v) {
+        const uint32_t c = hres[v * kResClasses + j];
+        if (!c) continue;
+        const int a = (int)fabs((float)(int)v - RDmedian);    // RDtmp[k]=abs((float)RD[i]-RDmedian), rsi.cpp:1134
+        hd[(size_t)a] += c;
+      }
+      rsih::Quantiles qd;
+      if (!int_quantiles(hd, sublen, qd)) return fail(ctx, RSI_ERR_INTERNAL, "empty MAD histogram");
+      mads[j] = qd.med;
+    }
+    const double mad = rsih::grid_quantiles(mads, (size_t)31).med;
+    const double r = RDmedian / mad;
+    S.nb_mad = mad; S.nb_r = r;
+    const double factor = sqrt(2.0 * (1.0 + P.epsilon) * log(3.1E9));   // rsi.cpp:1829
+    const int LmaxBase = std::max(20, 10000 / P.m);                      // rsi.cpp:1830-1831
+
+    HIPCHK(ctx->first_del.ensure((size_t)nb * 4));
+    HIPCHK(ctx->first_dup.ensure((size_t)nb * 4));
+    HIPCHK(ctx->status1.ensure((size_t)nb * 4));
+    HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
+    HIPCHK(ctx->status2.ensure((size_t)nb * 4));
+    HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
+
+    // ---- A10: NB transform (K5), always computed as the reference does (Q10) ----
+    HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
+    uint32_t* d_rawmin = reinterpret_cast<uint32_t*>(small + kOffRawMin);
+    HIPCHK(hipMemsetAsync(d_rawmin, 0xff, 4, st));
+    { Timer t(ctx, "nb_raw"); launch_nb_raw(ctx->binsum.as<int64_t>(), nb, P.m, ncompact, r, ctx->tnb.as<float>(), d_rawmin, st); }
+    uint32_t minkey;
+    HIPCHK(hipMemcpyAsync(&minkey, d_rawmin, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float tminf;
+    { uint32_t b = (minkey & 0x80000000u) ? (minkey & 0x7fffffffu) : ~minkey; memcpy(&tminf, &b, 4); }
+    const double tmin = tminf;
+    auto nbf = [&](double sum) {
+      const double mm = (double)P.m;
+      return 2.0 * sqrt(r) * log(sqrt((sum + 0.25) / (mm * r - 0.5)) + sqrt(1.0 + (sum + 0.25) / (mm * r - 0.5)));
+    };
+    double med_nbt = nbf(RDmedian * P.m), del_nbt = nbf(RDmedian / 2.0 * (double)P.m), dup_nbt = nbf(RDmedian * 1.5 * (double)P.m);
+    med_nbt -= tmin;
+    del_nbt -= tmin; dup_nbt -= tmin;
+    del_nbt = del_nbt / med_nbt * RDmedian;
+    dup_nbt = dup_nbt / med_nbt * RDmedian;
+    const double med_scaled = med_nbt / med_nbt * RDmedian;
+    const float lev0 = (float)del_nbt, lev1 = (float)dup_nbt, lev2 = (float)med_scaled;
+    { Timer t(ctx, "nb_scale"); launch_nb_scale(ctx->tnb.as<float>(), nb, tmin, med_nbt, RDmedian, lev0, lev1, lev2, st); }
+    S.nb_tmin = tmin;
+    ctx->have_nb = true;
+
+    rsih::CallerInput in;
+    in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
+    std::vector<int> medint((size_t)nb);
+    HIPCHK(hipMemcpyAsync(medint.data(), ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    in.binmedint = &medint;
+
+    auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
+      ScanOut so;
+      const float* d_T;
+      if (use_med) {
+        HIPCHK(ctx->tmed.ensure((size_t)nb * 4));
+        { Timer t(ctx, "i32_to_f32"); launch_i32_to_f32(ctx->binmed.as<int32_t>(), ctx->tmed.as<float>(), nb, st); }
+        d_T = ctx->tmed.as<float>();
+        ctx->have_med = true;
+      } else {
+        d_T = ctx->tnb.as<float>();
+      }
+      int rc2 = run_scan(ctx, P, use_med, d_T, nb, RDmedian, factor, LmaxBase, lev0, lev2, so);
+      if (rc2 != RSI_OK) return rc2;
+      ctx->last_scan_med = use_med;
+      S.tmedian1 = so.tmedian1; S.tsigma1 = so.tsigma1; S.tlamda1 = so.tlamda1;
+      S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;
+      S.Lmax = so.Lmax; S.trim_escapes += (int)so.escapes; S.inexact_sums = (int)so.inexact;
+      for (const Candidate& c : so.segs) segs_all.push_back(c);
+      segs = so.segs;
+      rsih::test_block_segments(in, so.status2, segs);   // areblockscnv, rsi.cpp:1847
+      return RSI_OK;
+    };
+    std::vector<Candidate> tested;
+    if (P.trans != 0) { if ((rc = do_scan(true, tested)) != RSI_OK) return rc; }          // rsi.cpp:1837-1840
+    if (P.trans == 0) { if ((rc = do_scan(false, tested)) != RSI_OK) return rc; }         // rsi.cpp:1845-1849
+    if (P.trans == 2) {                                                                   // rsi.cpp:1852-1858
+      std::vector<Candidate> more;
+      if ((rc = do_scan(false, more)) != RSI_OK) return rc;
+      tested.insert(tested.end(), more.begin(), more.end());
+    }
+    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st);
+    rsih::call_from_segments(in, tested, pager, blocks, raw, kept);
+  }
+  const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
+  for (int w = 0; w < 4; ++w) {
+    res->lists[w].resize(lists[w]->size());
+    for (size_t i = 0; i < lists[w]->size(); ++i) to_call((*lists[w])[i], &res->lists[w][i]);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  S.t_device_ms = now_ms() - t_begin;
+  if (ctx->timing) {
+    double tot = 0;
+    for (const KernelTime& k : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, k.a, k.b); tot += ms; }
+    S.t_kernels_ms = tot;
+  }
+  return RSI_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+void rsi_default_params(rsi_params* p) {   // rsi.cpp:34-98
+  p->m = 101; p->gcadjust = 1; p->trans = 0; p->merge = 1; p->maxchkbp = 100000; p->debug = 0;
+  p->cap = 4.0; p->epsilon = 1.5; p->threshold = -1.0; p->chklen = 2.5; p->minmlen = 3.01; p->buffer = 0.05; p->p = 0.05;
+}
+
+rsi_ctx* rsi_hot_create(int device, int* status) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    g_last_error = "no usable HIP device (librsi_hot has no CPU fallback)";
+    if (status) *status = RSI_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  rsi_ctx* ctx = new rsi_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_last_error = "hipSetDevice / hipStreamCreate failed";
+    if (status) *status = RSI_ERR_HIP;
+    delete ctx;
+    return nullptr;
+  }
+  if (status) *status = RSI_OK;
+  return ctx;
+}
+
+void rsi_hot_destroy(rsi_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* rsi_hot_last_error(const rsi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on != 0; }
+
+int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n, rsi_result** out) {
+  if (!ctx || !p || !d_depth || !d_fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  rsi_result* res = new rsi_result();
+  int rc = run_device_impl(ctx, p, static_cast<const int32_t*>(d_depth), static_cast<const uint8_t*>(d_fasta), n, res);
+  if (rc != RSI_OK) { delete res; *out = nullptr; return rc; }
+  *out = res;
+  return RSI_OK;
+}
+
+int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const uint8_t* fasta, int64_t n, rsi_result** out) {
+  if (!ctx || !p || !depth || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  if (n <= 0) return fail(ctx, RSI_ERR_BAD_ARG, "empty chromosome");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
+  HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
+  HIPCHK(hipMemcpyAsync(ctx->in_depth.p, depth, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
+}
+
+int rsi_result_ncalls(const rsi_result* r, int which) { return (r && which >= 0 && which < 4) ? (int)r->lists[which].size() : 0; }
+const rsi_call* rsi_result_calls(const rsi_result* r, int which) {
+  return (r && which >= 0 && which < 4 && !r->lists[which].empty()) ? r->lists[which].data() : nullptr;
+}
+const rsi_chrom_stats* rsi_result_stats(const rsi_result* r) { return r ? &r->stats : nullptr; }
+int rsi_result_noncode(const rsi_result* r, int32_t* pairs, int cap) {
+  if (!r) return 0;
+  const int k = (int)r->noncode.size() / 2;
+  for (int i = 0; i < k && i < cap; ++i) { pairs[2 * i] = r->noncode[2 * i]; pairs[2 * i + 1] = r->noncode[2 * i + 1]; }
+  return k;
+}
+void rsi_result_free(rsi_result* r) { delete r; }
+
+int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t cap) {
+  if (!ctx || !name) return RSI_ERR_BAD_ARG;
+  const std::string s(name);
+  const void* src = nullptr; int64_t cnt = 0;
+  if (s == "rd_gc" && ctx->have_gc) { src = ctx->rd_gc.p; cnt = ctx->n; }
+  else if (s == "rd_concat") { src = ctx->rdc.p; cnt = ctx->ncompact; }
+  else if (s == "binmedint") { src = ctx->binmed.p; cnt = ctx->nb; }
+  else if (s == "status1") { src = ctx->status1.p; cnt = ctx->nb; }
+  else if (s == "status1f") { src = ctx->status1f.p; cnt = ctx->nb; }
+  else if (s == "status2") { src = ctx->status2.p; cnt = ctx->nb; }
+  if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
+  if (out) {
+    const int64_t k = std::min(cnt, cap);
+    HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return cnt;
+}
+int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t cap) {
+  if (!ctx || !name) return RSI_ERR_BAD_ARG;
+  const std::string s(name);
+  const void* src = nullptr; int64_t cnt = 0;
+  if (s == "binnb" && ctx->have_nb) { src = ctx->tnb.p; cnt = ctx->nb; }
+  else if (s == "binmed" && ctx->have_med) { src = ctx->tmed.p; cnt = ctx->nb; }
+  if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
+  if (out) {
+    const int64_t k = std::min(cnt, cap);
+    HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return cnt;
+}
+int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t cap) {
+  if (!ctx || !name) return RSI_ERR_BAD_ARG;
+  const std::string s(name);
+  if (s != "binsum" || ctx->nb == 0) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
+  if (out) {
+    const int64_t k = std::min(ctx->nb, cap);
+    HIPCHK(hipMemcpyAsync(out, ctx->binsum.p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return ctx->nb;
+}
+
+int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap) {
+  if (!ctx) return 0;
+  int k = 0;
+  for (const KernelTime& t : ctx->ktimes) {
+    if (k < cap) { names[k] = t.name; float v = 0; (void)hipEventElapsedTime(&v, t.a, t.b); ms[k] = v; }
+    ++k;
+  }
+  return k;
+}
+
+// One output row as cnv_format1 prints it (rsi.cpp:581-631): default ostream formatting (%g-like,
+// 6 significant digits); RP/Q0 are -1 on this path (rsi.h:49-50).
+int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* buf, int cap) {
+  if (!r || i < 0 || i >= (int)r->lists[0].size()) return RSI_ERR_BAD_ARG;
+  const rsi_call& c = r->lists[0][(size_t)i];
+  static const char* kType[3] = {"DEL", "DUP", "UNKNOWN"};
+  const int k = snprintf(buf, (size_t)cap, "%s\t%d\t%d\t%s\t%d\t%d\t%g(%g);%g(%g);%g(%g)\tRP=%d;Q0=%g\trsi", chrom, c.start, c.end,
+                         kType[c.type < 0 || c.type > 2 ? 2 : c.type], c.qscore, c.end - c.start + 1, c.cnvmed,
+                         c.cnviqr / 1.349, c.refmed, c.refiqr / 1.349, r->stats.RDmedian, r->stats.RDsd, -1, -1.0);
+  return k;
+}
+
+}  // extern "C"
