@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- bases/s through the RSI read-depth hot path on MI355X.
+
+A "step" is one pass of the whole hot path (GC correction -> cap -> N removal -> bins -> NB
+transform -> RSI scan -> calls) over one synthetic genome already resident in HBM: the 24
+chromosomes totalling 3.0 Gb at 30x of BASELINE.json configs[3] with `-m 101 -NB` (the workload
+north_star's target is quoted on: ">= 50 Mbases/s ... on a 3 Gb synthetic genome at 1 MI355X").
+With N > 1 every rank (one process per GPU) processes its own genome (different sample seed);
+the per-chromosome summaries (chr median/SD + calls) are all-gathered over RCCL once per step
+-- the path's only exchange -- so scaling is weak and `value` is the whole-job bases/s.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README "Benchmark").  `roofline` is for the dominant kernel,
+timed with HIP events on the library's own stream inside the timed region; `cpu_baseline` times
+the compiled reference (oracle/_ref, kind "reference") or the CPU restatement (kind "port") on a
+bounded sample of the same workload, on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per base of the per-base kernels
+ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1, "fasta_classify": 1.0,
+                       "value_hist": 4.0}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+MAX_CALLS = 256         # per-chromosome slots in the gathered result block
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config (1-based as in SURVEY 8d): 2, 3, 4 or 5")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink chromosome lengths (debug only; invalidates the metric)")
+    ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workers", type=int, default=8, help="host threads / HIP streams per GPU (chromosomes in flight)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rsicnv_amd import api, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    lib = api.load_library()
+    pool = api.RsiPool(local_rank, args.workers)
+    pool.set_timing(True)
+    flags = synth.config_flags(args.config)
+    params = api.make_params(**flags)
+
+    # ---- synthetic genome, generated directly in HBM (not timed) ----
+    chroms = [0] if args.config in (2, 3) else list(range(24))
+    plans = []
+    for c in chroms:
+        p = synth.config_plan(args.config, chrom=c, scale=args.scale)
+        p["seed"] = p["seed"] + 1000003 * rank     # every rank = another sample of the cohort
+        plans.append(p)
+    t0 = time.time()
+    dev = torch.device("cuda", local_rank)
+    data = []
+    for p in plans:
+        d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device=dev)
+        d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device=dev)
+        synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
+        data.append((d_rd, d_fa, p["n"]))
+    torch.cuda.synchronize()
+    total_bases = sum(n for _, _, n in data)
+    if rank == 0:
+        log(f"[bench] generated {len(data)} chromosomes, {total_bases/1e9:.3f} Gb per rank in {time.time()-t0:.1f} s")
+
+    gather_in = torch.zeros(len(data), 4 + 4 * MAX_CALLS, dtype=torch.float64, device=dev)
+    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
+
+    chrom_args = [(d_rd.data_ptr(), d_fa.data_ptr(), n) for d_rd, d_fa, n in data]
+
+    def step(timed=False):
+        results = pool.run(params, chrom_args, collect_times=timed)
+        host_block = np.zeros((len(data), 4 + 4 * MAX_CALLS), dtype=np.float64)
+        ncalls = 0
+        for ci, res in enumerate(results):
+            calls = res.calls("calls")
+            ncalls += len(calls)
+            host_block[ci, 0:4] = (ci, res.stats["RDmedian"], res.stats["RDsd"], len(calls))
+            for k, c in enumerate(calls[:MAX_CALLS]):
+                host_block[ci, 4 + 4 * k: 8 + 4 * k] = (c["start"], c["end"], c["type"], c["qscore"])
+        if world > 1:   # the one exchange of the path: per-chromosome summaries to every rank
+            gather_in.copy_(torch.from_numpy(host_block))
+            dist.all_gather(gather_out, gather_in)
+        return ncalls
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pool.reset_times()
+    fence()
+    t_start = time.perf_counter()
+    ncalls = 0
+    for _ in range(args.steps):
+        ncalls = step(timed=True)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (HIP events on the library's streams, timed region) ----
+    per_kernel = pool.kernel_table()      # name -> (sum ms, launches, sum of chromosome lengths)
+    roofline = None
+    streaming = [k for k in per_kernel if k in ALGO_BYTES_PER_BASE]
+    if streaming:
+        dom = max(streaming, key=lambda k: per_kernel[k][0])
+        ms, cnt, bases = per_kernel[dom]
+        byts = ALGO_BYTES_PER_BASE[dom] * bases
+        achieved = byts / (ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / cnt, 4), "launches": int(cnt),
+                    "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[dom],
+                    "algorithmic_bytes_per_launch": round(byts / cnt)}
+    kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+    phase_ms = pool.phase_table()
+
+    # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(lib, args, flags)
+
+    if rank == 0:
+        value = world * total_bases * args.steps / elapsed
+        out = {
+            "metric": "bases/sec through RSI pipeline (bin+GC+NB+segment)", "value": round(value, 1), "unit": "bases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload_name(args), "chromosomes": len(data), "bases_per_gpu": total_bases,
+                       "flags": flag_string(flags), "calls_per_genome": ncalls,
+                       "parallelism": f"{world} rank(s), one genome per GPU, {args.workers} chromosomes in flight per GPU, "
+                                      "all_gather of per-chromosome summaries"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
+            "worker_phase_ms_per_step": {k: round(v / args.steps, 2) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
+        }
+        print(json.dumps(out), flush=True)
+    pool.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def flag_string(f):
+    return f"-m {f['m']} " + ("-NB" if f["trans"] == 0 else "-MED" if f["trans"] == 1 else "-ALL") + f" -cap {f['cap']:g}" + \
+        ("" if f["gcadjust"] else " -NOGC")
+
+
+def workload_name(args):
+    names = {2: "synthetic 60 Mb chromosome, 30x Poisson depth (configs[1])",
+             3: "synthetic 250 Mb chromosome, 30x gamma-Poisson depth with GC dependence (configs[2])",
+             4: "24 synthetic chromosomes totalling 3 Gb, 30x, per GPU (configs[3] data; north_star 3 Gb genome)",
+             5: "24 synthetic chromosomes totalling 3 Gb, 60x, -m 51 -MED -cap 4, per GPU (configs[4] data)"}
+    s = names[args.config]
+    if args.scale != 1.0:
+        s += f" [scaled x{args.scale}: NOT the metric's configuration]"
+    return s
+
+
+def cpu_baseline(lib, args, flags):
+    """Reference (or the oracle port) on one chromosome of the same model, compute-only, one core."""
+    import oracle
+    from rsicnv_amd import synth
+    n = int(args.cpu_sample_mb * 1e6 * min(args.scale, 1.0)) if args.scale < 1 else int(args.cpu_sample_mb * 1e6)
+    model = 0 if args.config == 2 else 1
+    mean = 60.0 if args.config == 5 else 30.0
+    plan = synth.make_plan(n, 0xC0FFEE, model=model, mean=mean, n_events=20 if model else 9, gaps=2,
+                           centromere=int(1_000_000 * min(args.scale, 1.0)) if model else 0)
+    fasta, depth = synth.generate_host(lib, plan)
+    p = oracle.make_params(**flags)
+    t0 = time.perf_counter()
+    if oracle.ref_available():
+        nc, stages = oracle.Ref().run_timed(p, depth, fasta)
+        kind = "reference"
+    else:
+        if not os.path.exists(oracle.ORACLE_SO):
+            import subprocess
+            subprocess.run(["make", "-f", "oracle/Makefile", "oracle/librsi_oracle.so"], cwd=ROOT, check=True)
+        O = oracle.Oracle()
+        nc = O.run(p, depth, fasta, snapshots=False)
+        stages = list(O.f64("stage_s"))
+        kind = "port"
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "bases/s", "cores": 1, "kind": kind,
+            "sample": f"one {n/1e6:.0f} Mb chromosome of the same depth model and flags, compute-only "
+                      f"(arrays in memory -> calls), {dt:.1f} s, {nc} calls",
+            "stage_s": [round(s, 3) for s in stages]}
+
+
+if __name__ == "__main__":
+    main()

@@ -125,8 +125,39 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
 /* Timing hooks for bench.py: per-kernel HIP-event times (ms) of the last run, by kernel name.
  * names/ms receive up to cap entries; returns the number of timed launches. */
 int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap);
+/* Host wall-clock per pipeline phase of the last run (ms, includes waits on the device). */
+int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int cap);
 /* Enable (1) / disable (0) per-kernel event timing (adds an event pair per launch). */
 void rsi_hot_set_timing(rsi_ctx* ctx, int on);
+
+/* ---- Pool: several chromosomes in flight on one GPU ------------------------------------------
+ * The reference's per-chromosome loop (rsi.cpp:2189-2217) has independent iterations.  A pool owns
+ * `nworkers` host threads, each with its own context (stream + workspace); rsi_pool_run hands the
+ * chromosomes out longest first.  The HBM-bound per-base phase is taken in turns (one at a time per
+ * GPU); bin-level kernels, copies and the host stages of different chromosomes overlap. */
+typedef struct rsi_pool rsi_pool;
+#define RSI_MAX_TIMED 64
+typedef struct rsi_batch_times {   /* accumulated over rsi_pool_run calls; zero it to start */
+  int32_t nkernels, nphases;
+  const char* kernel_name[RSI_MAX_TIMED];
+  double kernel_ms[RSI_MAX_TIMED];       /* sum of HIP-event durations */
+  int64_t kernel_launches[RSI_MAX_TIMED];
+  int64_t kernel_bases[RSI_MAX_TIMED];   /* sum over launches of the chromosome length */
+  const char* phase_name[RSI_MAX_TIMED];
+  double phase_ms[RSI_MAX_TIMED];        /* host wall-clock per pipeline phase, summed over workers */
+} rsi_batch_times;
+
+rsi_pool* rsi_pool_create(int device, int nworkers, int* status);
+void rsi_pool_destroy(rsi_pool* pool);
+int rsi_pool_workers(const rsi_pool* pool);
+rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w);
+void rsi_pool_set_timing(rsi_pool* pool, int on);
+const char* rsi_pool_last_error(const rsi_pool* pool);
+/* d_depth[i], d_fasta[i], n[i]: chromosome i, resident in HBM.  out[i] receives its result (or NULL),
+ * status[i] (optional) its rsi_status; returns the first failure or RSI_OK.  times may be NULL. */
+int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth,
+                 const void* const* d_fasta, const int64_t* n, rsi_result** out, int* status,
+                 rsi_batch_times* times);
 
 #ifdef __cplusplus
 }

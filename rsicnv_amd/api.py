@@ -20,7 +20,8 @@ STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3:
 EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
            "rsi_hot_run_device", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
-           "rsi_hot_kernel_times", "rsi_hot_set_timing", "rsi_synth_generate_host", "rsi_synth_generate_device"]
+           "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
+           "rsi_pool_set_timing", "rsi_pool_last_error", "rsi_pool_run", "rsi_synth_generate_host", "rsi_synth_generate_device"]
 
 
 class RsiParams(C.Structure):
@@ -44,6 +45,16 @@ class RsiChromStats(C.Structure):
                 ("tmedian1", C.c_double), ("tsigma1", C.c_double), ("tlamda1", C.c_double), ("tmedian2", C.c_double),
                 ("tsigma2", C.c_double), ("tlamda2", C.c_double), ("trim_escapes", C.c_int32),
                 ("inexact_sums", C.c_int32), ("t_device_ms", C.c_double), ("t_kernels_ms", C.c_double)]
+
+
+RSI_MAX_TIMED = 64
+
+
+class RsiBatchTimes(C.Structure):
+    _fields_ = [("nkernels", C.c_int32), ("nphases", C.c_int32), ("kernel_name", C.c_char_p * RSI_MAX_TIMED),
+                ("kernel_ms", C.c_double * RSI_MAX_TIMED), ("kernel_launches", C.c_int64 * RSI_MAX_TIMED),
+                ("kernel_bases", C.c_int64 * RSI_MAX_TIMED), ("phase_name", C.c_char_p * RSI_MAX_TIMED),
+                ("phase_ms", C.c_double * RSI_MAX_TIMED)]
 
 
 CALL_FIELDS = [f[0] for f in RsiCall._fields_ if f[0] != "pad"]
@@ -82,7 +93,19 @@ def load_library():
         f.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(ct), C.c_int64]
         f.restype = C.c_int64
     L.rsi_hot_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.rsi_hot_phase_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]
     L.rsi_hot_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.rsi_pool_create.restype = C.c_void_p
+    L.rsi_pool_destroy.argtypes = [C.c_void_p]
+    L.rsi_pool_workers.argtypes = [C.c_void_p]
+    L.rsi_pool_worker.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_pool_worker.restype = C.c_void_p
+    L.rsi_pool_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_pool_last_error.argtypes = [C.c_void_p]
+    L.rsi_pool_last_error.restype = C.c_char_p
+    L.rsi_pool_run.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(RsiBatchTimes)]
     _lib = L
     return L
 
@@ -188,8 +211,69 @@ class RsiHot:
                 return out
         raise KeyError(name)
 
+    def phase_times(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_double * 64)()
+        k = self.lib.rsi_hot_phase_times(self.ctx, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(k, 64))]
+
     def kernel_times(self):
         names = (C.c_char_p * 4096)()
         ms = (C.c_float * 4096)()
         k = self.lib.rsi_hot_kernel_times(self.ctx, names, ms, 4096)
         return [(names[i].decode(), float(ms[i])) for i in range(min(k, 4096))]
+
+
+class RsiPool:
+    """Several chromosomes in flight on one GPU (rsi_pool_*): `workers` host threads, each with its
+    own stream and workspace; the HBM-bound per-base phase is taken in turns."""
+
+    def __init__(self, device=0, workers=8):
+        self.lib = load_library()
+        st = C.c_int(0)
+        self.pool = self.lib.rsi_pool_create(device, workers, C.byref(st))
+        if not self.pool:
+            raise RsiError(st.value, self.lib.rsi_hot_last_error(None).decode())
+        self.times = RsiBatchTimes()
+
+    def close(self):
+        if getattr(self, "pool", None):
+            self.lib.rsi_pool_destroy(self.pool)
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on=True):
+        self.lib.rsi_pool_set_timing(self.pool, 1 if on else 0)
+
+    def reset_times(self):
+        self.times = RsiBatchTimes()
+
+    def run(self, params, chroms, collect_times=False):
+        """chroms: list of (d_depth_ptr, d_fasta_ptr, n).  Returns a list of Result in input order."""
+        k = len(chroms)
+        dp = (C.c_void_p * k)(*[C.c_void_p(c[0]) for c in chroms])
+        fp = (C.c_void_p * k)(*[C.c_void_p(c[1]) for c in chroms])
+        nn = (C.c_int64 * k)(*[c[2] for c in chroms])
+        out = (C.c_void_p * k)()
+        st = (C.c_int * k)()
+        rc = self.lib.rsi_pool_run(self.pool, C.byref(params), k, dp, fp, nn, out, st,
+                                   C.byref(self.times) if collect_times else None)
+        if rc != RSI_OK:
+            for i in range(k):
+                if out[i]:
+                    self.lib.rsi_result_free(out[i])
+            raise RsiError(rc, self.lib.rsi_pool_last_error(self.pool).decode())
+        return [Result(self.lib, C.c_void_p(out[i])) for i in range(k)]
+
+    def kernel_table(self):
+        t = self.times
+        return {t.kernel_name[i].decode(): (t.kernel_ms[i], t.kernel_launches[i], t.kernel_bases[i]) for i in range(t.nkernels)}
+
+    def phase_table(self):
+        t = self.times
+        return {t.phase_name[i].decode(): t.phase_ms[i] for i in range(t.nphases)}

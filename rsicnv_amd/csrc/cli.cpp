@@ -1,0 +1,255 @@
+// cli.cpp -- `rsicnv rsi ...`: the reference's command line (rsi.cpp:1949-2068, 2069-2217) in
+// front of librsi_hot.so.  Same flags and defaults, same output file (header lines, columns,
+// number formatting).  This round serves the depth-file input (-d RDFILE -c RNAME); BAM pileup
+// (-b), plot, stat and pin are outside the accelerated path and say so.
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rsi_hot.h"
+
+namespace {
+
+struct Options {
+  std::string function = "rsi", rdfile, bamfile, reffile, outfile = "rsiout.txt", chr = "1-22XY", plotfolder = "cnv_plots";
+  rsi_params P;
+  int minq = 0, min_baseQ = 13, device = 0;
+  bool saverd = false, plot = true;
+};
+
+int usage() {
+  std::cerr << "Usage:\n\n1. detect CNV\n\n"
+            << "   rsicnv rsi <options> [-b BAMFILE | -d RDFILE -c RNAME ] -f REFFILE \n"
+            << "\nOptions:\n"
+            << "   -m   INT  bin size, default=101\n"
+            << "   -q   INT  minimum mapping quality, default=0\n"
+            << "   -Q   INT  minimum base quality, default=10\n"
+            << "   -cap INT  cap read depth at INT*median, dafault=4\n"
+            << "             if INT<0, do not cap read depth\n"
+            << "   -NOGC     do not adjust GC content, default=adjust\n"
+            << "   -MED      only use median transformation \n"
+            << "   -NB       only use negative binomial transformation (default)\n"
+            << "   -o   STR  output file, default=rsiout.txt \n"
+            << "   -np       do not plot CNV\n"
+            << "   -gpu INT  HIP device to run on, default=0\n"
+            << "\nNote:\n"
+            << "   This build runs the read-depth hot path on an MI355X; input is a read depth file\n"
+            << "   (samtools mpileup BAM | cut -f2,4) with -c RNAME, plus the indexed reference.\n"
+            << std::endl;
+  return 0;
+}
+
+// get_parameters, rsi.cpp:1986-2068
+void parse(int argc, char** argv, Options& o) {
+  rsi_default_params(&o.P);
+  std::vector<std::string> a(argv, argv + argc);
+  if (a.size() < 2) exit(usage());
+  size_t i = 1;
+  if (a[1][0] != '-') {
+    o.function = a[1];
+    if (o.function != "rsi" && o.function != "plot" && o.function != "stat" && o.function != "pin") {
+      std::cerr << "no such function " << o.function << std::endl;
+      exit(usage());
+    }
+    i = 2;
+  }
+  auto need = [&](size_t k) { if (k + 1 >= a.size()) exit(usage()); return a[k + 1]; };
+  for (; i < a.size(); ++i) {
+    const std::string& s = a[i];
+    if (s == "-d") { o.rdfile = need(i); ++i; }
+    else if (s == "-b") { o.bamfile = need(i); ++i; }
+    else if (s == "-f") { o.reffile = need(i); ++i; }
+    else if (s == "-v") { need(i); ++i; }
+    else if (s == "-o") { o.outfile = need(i); ++i; }
+    else if (s == "-c") { o.chr = need(i); ++i; }
+    else if (s == "-s") o.saverd = true;
+    else if (s == "-m") { o.P.m = atoi(need(i).c_str()); ++i; }
+    else if (s == "-q") { o.minq = atoi(need(i).c_str()); ++i; }
+    else if (s == "-Q") { o.min_baseQ = atoi(need(i).c_str()); ++i; }
+    else if (s == "-L") { need(i); ++i; }
+    else if (s == "-p") { o.plotfolder = need(i); ++i; }
+    else if (s == "-np") o.plot = false;
+    else if (s == "-threshold") { o.P.threshold = atof(need(i).c_str()); ++i; }
+    else if (s == "-e") { o.P.epsilon = atof(need(i).c_str()); ++i; }
+    else if (s == "-cap") { o.P.cap = atof(need(i).c_str()); ++i; }
+    else if (s == "-reflen") { o.P.chklen = atof(need(i).c_str()); ++i; }
+    else if (s == "-maxchkbp") { o.P.maxchkbp = atoi(need(i).c_str()); ++i; }
+    else if (s == "-debug") o.P.debug = 1;
+    else if (s == "-MED") o.P.trans = 1;
+    else if (s == "-NB") o.P.trans = 0;
+    else if (s == "-ALL") o.P.trans = 2;
+    else if (s == "-nomerge") o.P.merge = 0;
+    else if (s == "-hist" || s == "-overlap" || s == "-combine" || s == "-nocode") {}
+    else if (s == "-NOGC") o.P.gcadjust = 0;
+    else if (s == "-gpu") { o.device = atoi(need(i).c_str()); ++i; }
+    else { std::cerr << "unknown option " << s << std::endl; exit(usage()); }
+  }
+  if (o.rdfile.empty() && o.bamfile.empty()) { std::cerr << "need input file " << std::endl; exit(usage()); }
+  if (o.reffile.empty() && o.function == "rsi") { std::cerr << "need reference file " << std::endl; exit(usage()); }
+  if (o.outfile == o.bamfile || o.outfile == o.rdfile) { std::cerr << "output file is same as input file " << std::endl; exit(usage()); }
+  if (!o.rdfile.empty() && o.chr.empty()) { std::cerr << "readdepth file and chromosome must be specified together" << std::endl; exit(usage()); }
+  if ((o.P.m % 2) != 1) { o.P.m += 1; std::cerr << "m is changed to " << o.P.m << std::endl; }   // rsi.cpp:2061-2064
+}
+
+// read_fasta, readref.cpp:10-86: one chromosome through the .fai index
+bool read_fasta(const std::string& fasta, const std::string& chr, std::string& ref) {
+  std::ifstream fai((fasta + ".fai").c_str());
+  if (!fai) { std::cerr << "[read_fasta] Index file " << fasta << ".fai not found\n"; return false; }
+  std::string name, line;
+  long len = 0, offset = 0, nbases = 0, lwidth = 0;
+  bool found = false;
+  while (std::getline(fai, line)) {
+    std::istringstream iss(line);
+    iss >> name >> len >> offset >> nbases >> lwidth;
+    if (name == chr || name == "chr" + chr) { found = true; break; }
+  }
+  if (!found) { std::cerr << chr << " not found in fai index\n"; return false; }
+  const long flen = len + (len / nbases) * (lwidth - nbases);
+  std::vector<char> buf((size_t)flen + 1);
+  std::ifstream fin(fasta.c_str(), std::ios::binary);
+  fin.seekg(offset, std::ios::beg);
+  fin.read(buf.data(), flen);
+  const long got = (long)fin.gcount();
+  ref.resize((size_t)len);
+  long k = 0;
+  for (long i = 0; i < got && k < len; ++i) if (buf[i] != '\n') ref[(size_t)k++] = buf[i];
+  if (k != len) { std::cerr << "Error reading the reference fasta\nread " << k << " bases\nexpecting " << len << " bases" << std::endl; return false; }
+  return true;
+}
+
+// The parse loop of load_data_from_text (loaddata.cpp:496-517): "pos depth" lines, '#' and empty
+// lines skipped, pos < 1 skipped, reading stops at the first pos >= size (App. A Q7).
+bool load_depth_text(const std::string& path, std::vector<int32_t>& rd) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) { std::cerr << "Cannot open file " << path << std::endl; return false; }
+  struct stat sb;
+  fstat(fd, &sb);
+  const size_t sz = (size_t)sb.st_size;
+  const char* p = sz ? (const char*)mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+  if (sz && p == MAP_FAILED) { close(fd); std::cerr << "Cannot map file " << path << std::endl; return false; }
+  const char* end = p + sz;
+  const long size = (long)rd.size();
+  auto parse_int = [&](const char*& q, const char* e, long& v) {
+    while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
+    bool neg = false;
+    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    if (q >= e || *q < '0' || *q > '9') return false;
+    long x = 0;
+    while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; }
+    v = neg ? -x : x;
+    return true;
+  };
+  const char* q = p;
+  while (q < end) {
+    const char* eol = (const char*)memchr(q, '\n', (size_t)(end - q));
+    if (!eol) eol = end;
+    if (eol > q && *q != '#') {
+      const char* c = q;
+      long pos = 0, d = 0;
+      if (parse_int(c, eol, pos)) {
+        parse_int(c, eol, d);
+        if (pos >= 1) {
+          if (pos >= size) break;
+          rd[(size_t)pos - 1] = (int32_t)d;
+        }
+      }
+    }
+    q = eol + 1;
+  }
+  if (sz) munmap((void*)p, sz);
+  close(fd);
+  return true;
+}
+
+const char* kHeader =
+    "#CHROM\tSTART\tEND\tTYPE\tSCORE\tLENGTH\tCNV_MED(CNV_SD);NEIGHBOR_MED(NEIGHBOR_RUNMEANSD);CHR_MED(CHR_SD)\t"
+    "RP=#support_read_pairs;Q0=#fraction_of_Q0_reads\tMETHOD";
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Options o;
+  parse(argc, argv, o);
+  if (o.function != "rsi") {
+    std::cerr << "rsicnv " << o.function << ": not part of the accelerated read-depth path in this build" << std::endl;
+    return 0;
+  }
+  if (!o.bamfile.empty()) {
+    std::cerr << "BAM input (-b) is not wired up in this build yet: produce a depth file with\n"
+              << "  samtools mpileup BAM | cut -f2,4   and pass it with -d RDFILE -c RNAME" << std::endl;
+    return 0;
+  }
+  std::ofstream log((o.outfile + ".log").c_str());
+  std::ostringstream hdr;
+  hdr << "#command:   "; for (int i = 0; i < argc; ++i) hdr << argv[i] << " ";
+  hdr << "\n#bamfile:   " << o.bamfile << "\n#rdfile:    " << o.rdfile << "\n#reffile:   " << o.reffile << "\n#chrom:     " << o.chr
+      << "\n#min_mapq:  " << o.minq << "\n#min_baseQ: " << o.min_baseQ << "\n#binsize:   " << o.P.m << "\n#adjustGC:  " << o.P.gcadjust
+      << "\n#output:    " << o.outfile << "\n";
+  std::cerr << hdr.str(); log << hdr.str();
+  std::cerr << "#processing " << o.chr << std::endl; log << "#processing " << o.chr << std::endl;
+
+  const double t0 = now_s();
+  std::string fasta;
+  if (!read_fasta(o.reffile, o.chr, fasta)) return 0;
+  std::vector<int32_t> rd(fasta.size(), 0);
+  if (!load_depth_text(o.rdfile, rd)) return 0;
+  const double t1 = now_s();
+
+  int st = 0;
+  rsi_ctx* ctx = rsi_hot_create(o.device, &st);
+  if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
+  rsi_result* res = nullptr;
+  const int rc = rsi_hot_run(ctx, &o.P, rd.data(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res);
+  if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
+    std::cerr << rsi_hot_last_error(ctx) << std::endl; log << rsi_hot_last_error(ctx) << std::endl;
+    rsi_hot_destroy(ctx);
+    return 0;
+  }
+  const double t2 = now_s();
+  const rsi_chrom_stats* S = rsi_result_stats(res);
+  std::ostringstream info;
+  info << "#Noseq regions excluded\n";
+  {
+    std::vector<int32_t> pairs((size_t)S->n_noncode * 2 + 2);
+    const int k = rsi_result_noncode(res, pairs.data(), S->n_noncode);
+    for (int i = 0; i < k; ++i) info << o.chr << "\t" << pairs[2 * i] << "\t" << pairs[2 * i + 1] << "\n";
+  }
+  if (o.P.gcadjust) info << "RD mean before GC adjust = " << S->gc_rdmean << "\n";
+  if (o.P.cap > 1) info << "applying cap " << o.P.cap << " times of mean " << S->cap_median << "\ncap = " << o.P.cap * S->cap_median << "\n";
+  info << "region  : " << o.chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
+  info << "RD median absolute deviation : " << S->nb_mad << "\n"
+       << "first pass\n\tmedian of transformations : " << S->tmedian1 << "\n\tsigma : " << S->tsigma1 << "\n\tlamda : " << S->tlamda1 << "\n"
+       << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
+       << "Selected " << rsi_result_ncalls(res, 3) << " segments for testing\n"
+       << "Found " << rsi_result_ncalls(res, 1) << " CNVs before sd_filters, " << rsi_result_ncalls(res, 0) << " written\n"
+       << "timing: load " << (t1 - t0) << " s, device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
+  std::cerr << info.str(); log << info.str();
+
+  // write_cnv_to_file, rsi.cpp:1592-1616
+  std::ofstream out(o.outfile.c_str());
+  if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << o.chr << std::endl;
+  if (o.P.gcadjust) out << "#GC adjusted\n";
+  out << kHeader << std::endl;
+  char row[1024];
+  for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
+    rsi_result_format_row(res, i, o.chr.c_str(), row, (int)sizeof(row));
+    out << row << std::endl;
+  }
+  out.close();
+  std::cerr << "output written to " << o.outfile << std::endl; log << "output written to " << o.outfile << std::endl;
+  rsi_result_free(res);
+  rsi_hot_destroy(ctx);
+  return 0;
+}

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict
     const uint32_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
     kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; bad |= __shfl_xor(bad, d);
   }
-  if (lane_id() == 0) {
+  __shared__ uint32_t s_min[kThreads / 64], s_max[kThreads / 64], s_bad[kThreads / 64];
+  if (lane_id() == 0) { s_min[threadIdx.x >> 6] = kmin; s_max[threadIdx.x >> 6] = kmax; s_bad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one set of atomics per workgroup
+    for (int w = 1; w < kThreads / 64; ++w) { kmin = s_min[w] < kmin ? s_min[w] : kmin; kmax = s_max[w] > kmax ? s_max[w] : kmax; bad |= s_bad[w]; }
     if (kmin != 0xffffffffu) atomicMin(&mm->min_bits, kmin);
     if (kmax != 0) atomicMax(&mm->max_bits, kmax);
     if (bad) atomicOr(&mm->nonfinite, 1u);
@@ -123,95 +127,83 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------
 // K7  RSI scan.  One workgroup per tile of kScanTile bins.  The tile plus a halo of Lmax/2+1 bins
-// each side is reduced to an exact double prefix in LDS, so the window sum for any (bin, L) is
-// one subtraction; the per-L score test is folded on the host into a threshold on that sum
-// (hit iff sum <= thr_del[L] / sum >= thr_dup[L]).  Hits are rare and handled by the whole wave:
-// exact window median of the bin medians, the four trim walks, then atomicMin(L) on the marked
-// bins ("smallest L wins", App. A Q14).
+// each side is staged in LDS: an exact double prefix of the transformed values (so the window sum
+// for any (bin, L) is one subtraction), the values and bin medians themselves for the trim walks,
+// and two integer prefixes that turn the exact window-median test into a count difference.  The
+// per-L score test is folded on the host into a threshold on the window sum (hit iff
+// sum <= thr_del[L] / sum >= thr_dup[L]).  Every lane owns a bin and walks L = 1..Lmax; a hit marks
+// its trimmed interval with atomicMin(L) in LDS ("smallest L wins", App. A Q14) and the tile's
+// marks are merged into HBM at the end.  Nothing in the hit path leaves LDS.
 constexpr int kScanTile = 1024;
+constexpr uint32_t kUnmarked = 0xffffffffu;
 
-__device__ inline uint32_t ld_relaxed(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // served from L2, never a stale L1 line
-}
+struct ScanLds {
+  double* P;        // count + 1
+  double* tdel;     // Lmax + 1
+  double* tdup;     // Lmax + 1
+  double* tot;      // kThreads
+  float* T;         // count
+  int* M;           // count
+  int* CL;          // count + 1: # staged bins before e with medint <= floor(lim_del)
+  int* CG;          // count + 1: # staged bins before e with medint >= ceil(lim_dup)
+  uint32_t* FD;     // count
+  uint32_t* FU;     // count
+};
 
-// Exact median of medint[w0 .. w0+L-1] (alglib samplemedian semantics), computed by the wave.
-__device__ inline double wave_window_median(const int32_t* __restrict__ medint, int64_t w0, int L) {
-  const int lane = lane_id();
-  int lo = 0x7fffffff, hi = (int)0x80000000;
-  for (int j = lane; j < L; j += 64) { const int v = medint[w0 + j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int a = __shfl_xor(lo, d), b = __shfl_xor(hi, d);
-    lo = a < lo ? a : lo; hi = b > hi ? b : hi;
-  }
-  const int klo = (L - 1) / 2 + 1;   // rank (1-based) of the lower middle element
-  while (lo < hi) {
-    const int mid = (int)(((long long)lo + (long long)hi) >> 1);
-    int c = 0;
-    for (int j = lane; j < L; j += 64) c += medint[w0 + j] <= mid;
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if (c >= klo) hi = mid; else lo = mid + 1;
-  }
-  const int a = lo;
-  if (L & 1) return (double)a;
-  // even L: mean of the two middle order statistics
-  int c = 0, nxt = 0x7fffffff;
-  for (int j = lane; j < L; j += 64) { const int v = medint[w0 + j]; c += v <= a; if (v > a && v < nxt) nxt = v; }
-  for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d); const int o = __shfl_xor(nxt, d); nxt = o < nxt ? o : nxt; }
-  const int b = (c >= klo + 1) ? a : nxt;
-  return 0.5 * ((double)a + (double)b);
-}
-
-// Walk from `pos` in direction dir (+1/-1) while the predicate holds; returns the first position
-// where it fails, or -1 / nb when the walk leaves the array (the reference would abort there).
-template <class Pred>
-__device__ inline int64_t wave_walk(int64_t pos, int dir, int64_t nb, Pred pred) {
-  const int lane = lane_id();
-  while (true) {
-    const int64_t idx = pos + (int64_t)dir * lane;
-    const bool inside = idx >= 0 && idx < nb;
-    const bool go = inside && pred(idx);
-    const unsigned long long stop = __ballot(!go);
-    if (stop) {
-      const int first = __ffsll((long long)stop) - 1;
-      return pos + (int64_t)dir * first;
+// One sweep's hit for the lane's window [w0, w0+L-1] (staged indices).  DEL: is_del = true.
+// vlo/vhi: staged indices inside the chromosome are [vlo, vhi).  Returns the updated "largest mark
+// in the window" (see the skip rule in the caller).
+__device__ inline uint32_t lane_hit(const ScanLds& S, int w0, int L, bool is_del, int thr_int, double lim, double tmed,
+                                    int vlo, int vhi, bool at_start, bool at_end, uint32_t* F, uint32_t* counters) {
+  const int* C = is_del ? S.CL : S.CG;
+  const int c = C[w0 + L] - C[w0];
+  bool pass;
+  if (L & 1) {
+    pass = c >= (L + 1) / 2;                       // middle order statistic on the right side of the limit
+  } else {
+    const int hh = L / 2;
+    if (c >= hh + 1) pass = true;
+    else if (c <= hh - 1) pass = false;
+    else {                                         // the two middle elements straddle the limit: need their values
+      int a, b;
+      if (is_del) {                                // a = max{x <= thr}, b = min{x > thr}
+        a = (int)0x80000000; b = 0x7fffffff;
+        for (int j = w0; j < w0 + L; ++j) { const int x = S.M[j]; if (x <= thr_int) a = x > a ? x : a; else b = x < b ? x : b; }
+        pass = !(0.5 * ((double)a + (double)b) > lim);          // rsi.cpp:1206
+      } else {                                     // a = max{x < thr}, b = min{x >= thr}
+        a = (int)0x80000000; b = 0x7fffffff;
+        for (int j = w0; j < w0 + L; ++j) { const int x = S.M[j]; if (x >= thr_int) b = x < b ? x : b; else a = x > a ? x : a; }
+        pass = !(0.5 * ((double)a + (double)b) < lim);          // rsi.cpp:1236
+      }
     }
-    pos += (int64_t)dir * 64;
   }
-}
-
-__device__ inline void wave_process_hit(const float* __restrict__ T, const int32_t* __restrict__ medint,
-                                        const ScanParams& sp, int64_t bi, int L, bool is_del,
-                                        uint32_t* __restrict__ first, uint32_t* __restrict__ counters) {
-  const int lane = lane_id();
-  const int64_t w0 = bi - L / 2;
-  // nothing to do when every bin of the window already carries a mark with a length <= L
-  {
-    uint32_t worst = 0;
-    for (int j = lane; j < L; j += 64) { const uint32_t f = ld_relaxed(first + w0 + j); worst = f > worst ? f : worst; }
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(worst, d); worst = o > worst ? o : worst; }
-    if (worst <= (uint32_t)L) return;
+  if (!pass) return kUnmarked;   // no marks from this hit, and no knowledge of the window's marks
+  uint32_t wmax = 0;
+  // trim walks in the reference's order (rsi.cpp:1211-1214 / 1241-1244), bounded to the chromosome
+  int i1 = w0, i2 = w0 + L - 1;
+  if (is_del) {
+    while (i1 < vhi && (double)S.T[i1] > tmed) ++i1;
+    while (i1 < vhi && S.M[i1] > thr_int) ++i1;
+    while (i2 >= vlo && (double)S.T[i2] > tmed) --i2;
+    while (i2 >= vlo && S.M[i2] > thr_int) --i2;
+  } else {
+    while (i1 < vhi && (double)S.T[i1] < tmed) ++i1;
+    while (i1 < vhi && S.M[i1] < thr_int) ++i1;
+    while (i2 >= vlo && (double)S.T[i2] < tmed) --i2;
+    while (i2 >= vlo && S.M[i2] < thr_int) --i2;
   }
-  const double med = wave_window_median(medint, w0, L);
-  const double lim = is_del ? sp.lim_del : sp.lim_dup;
-  if (is_del ? (med > lim) : (med < lim)) return;                 // rsi.cpp:1206 / 1236
-  const double tmed = sp.tmedian;
-  int64_t i1 = w0, i2 = w0 + L - 1;
-  if (is_del) {                                                    // rsi.cpp:1211-1214
-    i1 = wave_walk(i1, +1, sp.nb, [&](int64_t q) { return (double)T[q] > tmed; });
-    if (i1 >= 0 && i1 < sp.nb) i1 = wave_walk(i1, +1, sp.nb, [&](int64_t q) { return (double)medint[q] > lim; });
-    i2 = wave_walk(i2, -1, sp.nb, [&](int64_t q) { return (double)T[q] > tmed; });
-    if (i2 >= 0 && i2 < sp.nb) i2 = wave_walk(i2, -1, sp.nb, [&](int64_t q) { return (double)medint[q] > lim; });
-  } else {                                                         // rsi.cpp:1241-1244
-    i1 = wave_walk(i1, +1, sp.nb, [&](int64_t q) { return (double)T[q] < tmed; });
-    if (i1 >= 0 && i1 < sp.nb) i1 = wave_walk(i1, +1, sp.nb, [&](int64_t q) { return (double)medint[q] < lim; });
-    i2 = wave_walk(i2, -1, sp.nb, [&](int64_t q) { return (double)T[q] < tmed; });
-    if (i2 >= 0 && i2 < sp.nb) i2 = wave_walk(i2, -1, sp.nb, [&](int64_t q) { return (double)medint[q] < lim; });
+  if (i1 >= vhi || i2 < vlo) {
+    // left the staged range: the marked interval is empty either way.  Leaving the chromosome
+    // itself is where the reference aborts (App. A Q12): count those.
+    if ((i1 >= vhi && at_end) || (i2 < vlo && at_start)) atomicAdd(&counters[0], 1u);
+    i1 = 1; i2 = 0;
   }
-  if (i1 < 0 || i1 >= sp.nb || i2 < 0 || i2 >= sp.nb) {            // App. A Q12: mark nothing, count it
-    if (lane == 0) atomicAdd(&counters[0], 1u);
-    return;
+  for (int j = w0; j < w0 + L; ++j) {
+    uint32_t v = F[j];
+    if (j >= i1 && j <= i2 && v > (uint32_t)L) { atomicMin(&F[j], (uint32_t)L); v = (uint32_t)L; }
+    wmax = v > wmax ? v : wmax;
   }
-  for (int64_t j = i1 + lane; j <= i2; j += 64) atomicMin(&first[j], (uint32_t)L);
+  return wmax;
 }
 
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
@@ -223,72 +215,108 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   const int Lmax = sp.Lmax;
   const int halo = Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;          // staged bins
-  double* P = sm;                                  // count + 1 prefix entries
-  double* s_del = sm + count + 1;                  // Lmax + 1
-  double* s_dup = s_del + Lmax + 1;                // Lmax + 1
-  double* s_tot = s_dup + Lmax + 1;                // kThreads chunk totals
+  ScanLds S;
+  S.P = sm;
+  S.tdel = S.P + count + 1;
+  S.tdup = S.tdel + Lmax + 1;
+  S.tot = S.tdup + Lmax + 1;
+  S.T = reinterpret_cast<float*>(S.tot + kThreads);
+  S.M = reinterpret_cast<int*>(S.T + count);
+  S.CL = S.M + count;
+  S.CG = S.CL + count + 1;
+  S.FD = reinterpret_cast<uint32_t*>(S.CG + count + 1);
+  S.FU = S.FD + count;
   const int64_t tile_start = (int64_t)blockIdx.x * kScanTile;
   const int64_t lo = tile_start - halo;
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { s_del[e] = thr_del[e]; s_dup[e] = thr_dup[e]; }
-  // ---- exact prefix over the staged bins: serial chunk per thread, then a scan of the chunk totals ----
+  const int vlo = lo < 0 ? (int)(-lo) : 0;
+  const int vhi = (lo + count > sp.nb) ? (int)(sp.nb - lo) : count;
+  const bool at_start = lo <= 0, at_end = lo + count >= sp.nb;
+  // integer forms of the median limits: x > lim_del <=> x > fl_del ; x < lim_dup <=> x < ce_dup
+  const int fl_del = (int)floor(sp.lim_del), ce_dup = (int)ceil(sp.lim_dup);
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { S.tdel[e] = thr_del[e]; S.tdup[e] = thr_dup[e]; }
+  // ---- stage + exact prefixes: serial chunk per thread, then a scan of the 256 chunk totals ----
   const int chunk = (count + kThreads - 1) / kThreads;
   const int c0 = threadIdx.x * chunk;
   double run = 0.0;
+  int runl = 0, rung = 0;
   unsigned int inexact = 0;
   for (int e = c0; e < c0 + chunk && e < count; ++e) {
-    const int64_t g = lo + e;
-    const float v = (g >= 0 && g < sp.nb) ? T[g] : 0.0f;
-    // exact-sum precondition: 0, or 2^-10 <= |v| < 2^20; counted once per owning tile
+    const bool in = e >= vlo && e < vhi;
+    const float v = in ? T[lo + e] : 0.0f;
+    const int mi = in ? medint[lo + e] : 0;
+    // exact-sum precondition: 0, or 2^-10 <= |v| < 2^20; counted once, by the owning tile
     const float av = fabsf(v);
-    if (!(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && g >= tile_start && g < tile_start + kScanTile) inexact++;
+    if (!(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && e >= halo && e < halo + kScanTile) inexact++;
+    S.T[e] = v; S.M[e] = mi; S.FD[e] = kUnmarked; S.FU[e] = kUnmarked;
     run += (double)v;
-    P[e + 1] = run;
+    runl += (in && mi <= fl_del);
+    rung += (in && mi >= ce_dup);
+    S.P[e + 1] = run; S.CL[e + 1] = runl; S.CG[e + 1] = rung;
   }
-  s_tot[threadIdx.x] = run;
-  if (threadIdx.x == 0) P[0] = 0.0;
+  // pack the three chunk totals for the cross-thread scan (counts are exact in double)
+  S.tot[threadIdx.x] = run;
+  __shared__ int s_cl[kThreads], s_cg[kThreads];
+  s_cl[threadIdx.x] = runl; s_cg[threadIdx.x] = rung;
+  if (threadIdx.x == 0) { S.P[0] = 0.0; S.CL[0] = 0; S.CG[0] = 0; }
   __syncthreads();
   if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
-    double carry = 0.0;
+    double carry = 0.0; int carl = 0, carg = 0;
     for (int k = 0; k < kThreads / 64; ++k) {
-      const double mine = s_tot[k * 64 + threadIdx.x];
-      double incl = mine;
-      for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
-      s_tot[k * 64 + threadIdx.x] = carry + incl - mine;
-      carry += __shfl(incl, 63);
+      const int idx = k * 64 + threadIdx.x;
+      const double mine = S.tot[idx]; const int ml = s_cl[idx], mg = s_cg[idx];
+      double incl = mine; int il = ml, ig = mg;
+      for (int d = 1; d < 64; d <<= 1) {
+        const double up = __shfl_up(incl, d); const int ul = __shfl_up(il, d), ug = __shfl_up(ig, d);
+        if ((int)threadIdx.x >= d) { incl += up; il += ul; ig += ug; }
+      }
+      S.tot[idx] = carry + incl - mine; s_cl[idx] = carl + il - ml; s_cg[idx] = carg + ig - mg;
+      carry += __shfl(incl, 63); carl += __shfl(il, 63); carg += __shfl(ig, 63);
     }
   }
   __syncthreads();
   {
-    const double off = s_tot[threadIdx.x];
-    for (int e = c0; e < c0 + chunk && e < count; ++e) P[e + 1] += off;
+    const double off = S.tot[threadIdx.x]; const int ol = s_cl[threadIdx.x], og = s_cg[threadIdx.x];
+    for (int e = c0; e < c0 + chunk && e < count; ++e) { S.P[e + 1] += off; S.CL[e + 1] += ol; S.CG[e + 1] += og; }
   }
   for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
   if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
   __syncthreads();
 
-  // ---- evaluate every (bin, L) of the tile ----
+  // ---- every (bin, L) of the tile; lanes are independent ----
+  const double tmed = sp.tmedian;
   for (int r = 0; r < kScanTile / kThreads; ++r) {
     const int64_t i = tile_start + r * kThreads + threadIdx.x;
-    const int rel = (int)(i - lo);   // index of bin i among the staged bins
+    const int rel = (int)(i - lo);   // staged index of bin i
+    // skip rule: wd / wu hold the largest mark in the lane's window as of length ld / lu; while the
+    // window grows by one bin per L they are extended incrementally, otherwise recomputed by lane_hit.
+    // A hit whose whole window already carries marks <= L cannot change anything (the trimmed
+    // interval lies inside the window), so it is skipped.
+    uint32_t wd = kUnmarked, wu = kUnmarked; int ld = -1, lu = -1;
     for (int L = 1; L <= Lmax; ++L) {
       const int h = L / 2;
       // the reference visits i in [L/2+1, nb-L/2-2] (rsi.cpp:1204)
-      const bool visit = i < sp.nb && i >= h + 1 && i < sp.nb - h - 1;
-      bool hd = false, hu = false;
-      if (visit) {
-        const double sum = P[rel - h + L] - P[rel - h];
-        hd = sum <= s_del[L];
-        hu = sum >= s_dup[L];
+      if (!(i < sp.nb && i >= h + 1 && i < sp.nb - h - 1)) continue;
+      const int w0 = rel - h;
+      const double sum = S.P[w0 + L] - S.P[w0];
+      const int grown = (L & 1) ? w0 + L - 1 : w0;   // the bin the window gained going from L-1 to L
+      if (sum <= S.tdel[L]) {
+        if (ld == L - 1) { const uint32_t v = S.FD[grown]; wd = v > wd ? v : wd; } else wd = kUnmarked;
+        if (wd > (uint32_t)L) wd = lane_hit(S, w0, L, true, fl_del, sp.lim_del, tmed, vlo, vhi, at_start, at_end, S.FD, counters);
+        ld = L;
       }
-      unsigned long long any = __ballot(hd || hu);
-      while (any) {
-        const int src = __ffsll((long long)any) - 1;
-        any &= any - 1;
-        const int64_t bi = __shfl(i, src);
-        const int isdel = __shfl((int)hd, src);
-        wave_process_hit(T, medint, sp, bi, L, isdel != 0, isdel ? first_del : first_dup, counters);
+      if (sum >= S.tdup[L]) {
+        if (lu == L - 1) { const uint32_t v = S.FU[grown]; wu = v > wu ? v : wu; } else wu = kUnmarked;
+        if (wu > (uint32_t)L) wu = lane_hit(S, w0, L, false, ce_dup, sp.lim_dup, tmed, vlo, vhi, at_start, at_end, S.FU, counters);
+        lu = L;
       }
     }
+  }
+  __syncthreads();
+  // ---- merge the tile's marks into HBM (halo bins are shared with the neighbouring tiles) ----
+  for (int e = vlo + threadIdx.x; e < vhi; e += kThreads) {
+    const uint32_t d = S.FD[e], u = S.FU[e];
+    if (d != kUnmarked) atomicMin(&first_del[lo + e], d);
+    if (u != kUnmarked) atomicMin(&first_dup[lo + e], u);
   }
 }
 
@@ -438,7 +466,7 @@ void launch_i32_to_f32(const int32_t* in, float* out, int64_t nb, hipStream_t st
 }
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
                        hipStream_t stream) {
-  hipLaunchKernelGGL(k_minmax_f32, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
+  hipLaunchKernelGGL(k_minmax_f32, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
 }
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin, uint32_t* hist,
                      uint32_t np, hipStream_t stream) {
@@ -449,8 +477,10 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del, const double* thr_dup,
                      uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
   const int halo = sp.Lmax / 2 + 1;
-  const size_t lds = ((size_t)(kScanTile + 2 * halo + 1) + 2 * (size_t)(sp.Lmax + 1) + kThreads) * sizeof(double);
+  const size_t count = (size_t)kScanTile + 2 * halo;
+  const size_t lds = ((count + 1) + 2 * (size_t)(sp.Lmax + 1) + kThreads) * sizeof(double) + count * 4 * 4 + 2 * (count + 1) * 4;
   const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rsi_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_rsi_scan, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters);
 }
 void launch_level_hist(const uint32_t* first, const uint32_t* exclude, uint32_t exclude_max, int64_t nb, int32_t Lmax,

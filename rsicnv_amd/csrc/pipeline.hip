@@ -9,7 +9,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -24,7 +27,9 @@ using rsih::Region;
 
 namespace {
 
-std::string g_last_error;
+std::string g_last_error;   // last failure of any context (diagnostic; guarded by g_err_mu)
+std::mutex g_err_mu;
+void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_last_error = m; }
 
 struct DevBuf {   // grow-only device allocation
   void* p = nullptr;
@@ -73,6 +78,10 @@ struct rsi_ctx {
   int64_t n = 0, ncompact = 0, nb = 0;
   bool have_gc = false, have_nb = false, have_med = false;
   int last_scan_med = 0;
+  // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
+  std::vector<std::pair<const char*, double>> phases;
+  // when the context belongs to a pool: one streaming (HBM-bound) phase at a time per GPU
+  std::mutex* hbm_token = nullptr;
 };
 
 namespace {
@@ -82,14 +91,14 @@ namespace {
     hipError_t e__ = (expr);                                                                  \
     if (e__ != hipSuccess) {                                                                  \
       ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);                          \
-      g_last_error = ctx->err;                                                                \
+      set_global_error(ctx->err);                                                             \
       return RSI_ERR_HIP;                                                                     \
     }                                                                                         \
   } while (0)
 
 int fail(rsi_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
-  g_last_error = msg;
+  set_global_error(msg);
   return code;
 }
 
@@ -124,6 +133,19 @@ struct Timer {   // optional HIP-event bracket around one launch
 bool int_quantiles(const std::vector<uint64_t>& h, uint64_t total, rsih::Quantiles& q) {
   return rsih::hist_quantiles_int(h.data(), h.size(), total, q);
 }
+
+struct Phase {   // wall-clock bracket of one pipeline phase (host view)
+  rsi_ctx* ctx; const char* name; double t0; bool open = true;
+  Phase(rsi_ctx* c, const char* nm) : ctx(c), name(nm), t0(now_ms()) {}
+  void stop() {
+    if (!open) return;
+    open = false;
+    const double dt = now_ms() - t0;
+    for (auto& p : ctx->phases) if (p.first == name) { p.second += dt; return; }
+    ctx->phases.push_back({name, dt});
+  }
+  ~Phase() { stop(); }
+};
 
 struct ScanOut {
   double tmedian1 = 0, tsigma1 = 0, tlamda1 = 0, tmedian2 = 0, tsigma2 = 0, tlamda2 = 0;
@@ -278,12 +300,15 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   double tmedian, tsigma, tlamda, target, dev, absmed;
   uint64_t cnt;
   int rc, cal_max;
-  if (!use_med) {
-    if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
-  } else {
-    tmedian = RDmedian;
+  {
+    Phase ph(ctx, "scan.quantiles");
+    if (!use_med) {
+      if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
+    } else {
+      tmedian = RDmedian;
+    }
+    if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
   }
-  if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
   tsigma = absmed / 0.6745;
   tlamda = factor * tsigma;
   if (!use_med) {
@@ -310,8 +335,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int32_t* d_st1 = ctx->status1.as<int32_t>();
   int32_t* d_st1f = ctx->status1f.as<int32_t>();
   int32_t* d_st2 = ctx->status2.as<int32_t>();
-  if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc;
+  { Phase ph(ctx, "scan.pass"); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
 
+  Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
   // definition (App. A Q13) -> host; the edge trimming runs on the device, one thread per run ----
   std::vector<float> hT((size_t)nb);
@@ -345,7 +371,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       }
     }
   }
+  ph_filter.stop();
   // ---- second-pass parameters on the unmarked bins (rsi.cpp:1307-1319 / 1457-1469) ----
+  Phase ph_q2(ctx, "scan.quantiles");
   double tmed2;
   uint64_t k = 0;
   if ((rc = grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k)) != RSI_OK) return rc;
@@ -357,7 +385,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     tlamda = std::max(tlamda, target);
   }
   out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
-  if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc;
+  ph_q2.stop();
+  { Phase ph(ctx, "scan.pass"); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
+  Phase ph_seg(ctx, "scan.segments");
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
   out.status2.resize((size_t)nb);
@@ -370,7 +400,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   if ((rc = upload_runs(ctx, runs, &d_rs, &d_re)) != RSI_OK) return rc;
   std::vector<int64_t> poff(runs.size() + 1, 0);
   std::vector<SegItem> items;
-  const int64_t kPairsPerItem = 1 << 21;
+  const int64_t kPairsPerItem = 1 << 16;   // about 256 pairs per thread: enough workgroups to cover the chip
   for (size_t r = 0; r < runs.size(); ++r) {
     const int len = runs[r].end - runs[r].start + 1;
     poff[r + 1] = poff[r] + len + 1;
@@ -435,6 +465,16 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   HIPCHK(hipSetDevice(ctx->device));
   ctx->ktimes.clear();
   ctx->event_next = 0;
+  ctx->phases.clear();
+  // The per-base kernels are HBM-bound: workers of a pool take turns through this phase so that
+  // each launch has the memory system to itself, while bin-level kernels, copies and host stages of
+  // other chromosomes overlap freely.
+  std::unique_lock<std::mutex> hbm_turn;
+  if (ctx->hbm_token) {
+    Phase ph_wait(ctx, "wait.hbm_turn");
+    hbm_turn = std::unique_lock<std::mutex>(*ctx->hbm_token);
+  }
+  Phase ph_a1(ctx, "a1.classify+nruns");
   ctx->n = n; ctx->ncompact = 0; ctx->nb = 0; ctx->have_gc = ctx->have_nb = ctx->have_med = false;
   rsi_chrom_stats& S = res->stats;
   memset(&S, 0, sizeof(S));
@@ -472,6 +512,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   res->noncode.clear();
   for (const Region& r : noncode) { res->noncode.push_back(r.start); res->noncode.push_back(r.end); }
 
+  ph_a1.stop();
+  Phase ph_gc(ctx, "a2-3.gc");
   // ---- A2/A3: GC table and rescale (K2, K3) ----
   const int32_t* d_src = d_depth;
   const bool want_cap = P.cap > 1;
@@ -505,6 +547,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
   }
 
+  ph_gc.stop();
+  Phase ph_cap(ctx, "a4.cap_median");
   // ---- A4: cap from the median of the uncompacted array (loaddata.cpp:229-240, Q15) ----
   int32_t capval = 0x7fffffff;
   if (want_cap) {
@@ -525,6 +569,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     capval = (int32_t)(q.med * P.cap);   // RD[i] = RDmedian*cap, truncated (loaddata.cpp:238)
   }
 
+  ph_cap.stop();
+  Phase ph_bins(ctx, "a5-9.compact+bins+stats");
   // ---- A5-A9: cap + compaction + bins + statistics (K4) ----
   std::vector<int64_t> cbreak(noncode.size()), cum(noncode.size() + 1, 0);
   for (size_t k = 0; k < noncode.size(); ++k) {
@@ -568,11 +614,12 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     S.RDsd = sqrt(s2 / double((int)ncompact) - mean * mean);
   }
   S.RDmedian = RDmedian;
-  const double t_base_end = now_ms();
-  (void)t_base_end;
+  ph_bins.stop();
+  if (hbm_turn.owns_lock()) hbm_turn.unlock();
 
   std::vector<Candidate> blocks, raw, kept, segs_all;
   if (!(RDmedian < 5)) {   // rsi.cpp:1809-1812
+    Phase ph_nb(ctx, "a9-10.mad+nb");
     // ---- A9: MAD of the 31 interleaved subsamples from their value histograms (rsi.cpp:1127-1143) ----
     double mads[31];
     const uint64_t sublen = (uint64_t)(ncompact / 31);
@@ -628,6 +675,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     S.nb_tmin = tmin;
     ctx->have_nb = true;
 
+    ph_nb.stop();
     rsih::CallerInput in;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     std::vector<int> medint((size_t)nb);
@@ -654,7 +702,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       S.Lmax = so.Lmax; S.trim_escapes += (int)so.escapes; S.inexact_sums = (int)so.inexact;
       for (const Candidate& c : so.segs) segs_all.push_back(c);
       segs = so.segs;
-      rsih::test_block_segments(in, so.status2, segs);   // areblockscnv, rsi.cpp:1847
+      { Phase ph(ctx, "a15.blocks"); rsih::test_block_segments(in, so.status2, segs); }   // areblockscnv, rsi.cpp:1847
       return RSI_OK;
     };
     std::vector<Candidate> tested;
@@ -666,7 +714,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       tested.insert(tested.end(), more.begin(), more.end());
     }
     rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st);
-    rsih::call_from_segments(in, tested, pager, blocks, raw, kept);
+    { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
   }
   const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
   for (int w = 0; w < 4; ++w) {
@@ -697,14 +745,14 @@ rsi_ctx* rsi_hot_create(int device, int* status) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0 || device < 0 || device >= count) {
-    g_last_error = "no usable HIP device (librsi_hot has no CPU fallback)";
+    set_global_error("no usable HIP device (librsi_hot has no CPU fallback)");
     if (status) *status = RSI_ERR_NO_DEVICE;
     return nullptr;
   }
   rsi_ctx* ctx = new rsi_ctx();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-    g_last_error = "hipSetDevice / hipStreamCreate failed";
+    set_global_error("hipSetDevice / hipStreamCreate failed");
     if (status) *status = RSI_ERR_HIP;
     delete ctx;
     return nullptr;
@@ -803,6 +851,13 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
   return ctx->nb;
 }
 
+int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int cap) {
+  if (!ctx) return 0;
+  int k = 0;
+  for (const auto& p : ctx->phases) { if (k < cap) { names[k] = p.first; ms[k] = p.second; } ++k; }
+  return k;
+}
+
 int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap) {
   if (!ctx) return 0;
   int k = 0;
@@ -823,6 +878,102 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
                          kType[c.type < 0 || c.type > 2 ? 2 : c.type], c.qscore, c.end - c.start + 1, c.cnvmed,
                          c.cnviqr / 1.349, c.refmed, c.refiqr / 1.349, r->stats.RDmedian, r->stats.RDsd, -1, -1.0);
   return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pool: `nworkers` host threads, each with its own context (stream + workspace) on one GPU.
+// Chromosomes are independent iterations of the reference's loop (rsi.cpp:2189-2217); the pool
+// hands them out longest first.
+struct rsi_pool {
+  int device = 0;
+  std::vector<rsi_ctx*> workers;
+  std::mutex hbm_token;
+  std::string err;
+};
+
+rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
+  if (nworkers < 1) nworkers = 1;
+  if (nworkers > 64) nworkers = 64;
+  rsi_pool* pool = new rsi_pool();
+  pool->device = device;
+  for (int w = 0; w < nworkers; ++w) {
+    int st = 0;
+    rsi_ctx* c = rsi_hot_create(device, &st);
+    if (!c) {
+      if (status) *status = st;
+      for (rsi_ctx* x : pool->workers) rsi_hot_destroy(x);
+      delete pool;
+      return nullptr;
+    }
+    c->hbm_token = &pool->hbm_token;
+    pool->workers.push_back(c);
+  }
+  if (status) *status = RSI_OK;
+  return pool;
+}
+
+void rsi_pool_destroy(rsi_pool* pool) {
+  if (!pool) return;
+  for (rsi_ctx* c : pool->workers) rsi_hot_destroy(c);
+  delete pool;
+}
+
+int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
+rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
+void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) c->timing = on != 0; }
+const char* rsi_pool_last_error(const rsi_pool* pool) { return pool ? pool->err.c_str() : g_last_error.c_str(); }
+
+int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+  if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
+  std::vector<int> order((size_t)nchrom);
+  for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
+  std::atomic<int> next(0);
+  std::vector<int> rcs((size_t)nchrom, RSI_OK);
+  std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
+  std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
+  std::vector<std::vector<int64_t>> kbases(pool->workers.size());
+  auto work = [&](size_t w) {
+    rsi_ctx* ctx = pool->workers[w];
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= nchrom) break;
+      const int i = order[(size_t)k];
+      out[i] = nullptr;
+      rcs[(size_t)i] = rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
+      if (times) {
+        for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); ktimes[w].push_back({t.name, ms}); kbases[w].push_back(n[i]); }
+        for (const auto& ph : ctx->phases) ptimes[w].push_back(ph);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 1; w < pool->workers.size(); ++w) th.emplace_back(work, w);
+  work(0);
+  for (auto& t : th) t.join();
+  int worst = RSI_OK;
+  for (int i = 0; i < nchrom; ++i) {
+    if (status) status[i] = rcs[(size_t)i];
+    if (rcs[(size_t)i] != RSI_OK && worst == RSI_OK) { worst = rcs[(size_t)i]; pool->err = g_last_error; }
+  }
+  if (times) {   // accumulate into the caller's table (names are static strings)
+    for (size_t w = 0; w < pool->workers.size(); ++w) {
+      for (size_t e = 0; e < ktimes[w].size(); ++e) {
+        int slot = -1;
+        for (int q = 0; q < times->nkernels; ++q) if (times->kernel_name[q] == ktimes[w][e].first) { slot = q; break; }
+        if (slot < 0 && times->nkernels < RSI_MAX_TIMED) { slot = times->nkernels++; times->kernel_name[slot] = ktimes[w][e].first; times->kernel_ms[slot] = 0; times->kernel_launches[slot] = 0; times->kernel_bases[slot] = 0; }
+        if (slot >= 0) { times->kernel_ms[slot] += ktimes[w][e].second; times->kernel_launches[slot] += 1; times->kernel_bases[slot] += kbases[w][e]; }
+      }
+      for (const auto& ph : ptimes[w]) {
+        int slot = -1;
+        for (int q = 0; q < times->nphases; ++q) if (times->phase_name[q] == ph.first) { slot = q; break; }
+        if (slot < 0 && times->nphases < RSI_MAX_TIMED) { slot = times->nphases++; times->phase_name[slot] = ph.first; times->phase_ms[slot] = 0; }
+        if (slot >= 0) times->phase_ms[slot] += ph.second;
+      }
+    }
+  }
+  return worst;
 }
 
 }  // extern "C"
