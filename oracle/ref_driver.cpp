@@ -174,10 +174,12 @@ int ref_load(const ref_params* p, const int32_t* depth, const char* fasta, int32
 
   quiet_begin();
   string FASTA(fasta, (size_t)n);
+  S.GC.resize(0);
   S.GC.resize(n);
   S.GC.assign(false);
   for (int k = 0; k < n; ++k) S.GC[k] = (FASTA[k] == 'G' || FASTA[k] == 'C');   // loaddata.cpp:481-483
   get_noseq_regions(FASTA);
+  S.RD.resize(0);   // Array::resize keeps a shrunken logical size when the capacity already matches
   S.RD.resize(n);
   for (int k = 0; k < n; ++k) S.RD[k] = depth[k];
   rsi::start = 1;
