@@ -71,6 +71,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -f rsicnv_amd/csrc/Makefile` "
                            "(or __graft_entry__.build()); rsicnv_amd has no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64;
+    # if librsi_hot.so were loaded first it would pull /opt/rocm's copy and the second runtime to
+    # touch the GPU would fail with "no ROCm-capable device".  Importing torch first makes our
+    # DT_NEEDED libamdhip64.so.7 resolve to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.rsi_default_params.argtypes = [C.POINTER(RsiParams)]
     L.rsi_hot_create.argtypes = [C.c_int, C.POINTER(C.c_int)]

@@ -2,6 +2,7 @@
 // counter-based generator (synth_core.h) evaluated per base on gfx950, so that multi-gigabase
 // inputs for bench.py are produced directly in HBM.  Input generation only (not timed).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <vector>
 #include "synth_tables.h"
 
@@ -53,8 +54,8 @@ template <class T>
 hipError_t upload(const T* host, size_t count, T** dev) {
   *dev = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(dev), (count ? count : 1) * sizeof(T));
-  if (e != hipSuccess) return e;
-  if (count) e = hipMemcpy(*dev, host, count * sizeof(T), hipMemcpyHostToDevice);
+  if (e == hipSuccess && count) e = hipMemcpy(*dev, host, count * sizeof(T), hipMemcpyHostToDevice);
+  if (e != hipSuccess) fprintf(stderr, "rsi_synth_generate_device: upload of %zu x %zu bytes failed: %s\n", count, sizeof(T), hipGetErrorString(e));
   return e;
 }
 

@@ -1,0 +1,166 @@
+"""GPU: generator twins, the worker pool, the command line against the reference's own binary,
+error behaviour, and size-independent properties at a BASELINE.json size (60 Mb)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import calls_equal, make_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hot():
+    from rsicnv_amd import api
+    h = api.RsiHot(0)
+    yield h
+    h.close()
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_device_generator_equals_host(hotlib, model):
+    import torch
+    from rsicnv_amd import synth
+    plan = synth.make_plan(n=1_234_567, seed=0xFEED + model, model=model, n_events=7, gaps=2, max_len=30000, end_n=7000, gap_len=9000)
+    fasta, depth = synth.generate_host(hotlib, plan)
+    d_fa = torch.empty(plan["n"] + 64, dtype=torch.uint8, device="cuda")
+    d_rd = torch.empty(plan["n"] + 16, dtype=torch.int32, device="cuda")
+    synth.generate_device(hotlib, plan, d_fa.data_ptr(), d_rd.data_ptr())
+    assert np.array_equal(d_fa[:plan["n"]].cpu().numpy(), fasta)
+    assert np.array_equal(d_rd[:plan["n"]].cpu().numpy(), depth)
+
+
+def test_pool_equals_single_context(hot, hotlib):
+    import torch
+    from rsicnv_amd import api, synth
+    plans = [synth.make_plan(n=300_000 + 50_017 * i, seed=0x9000 + i, model=i % 2, n_events=4, gaps=1, max_len=15000, end_n=4000,
+                             gap_len=5000) for i in range(6)]
+    bufs, chroms, single = [], [], []
+    p = api.make_params()
+    for pl in plans:
+        d_fa = torch.empty(pl["n"] + 64, dtype=torch.uint8, device="cuda")
+        d_rd = torch.empty(pl["n"] + 16, dtype=torch.int32, device="cuda")
+        synth.generate_device(hotlib, pl, d_fa.data_ptr(), d_rd.data_ptr())
+        bufs.append((d_fa, d_rd))
+        chroms.append((d_rd.data_ptr(), d_fa.data_ptr(), pl["n"]))
+        single.append(hot.run_device(p, d_rd.data_ptr(), d_fa.data_ptr(), pl["n"]))
+    pool = api.RsiPool(0, 3)
+    for _ in range(2):
+        batch = pool.run(p, chroms)
+        for a, b in zip(single, batch):
+            ok, why = calls_equal(a.calls("calls_raw"), b.calls("calls_raw"), rtol=0)
+            assert ok, why
+            assert a.stats["RDmedian"] == b.stats["RDmedian"] and a.stats["RDsd"] == b.stats["RDsd"]
+    pool.close()
+
+
+def _write_case(tmp, fasta, depth, chrom="chrS"):
+    fa = os.path.join(tmp, "ref.fa")
+    with open(fa, "wb") as f:
+        f.write(f">{chrom}\n".encode())
+        seq = fasta.tobytes()
+        for i in range(0, len(seq), 60):
+            f.write(seq[i:i + 60] + b"\n")
+    with open(fa + ".fai", "w") as f:
+        f.write(f"{chrom}\t{len(fasta)}\t{len(chrom) + 2}\t60\t61\n")
+    rd = os.path.join(tmp, "depth.txt")
+    pos = np.arange(1, len(depth) + 1)
+    with open(rd, "w") as f:
+        f.write("#pos depth\n")
+        np.savetxt(f, np.stack([pos, depth], axis=1), fmt="%d", delimiter="\t")
+    return fa, rd
+
+
+@pytest.mark.parametrize("extra", [[], ["-MED", "-m", "51"], ["-NOGC"]], ids=["nb", "med51", "nogc"])
+def test_cli_output_file_matches_reference_binary(hotlib, tmp_path, extra):
+    import oracle
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref/rsicnv_ref not built")
+    _, fasta, depth = make_case(hotlib, dict(n=400_007, seed=0xC11, model=1, n_events=5, gaps=1, max_len=20000, end_n=5000, gap_len=8000))
+    fa, rd = _write_case(str(tmp_path), fasta, depth)
+    ours, theirs = str(tmp_path / "ours.txt"), str(tmp_path / "ref.txt")
+    exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+    subprocess.run([exe, "rsi", "-f", fa, "-d", rd, "-c", "chrS", "-o", ours, "-np"] + extra, check=True, capture_output=True, timeout=300)
+    subprocess.run([oracle.REF_BIN, "rsi", "-f", fa, "-d", rd, "-c", "chrS", "-o", theirs, "-np"] + extra, check=True,
+                   capture_output=True, timeout=600, cwd=str(tmp_path))
+    a, b = open(ours, "rb").read(), open(theirs, "rb").read()
+    assert a == b, f"output files differ:\n{a.decode()}\n---\n{b.decode()}"
+    assert a.count(b"\n") >= 4
+
+
+def test_error_behaviour(hot, hotlib):
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=300_000, seed=0xE44, model=0, n_events=3, gaps=0, max_len=9000, end_n=0))
+    # chromosome too short for the 20-slice GC adjust: the reference exits (gccontent.cpp:66-71)
+    with pytest.raises(api.RsiError) as e:
+        hot.run(api.make_params(), depth[:4000], fasta[:4000])
+    assert e.value.code == -4
+    # negative depth is outside the contract of the integer histograms
+    bad = depth.copy()
+    bad[1234] = -3
+    with pytest.raises(api.RsiError) as e:
+        hot.run(api.make_params(), bad, fasta)
+    assert e.value.code == -5
+    # "Read depths too low, cannot call" (rsi.cpp:1809-1812): no calls, no error
+    res = hot.run(api.make_params(), (depth // 10).astype(np.int32), fasta)
+    assert res.stats["RDmedian"] < 5 and res.calls("calls_raw") == []
+    # mismatched lengths are the caller's bug
+    with pytest.raises(ValueError):
+        hot.run(api.make_params(), depth[:-1], fasta)
+
+
+def test_properties_at_60mb(hot, hotlib):
+    """BASELINE.json configs[1] size: checks that do not need the (slow) CPU path."""
+    import torch
+    from rsicnv_amd import api, synth
+    plan = synth.config_plan(2)
+    n = plan["n"]
+    d_fa = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    d_rd = torch.empty(n + 16, dtype=torch.int32, device="cuda")
+    synth.generate_device(hotlib, plan, d_fa.data_ptr(), d_rd.data_ptr())
+    p = api.make_params()
+    r1 = hot.run_device(p, d_rd.data_ptr(), d_fa.data_ptr(), n)
+    rdc = hot.fetch("rd_concat")
+    medint = hot.fetch("binmedint")
+    sums = hot.fetch("binsum")
+    st2 = hot.fetch("status2")
+    removed = int(np.sum(r1.noncode[1::2] - r1.noncode[0::2] + 1))
+    m, nb = 101, len(medint)
+    assert len(rdc) == n - removed and nb == len(rdc) // m
+    bins = rdc[:nb * m].reshape(nb, m)
+    assert np.array_equal(np.median(bins, axis=1).astype(np.int32), medint)      # exact order statistic, m odd
+    assert np.array_equal(bins.sum(axis=1, dtype=np.int64), sums)                # checksum of checksums
+    assert rdc.max() <= int(r1.stats["cap_median"] * 4.0)
+    assert r1.stats["RDsd"] == pytest.approx(float(np.sqrt((rdc.astype(np.float64) ** 2).mean() - rdc.astype(np.float64).mean() ** 2)), rel=1e-12)
+    # every implanted event is called with the right type, within two bins of its ends -- except the
+    # last marked run of the chromosome, which the reference never emits
+    calls = r1.calls("calls")
+    for (a, b, code) in plan["events"][:-1]:
+        typ = 0 if code in (1, 2) else 1
+        hit = [c for c in calls if c["type"] == typ and abs(c["start"] - a) <= 2 * m and abs(c["end"] - b) <= 2 * m]
+        assert hit, f"event {(a, b, code)} not called; calls: {[(c['start'], c['end'], c['type']) for c in calls]}"
+    assert np.count_nonzero(st2) / nb < 0.2
+    # idempotence: the inputs are not modified and a second run reproduces every call
+    r2 = hot.run_device(p, d_rd.data_ptr(), d_fa.data_ptr(), n)
+    ok, why = calls_equal(r1.calls("calls_raw"), r2.calls("calls_raw"), rtol=0)
+    assert ok, why
+
+
+def test_parity_20mb_vs_oracle(hot, hotlib, oracle_cls):
+    import oracle
+    from rsicnv_amd import api
+    plan_kw = dict(n=20_000_011, seed=0x20B, model=1, n_events=24, gaps=3, max_len=90000, end_n=10000, gap_len=50000, centromere=300000)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta, snapshots=False)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    assert np.array_equal(hot.fetch("status2"), O.i32("nb_status2"))
+    for which in ("segs", "blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls({"segs": "segs_nb"}.get(which, which)))
+        assert ok, f"{which}: {why}"
+    assert len(res.calls("calls")) >= 15
