@@ -4,6 +4,7 @@
 // candidates survive, so they have to round like the reference's x86-64 build.
 #include "host_calls.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "hostmath.h"
@@ -11,6 +12,21 @@
 namespace rsih {
 
 // ------------------------------------------------------------------------------------------
+namespace {
+inline void bucket_indices_body(const float* x, size_t n, double lo, double dy, uint32_t* idx) {
+  for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)(int64_t)(((double)x[i] - lo) / dy + 0.5);
+}
+__attribute__((target("avx2"))) void bucket_indices_avx2(const float* x, size_t n, double lo, double dy, uint32_t* idx) {
+  bucket_indices_body(x, n, lo, dy, idx);
+}
+void bucket_indices_sse2(const float* x, size_t n, double lo, double dy, uint32_t* idx) { bucket_indices_body(x, n, lo, dy, idx); }
+}  // namespace
+
+void bucket_indices_f32(const float* x, size_t n, double lo, double dy, uint32_t* idx) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) bucket_indices_avx2(x, n, lo, dy, idx); else bucket_indices_sse2(x, n, lo, dy, idx);
+}
+
 double normal_cdf(double x) {
   // erf / erfc rational approximations of Cephes ndtr as used by alglib
   // (alglib/specialfunctions.cpp:3152-3302); numerators/denominators highest power first.
@@ -45,24 +61,29 @@ double normal_cdf(double x) {
 }
 
 // ------------------------------------------------------------------------------------------
-DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream)
-    : d_(d_ptr), n_(n), stream_(stream), pages_((size_t)((n + kMask) >> kBits) + 1) {}
+DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging, size_t staging_bytes)
+    : d_(d_ptr), n_(n), stream_(stream), mirror_(mirror), have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 0),
+      staging_(static_cast<int32_t*>(staging)), staging_elems_((int64_t)(staging_bytes / sizeof(int32_t))) {}
 
 void DepthPager::fetch(int64_t p0, int64_t p1) {
   const int64_t lo = p0 << kBits;
   int64_t hi = ((p1 + 1) << kBits);
   if (hi > n_) hi = n_;
-  if (hi <= lo) { for (int64_t p = p0; p <= p1; ++p) if (!pages_[p]) pages_[p].reset(new int32_t[(size_t)1 << kBits]()); return; }
-  std::vector<int32_t> tmp((size_t)(hi - lo));
-  (void)hipMemcpyAsync(tmp.data(), d_ + lo, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
-  (void)hipStreamSynchronize(stream_);
-  fetched_ += (hi - lo) * (int64_t)sizeof(int32_t);
-  for (int64_t p = p0; p <= p1; ++p) {
-    if (pages_[p]) continue;
-    pages_[p].reset(new int32_t[(size_t)1 << kBits]());
-    const int64_t a = p << kBits, b = std::min(a + (1 << kBits), hi);
-    if (b > a) memcpy(pages_[p].get(), tmp.data() + (a - lo), (size_t)(b - a) * sizeof(int32_t));
+  if (hi > lo) {
+    if (staging_ && staging_elems_ > 0) {   // DMA into pinned memory, then a plain copy into the mirror
+      for (int64_t a = lo; a < hi; a += staging_elems_) {
+        const int64_t k = std::min(staging_elems_, hi - a);
+        (void)hipMemcpyAsync(staging_, d_ + a, (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
+        (void)hipStreamSynchronize(stream_);
+        memcpy(mirror_ + a, staging_, (size_t)k * sizeof(int32_t));
+      }
+    } else {
+      (void)hipMemcpyAsync(mirror_ + lo, d_ + lo, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
+      (void)hipStreamSynchronize(stream_);
+    }
+    fetched_ += (hi - lo) * (int64_t)sizeof(int32_t);
   }
+  for (int64_t p = p0; p <= p1; ++p) have_[(size_t)p] = 1;
 }
 
 void DepthPager::prefetch(int64_t lo, int64_t hi) {
@@ -71,9 +92,9 @@ void DepthPager::prefetch(int64_t lo, int64_t hi) {
   if (hi < lo) return;
   const int64_t p_lo = lo >> kBits, p_hi = hi >> kBits;
   for (int64_t p = p_lo; p <= p_hi;) {
-    if (pages_[p]) { ++p; continue; }
+    if (have_[(size_t)p]) { ++p; continue; }
     int64_t q = p;
-    while (q + 1 <= p_hi && !pages_[q + 1]) ++q;
+    while (q + 1 <= p_hi && !have_[(size_t)(q + 1)]) ++q;
     fetch(p, q);
     p = q + 1;
   }

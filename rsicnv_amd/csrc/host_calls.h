@@ -20,23 +20,34 @@ struct Candidate {     // working record, mirrors cnv_st (rsi.h:8-51)
 
 struct Region { int start, end; };   // inclusive, reference coordinates (rsi::noncodelist)
 
-// Read-only view of an int32 array living in device memory, fetched in 64 KB pages on first touch.
+// Read-only view of an int32 array living in device memory.  A host mirror of the whole array is
+// reserved but never touched up front; 64 KB pages are copied from HBM into it on first use
+// (about 0.1-1 % of a chromosome around the candidates), in one transfer per missing stretch.
 class DepthPager {
  public:
-  DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream);
+  // mirror: host buffer of at least n elements owned by the caller (reused across chromosomes, so
+  // no address space is mapped and unmapped per call); staging: optional pinned buffer for the DMA.
+  DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging = nullptr,
+             size_t staging_bytes = 0);
+  DepthPager(const DepthPager&) = delete;
+  DepthPager& operator=(const DepthPager&) = delete;
   int64_t size() const { return n_; }
-  int operator[](int64_t i) { return page(i >> kBits)[i & kMask]; }
+  int operator[](int64_t i) {
+    if (!have_[(size_t)(i >> kBits)]) fetch(i >> kBits, i >> kBits);
+    return mirror_[i];
+  }
   void prefetch(int64_t lo, int64_t hi);   // [lo, hi] clipped to the array, one copy per missing stretch
   int64_t bytes_fetched() const { return fetched_; }
  private:
   static constexpr int kBits = 14;
-  static constexpr int64_t kMask = (1 << kBits) - 1;
-  const int32_t* page(int64_t p) { if (!pages_[p]) fetch(p, p); return pages_[p].get(); }
   void fetch(int64_t p0, int64_t p1);
   const int32_t* d_;
   int64_t n_;
   hipStream_t stream_;
-  std::vector<std::unique_ptr<int32_t[]>> pages_;
+  int32_t* mirror_ = nullptr;          // malloc'ed, untouched until a page is fetched
+  std::vector<unsigned char> have_;
+  int32_t* staging_ = nullptr;         // pinned, owned by the context
+  int64_t staging_elems_ = 0;
   int64_t fetched_ = 0;
 };
 

@@ -20,6 +20,11 @@ inline double grid_step(const T*) { return 0.01; }
 template <>
 inline double grid_step<int>(const int*) { return 1.0; }
 
+// bucket index (size_t)((x - lo)/dy + 0.5) for a float array, written as uint32 (wufunctions.cpp:396).
+// Separate from the counting loop so that the divisions vectorise; the AVX2 clone is selected at
+// run time.  Same IEEE operations in every variant (no FMA, no reciprocal tricks).
+void bucket_indices_f32(const float* x, size_t n, double lo, double dy, uint32_t* idx);
+
 template <class T>
 Quantiles grid_quantiles(const T* x, size_t n) {
   const double dy = grid_step(x);
@@ -34,6 +39,57 @@ Quantiles grid_quantiles(const T* x, size_t n) {
   const size_t buckets = (size_t)((hi - lo) / dy + 2);
   std::vector<uint32_t> cnt(buckets + 1, 0);
   for (size_t i = 0; i < n; ++i) cnt[(size_t)((x[i] - lo) / dy + 0.5)]++;
+  const size_t r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
+  size_t seen = 0;
+  for (size_t b = 0; b < buckets; ++b) {
+    const size_t upto = seen + cnt[b];
+    if (seen < r1 && upto >= r1) q.lqt = lo + b * dy;
+    if (seen < r2 && upto >= r2) q.med = lo + b * dy;
+    if (seen < r3 && upto >= r3) q.uqt = lo + b * dy;
+    seen = upto;
+  }
+  return q;
+}
+
+// Specialisations for the two hot element types of the candidate tests.
+// int: dy = 1, so (x - lo)/1 + 0.5 truncates to x - lo exactly -- no floating point per element.
+template <>
+inline Quantiles grid_quantiles<int>(const int* x, size_t n) {
+  int lo = x[0], hi = x[0];
+  double acc = 0;   // sums of ints are exact in double (n * max < 2^53)
+  long long isum = 0;
+  for (size_t i = 0; i < n; ++i) { isum += x[i]; lo = x[i] < lo ? x[i] : lo; hi = x[i] > hi ? x[i] : hi; }
+  acc = (double)isum;
+  Quantiles q{(double)lo, acc / (double)n, (double)hi};
+  if (((double)hi - (double)lo) < 1.0) return q;
+  const size_t buckets = (size_t)(((double)hi - (double)lo) / 1.0 + 2);
+  std::vector<uint32_t> cnt(buckets + 1, 0);
+  for (size_t i = 0; i < n; ++i) cnt[(size_t)((long long)x[i] - lo)]++;
+  const size_t r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
+  size_t seen = 0;
+  for (size_t b = 0; b < buckets; ++b) {
+    const size_t upto = seen + cnt[b];
+    if (seen < r1 && upto >= r1) q.lqt = (double)lo + b * 1.0;
+    if (seen < r2 && upto >= r2) q.med = (double)lo + b * 1.0;
+    if (seen < r3 && upto >= r3) q.uqt = (double)lo + b * 1.0;
+    seen = upto;
+  }
+  return q;
+}
+// float: the mean is accumulated in index order as the reference does (double += float).
+template <>
+inline Quantiles grid_quantiles<float>(const float* x, size_t n) {
+  const double dy = 0.01;
+  float flo = x[0], fhi = x[0];
+  double acc = 0;
+  for (size_t i = 0; i < n; ++i) { acc += x[i]; flo = x[i] < flo ? x[i] : flo; fhi = x[i] > fhi ? x[i] : fhi; }
+  const double lo = flo, hi = fhi;
+  Quantiles q{lo, acc / (double)n, hi};
+  if ((hi - lo) < dy) return q;
+  const size_t buckets = (size_t)((hi - lo) / dy + 2);
+  std::vector<uint32_t> cnt(buckets + 1, 0), idx(n);
+  bucket_indices_f32(x, n, lo, dy, idx.data());
+  for (size_t i = 0; i < n; ++i) cnt[idx[i]]++;
   const size_t r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
   size_t seen = 0;
   for (size_t b = 0; b < buckets; ++b) {

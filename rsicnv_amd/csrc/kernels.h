@@ -26,10 +26,12 @@ struct GcAccum {
   unsigned long long sum[kGcLevels];   // sum of depth per window GC count
   unsigned long long cnt[kGcLevels];
   unsigned long long possum, poscnt;   // over depth > 0
-  unsigned int negatives;              // depth < 0 seen (unsupported)
+  unsigned int negatives;              // bit 0: depth < 0 seen (unsupported); bit 1: depth >= 2^21, packed form invalid
   unsigned int pad;
 };
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, hipStream_t stream);
+// packed = 1: one LDS atomic per base (count and sum in one 64-bit word), valid for depths < 2^21;
+// when the result carries flag bit 1 the caller zeroes acc and launches again with packed = 0.
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, hipStream_t stream);
 
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
@@ -38,24 +40,23 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
 struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int negatives; };
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
-// Tail quirks of the 20-slice write-back, fixes out[] and hist[] in place.
+// Must follow launch_gc_rescale: tail quirks of the 20-slice write-back fixed
+// in out[] and hist[], plus the last n % 4 bases, which the streaming kernel leaves out.
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
-                          int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
+                          int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
 // (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;
 //  median_transfer rsi.cpp:1363; bin sums + MAD subsamples rsi.cpp:1127-1157)
 struct BinAccum {
-  unsigned long long sum;        // sum of capped compacted values
-  unsigned long long sq_lo;      // sum of (v*v) & 0xffffffff
-  unsigned long long sq_hi;      // sum of (v*v) >> 32
-  unsigned long long big;        // values >= kHistValues (not in the histograms)
+  unsigned long long big;        // values >= kHistValues (not in the histograms): unsupported by the caller
   unsigned int vmax;
   unsigned int pad;
 };
 // cbreak[k]: compacted index where region k is cut out; cum[k]: bases removed before compacted
 // index cbreak[k] (cum[nreg] = total).  res_hist: [kHistValues][kResClasses] counts of value by
-// class (compacted index mod 31, or 31 for the tail beyond 31*floor(n'/31)).
+// class (compacted index mod 31, or 31 for the tail beyond 31*floor(n'/31)); the chromosome's sum,
+// sum of squares and median all derive from it.
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
                             uint32_t* res_hist, BinAccum* acc, hipStream_t stream);

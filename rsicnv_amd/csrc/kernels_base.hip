@@ -84,12 +84,26 @@ struct GcTile {
   uint32_t pre[kGcLds + 1];
 };
 
-__device__ inline void gc_tile_load(GcTile& t, const uint64_t* __restrict__ gcbits, int64_t nwords, int64_t tile_word0) {
-  // wave 0 loads and scans; callers __syncthreads() afterwards
+// The tile's GC words are requested one tile ahead (by wave 0, two words per lane) and committed
+// to LDS, with their popcount prefix, when the tile is processed.
+struct GcRegs { uint64_t a, b; };
+
+__device__ inline void gc_tile_request(GcRegs& g, const uint64_t* __restrict__ gcbits, int64_t nwords, int64_t tile_word0) {
   if (threadIdx.x < 64) {
     const int l = threadIdx.x;
-    const int64_t gw = tile_word0 - kGcLeft + l;
-    const uint64_t w = (gw >= 0 && gw < nwords) ? gcbits[gw] : 0;
+    const int64_t gw = tile_word0 - kGcLeft + l, gw2 = gw + 64;
+    // out-of-range words read word 0 and are zeroed at commit (keeps the loads branch-free)
+    g.a = gcbits[(gw >= 0 && gw < nwords) ? gw : 0];
+    g.b = gcbits[(l < kGcLds - 64 && gw2 >= 0 && gw2 < nwords) ? gw2 : 0];
+  }
+}
+
+__device__ inline void gc_tile_commit(GcTile& t, const GcRegs& g, int64_t nwords, int64_t tile_word0) {
+  // wave 0 writes and scans; callers __syncthreads() afterwards
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    const int64_t gw = tile_word0 - kGcLeft + l, gw2 = gw + 64;
+    const uint64_t w = (gw >= 0 && gw < nwords) ? g.a : 0;
     t.word[l] = w;
     uint32_t c = __popcll(w), incl = c;
 #pragma unroll
@@ -100,12 +114,8 @@ __device__ inline void gc_tile_load(GcTile& t, const uint64_t* __restrict__ gcbi
     t.pre[l] = incl - c;
     const uint32_t total = __shfl(incl, 63);
     // remaining words 64..69 by lanes 0..5
-    uint64_t w2 = 0;
-    if (l < kGcLds - 64) {
-      const int64_t gw2 = tile_word0 - kGcLeft + 64 + l;
-      w2 = (gw2 >= 0 && gw2 < nwords) ? gcbits[gw2] : 0;
-      t.word[64 + l] = w2;
-    }
+    const uint64_t w2 = (l < kGcLds - 64 && gw2 >= 0 && gw2 < nwords) ? g.b : 0;
+    if (l < kGcLds - 64) t.word[64 + l] = w2;
     uint32_t c2 = __popcll(w2), incl2 = c2;
 #pragma unroll
     for (int d = 1; d < 8; d <<= 1) {
@@ -135,54 +145,154 @@ __device__ inline int gc_window(const GcTile& t, int64_t i, int64_t n, int64_t f
 }
 
 // ------------------------------------------------------------------------------------------
-// K2  gc_hist
-constexpr int kGcRep = 8;   // LDS replicas per GC level, selected by lane & 7 (spreads hot levels over banks)
+// Shared skeleton of the two GC streaming kernels (K2, K3).  Per tile of 4096 bases:
+//   1. the tile's depth is requested with four coalesced 16-byte loads per thread, one tile ahead
+//      of its use (registers double-buffered), so a workgroup always has 16 KB in flight;
+//   2. meanwhile the window GC count of every base of the tile is produced cooperatively into LDS
+//      as one byte per base: each thread takes 16 consecutive bases, two rank queries for the
+//      first and one leaving/entering bit pair for each of the others;
+//   3. each thread then consumes its four quads with one 4-byte LDS read of counts per quad.
+struct TileRegs { int4 q[kTileBases / (4 * kThreads)]; };
 
+__device__ inline void tile_request(TileRegs& r, const int32_t* __restrict__ depth, int64_t base, int64_t n) {
+  // Branch-free: quads that are not completely inside the array read quad 0 instead (ignored later),
+  // so the four loads issue back to back with nothing waiting in between.
+#pragma unroll
+  for (int k = 0; k < kTileBases / (4 * kThreads); ++k) {
+    const int64_t q = base + 4 * (int64_t)(k * kThreads + threadIdx.x);
+    const int64_t qs = (q + 4 <= n) ? q : 0;
+    r.q[k] = *reinterpret_cast<const int4*>(depth + qs);
+  }
+}
+
+// The ragged last quad of the chromosome (n % 4 != 0) is left to the tail kernels
+// (k_gc_hist_tail, k_gc_tail_fixup): the streaming kernels only consume whole quads, so nothing in
+// their loop body waits on a memory operation other than the tile that was requested one trip ago.
+
+// 16 mask bits starting at staged bit `rel` (rel + 16 stays inside the staged words)
+__device__ inline uint32_t gc_field16(const GcTile& t, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  uint64_t v = t.word[k] >> b;
+  if (b > 48) v |= t.word[k + 1] << (64 - b);
+  return (uint32_t)v & 0xffffu;
+}
+
+// Window counts of the tile's bases into s_g (one byte each).  Thread t covers bases 16t..16t+15.
+__device__ inline void tile_window_counts(const GcTile& gt, unsigned char* s_g, int64_t base, int64_t n, int64_t first_bit) {
+  const int64_t i0 = base + 16 * (int64_t)threadIdx.x;
+  uint32_t c[16];
+  const bool interior = base >= 101 && base + kTileBases - 1 <= n - 102;   // no edge clamping anywhere in the tile
+  if (interior) {
+    const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
+    uint32_t cnt = gc_rank(gt, rel + 201) - gc_rank(gt, rel);
+    const uint32_t leave = gc_field16(gt, rel), enter = gc_field16(gt, rel + 201);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      c[j] = cnt;
+      cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = (i0 + j < n) ? (uint32_t)gc_window(gt, i0 + j, n, first_bit) : 0u;
+  }
+  uint4 packed;
+  packed.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+  packed.y = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+  packed.z = c[8] | (c[9] << 8) | (c[10] << 16) | (c[11] << 24);
+  packed.w = c[12] | (c[13] << 8) | (c[14] << 16) | (c[15] << 24);
+  *reinterpret_cast<uint4*>(s_g + 16 * threadIdx.x) = packed;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  gc_hist.  PACKED: one 64-bit LDS atomic per base adds (1 << 40) + depth, i.e. count and sum
+// together; valid while every depth is below 2^21 and a workgroup sees at most 64 tiles (sum field
+// < 2^40, count field < 2^24).  Larger depths raise flag bit 1 and the host re-runs the two-atomic
+// form (PACKED = false).
+constexpr int kGcRep = 16;  // LDS replicas per GC level, selected by lane & 15: lanes sharing a replica are 64 bases
+                            // apart, where the window count has usually moved on (neighbouring bases share it)
+constexpr int kGcMaxTilesPerWg = 64;
+
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict__ depth,
                                                       const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
                                                       GcAccum* __restrict__ acc) {
   __shared__ GcTile gt;
+  __shared__ __align__(16) unsigned char s_g[kTileBases];
   __shared__ unsigned long long s_sum[kGcLevels * kGcRep];
-  __shared__ unsigned int s_cnt[kGcLevels * kGcRep];
-  for (int e = threadIdx.x; e < kGcLevels * kGcRep; e += kThreads) { s_sum[e] = 0; s_cnt[e] = 0; }
+  __shared__ unsigned int s_cnt[PACKED ? 1 : kGcLevels * kGcRep];
+  for (int e = threadIdx.x; e < kGcLevels * kGcRep; e += kThreads) { s_sum[e] = 0; if (!PACKED) s_cnt[e] = 0; }
   unsigned long long possum = 0, poscnt = 0;
   unsigned int neg = 0;
+  int vmax = 0;
   const int rep = threadIdx.x & (kGcRep - 1);
   const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Two register sets used alternately (no copies): the set requested during trip t is consumed in
+  // trip t+1, after that trip's window counts, so a request has a whole trip to land.
+  auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
     const int64_t base = tile * kTileBases;
-    __syncthreads();   // previous tile's readers are done with gt (and the zeroing above)
-    gc_tile_load(gt, gcbits, nwords, base / 64);
-    __syncthreads();
     const int64_t first_bit = base - kGcLeft * 64;
+    __syncthreads();   // previous tile's consumers are done with gt / s_g (and the zeroing above)
+    gc_tile_commit(gt, gcur, nwords, base / 64);
+    __syncthreads();
+    tile_window_counts(gt, s_g, base, n, first_bit);
+    if (tile + gridDim.x < ntiles) {
+      tile_request(nxt, depth, (tile + gridDim.x) * kTileBases, n);
+      gc_tile_request(gnxt, gcbits, nwords, (tile + gridDim.x) * kGcWords);
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kTileBases / (4 * kThreads); ++k) {
-      const int64_t q = base + 4 * (int64_t)(k * kThreads + threadIdx.x);
-      if (q >= n) continue;
-      int v[4] = {0, 0, 0, 0};
-      int cntv = 4;
-      if (q + 4 <= n) {
-        const int4 d = *reinterpret_cast<const int4*>(depth + q);
-        v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w;
-      } else {
-        cntv = (int)(n - q);
-        for (int j = 0; j < cntv; ++j) v[j] = depth[q + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j >= cntv) break;
-        const int g = gc_window(gt, q + j, n, first_bit);
-        atomicAdd(&s_sum[g * kGcRep + rep], (unsigned long long)(long long)v[j]);
-        atomicAdd(&s_cnt[g * kGcRep + rep], 1u);
-        if (v[j] > 0) { possum += (unsigned long long)v[j]; poscnt += 1; }
-        if (v[j] < 0) neg = 1;
-      }
+      const int li = 4 * (k * kThreads + threadIdx.x);
+      const int64_t q = base + li;
+      if (q + 4 > n) continue;
+      const uint32_t g4 = *reinterpret_cast<const uint32_t*>(s_g + li);
+      // Consecutive bases often share the window count: values of equal count inside the quad are
+      // merged before the LDS atomic.  Named components only (a runtime-indexed array would live in
+      // scratch memory).
+      unsigned long long pend = 0; uint32_t pend_g = 0xffffffffu; unsigned int pend_c = 0;
+      auto flush = [&]() {
+        if (pend_g == 0xffffffffu) return;
+        if (PACKED) atomicAdd(&s_sum[pend_g * kGcRep + rep], pend);
+        else { atomicAdd(&s_sum[pend_g * kGcRep + rep], pend); atomicAdd(&s_cnt[pend_g * kGcRep + rep], pend_c); }
+      };
+      auto one = [&](int val, uint32_t g) {
+        if (g != pend_g) { flush(); pend_g = g; pend = 0; pend_c = 0; }
+        pend += PACKED ? (1ull << 40) + (unsigned long long)(unsigned int)val : (unsigned long long)(long long)val;
+        pend_c += 1;
+        if (val > 0) { possum += (unsigned long long)val; poscnt += 1; }
+        if (val < 0) neg = 1;
+        vmax = val > vmax ? val : vmax;
+      };
+      one(cur.q[k].x, g4 & 0xffu);
+      one(cur.q[k].y, (g4 >> 8) & 0xffu);
+      one(cur.q[k].z, (g4 >> 16) & 0xffu);
+      one(cur.q[k].w, g4 >> 24);
+      flush();
     }
+  };
+  TileRegs ra, rb;
+  GcRegs ga = {0, 0}, gb = {0, 0};
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) {
+    tile_request(ra, depth, tile * kTileBases, n);
+    gc_tile_request(ga, gcbits, nwords, tile * kGcWords);
   }
+  while (tile < ntiles) {
+    trip(ra, ga, rb, gb, tile);
+    tile += gridDim.x;
+    if (tile >= ntiles) break;
+    trip(rb, gb, ra, ga, tile);
+    tile += gridDim.x;
+  }
+  if (PACKED && vmax >= (1 << 21)) neg |= 2;   // packed fields could overflow: results of this launch are discarded
   __syncthreads();
   for (int g = threadIdx.x; g < kGcLevels; g += kThreads) {
     unsigned long long s = 0, c = 0;
-    for (int r = 0; r < kGcRep; ++r) { s += s_sum[g * kGcRep + r]; c += s_cnt[g * kGcRep + r]; }
+    for (int r = 0; r < kGcRep; ++r) {
+      const unsigned long long w = s_sum[g * kGcRep + r];
+      if (PACKED) { s += w & ((1ull << 40) - 1); c += w >> 40; }
+      else { s += w; c += s_cnt[g * kGcRep + r]; }
+    }
     if (c) { atomicAdd(&acc->sum[g], s); atomicAdd(&acc->cnt[g], c); }
   }
   // wave reduction of the positive-depth sums, one atomic per wave
@@ -193,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
   }
   if (lane_id() == 0) {
     if (poscnt) { atomicAdd(&acc->possum, possum); atomicAdd(&acc->poscnt, poscnt); }
-    if (neg) atomicOr(&acc->negatives, 1u);
+    if (neg) atomicOr(&acc->negatives, neg);
   }
 }
 
@@ -201,7 +311,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
 // K3  gc_rescale (+ value histogram for the cap median)
 constexpr int kValLds = 256;   // values below this are counted in LDS, [value][32 lane phases]
 
-__device__ inline void value_hist_add(unsigned int* s_hist, uint32_t* __restrict__ ghist, ValueHistAux* aux, int v,
+// rare path (values outside the LDS range): kept out of line so the unrolled callers stay small
+__device__ __attribute__((noinline)) void value_hist_add(unsigned int* s_hist, uint32_t* __restrict__ ghist, ValueHistAux* aux, int v,
                                       int phase) {
   if (v >= 0 && v < kValLds) atomicAdd(&s_hist[v * 32 + phase], 1u);
   else if (v >= 0 && v < kHistValues) atomicAdd(&ghist[v], 1u);
@@ -216,48 +327,65 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          double rdmean, int32_t* __restrict__ out,
                                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
   __shared__ GcTile gt;
+  __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
   __shared__ double s_table[kGcLevels];
   __shared__ unsigned int s_hist[kValLds * 32];
   for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
   if (ADJUST) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
   const int phase = threadIdx.x & 31;
   const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
     const int64_t base = tile * kTileBases;
     const int64_t first_bit = base - kGcLeft * 64;
     if (ADJUST) {
       __syncthreads();
-      gc_tile_load(gt, gcbits, nwords, base / 64);
+      gc_tile_commit(gt, gcur, nwords, base / 64);
+      __syncthreads();
+      tile_window_counts(gt, s_g, base, n, first_bit);
+    }
+    if (tile + gridDim.x < ntiles) {
+      tile_request(nxt, depth, (tile + gridDim.x) * kTileBases, n);
+      if (ADJUST) gc_tile_request(gnxt, gcbits, nwords, (tile + gridDim.x) * kGcWords);
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kTileBases / (4 * kThreads); ++k) {
-      const int64_t q = base + 4 * (int64_t)(k * kThreads + threadIdx.x);
-      if (q >= n) continue;
-      int v[4] = {0, 0, 0, 0};
-      int cntv = 4;
-      if (q + 4 <= n) {
-        const int4 d = *reinterpret_cast<const int4*>(depth + q);
-        v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w;
+      const int li = 4 * (k * kThreads + threadIdx.x);
+      const int64_t q = base + li;
+      if (q + 4 > n) continue;
+      const uint32_t g4 = ADJUST ? *reinterpret_cast<const uint32_t*>(s_g + li) : 0u;
+      // named components only: a runtime-indexed array would live in scratch memory
+      auto one = [&](int val, uint32_t g) -> int {
+        if (ADJUST) val = (int)((double)val * rdmean / s_table[g] + 0.5);   // gccontent.cpp:89, truncation
+        return val;
+      };
+      const int v0 = one(cur.q[k].x, g4 & 0xffu);
+      const int v1 = one(cur.q[k].y, (g4 >> 8) & 0xffu);
+      const int v2 = one(cur.q[k].z, (g4 >> 16) & 0xffu);
+      const int v3 = one(cur.q[k].w, g4 >> 24);
+      if (((unsigned)v0 | (unsigned)v1 | (unsigned)v2 | (unsigned)v3) < (unsigned)kValLds) {   // the common case, branch-free
+        atomicAdd(&s_hist[v0 * 32 + phase], 1u); atomicAdd(&s_hist[v1 * 32 + phase], 1u);
+        atomicAdd(&s_hist[v2 * 32 + phase], 1u); atomicAdd(&s_hist[v3 * 32 + phase], 1u);
       } else {
-        cntv = (int)(n - q);
-        for (int j = 0; j < cntv; ++j) v[j] = depth[q + j];
+        value_hist_add(s_hist, ghist, aux, v0, phase); value_hist_add(s_hist, ghist, aux, v1, phase);
+        value_hist_add(s_hist, ghist, aux, v2, phase); value_hist_add(s_hist, ghist, aux, v3, phase);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j >= cntv) break;
-        if (ADJUST) {
-          const int g = gc_window(gt, q + j, n, first_bit);
-          // RDA[k] = RD[i]*RDmean/GCRD[nGC] + 0.5, truncated to int (gccontent.cpp:89)
-          v[j] = (int)((double)v[j] * rdmean / s_table[g] + 0.5);
-        }
-        value_hist_add(s_hist, ghist, aux, v[j], phase);
-      }
-      if (out) {
-        if (cntv == 4) *reinterpret_cast<int4*>(out + q) = make_int4(v[0], v[1], v[2], v[3]);
-        else for (int j = 0; j < cntv; ++j) out[q + j] = v[j];
-      }
+      if (out) *reinterpret_cast<int4*>(out + q) = make_int4(v0, v1, v2, v3);
     }
+  };
+  TileRegs ra, rb;
+  GcRegs ga = {0, 0}, gb = {0, 0};
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) {
+    tile_request(ra, depth, tile * kTileBases, n);
+    if (ADJUST) gc_tile_request(ga, gcbits, nwords, tile * kGcWords);
+  }
+  while (tile < ntiles) {
+    trip(ra, ga, rb, gb, tile);
+    tile += gridDim.x;
+    if (tile >= ntiles) break;
+    trip(rb, gb, ra, ga, tile);
+    tile += gridDim.x;
   }
   __syncthreads();
   for (int v = threadIdx.x; v < kValLds; v += kThreads) {
@@ -267,47 +395,95 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   }
 }
 
-// Tail of the 20-slice write-back (gccontent.cpp:156-175; App. A Q2/Q3).  One thread.
+// The last n % 4 bases for K2 (one thread): they lie in the stale-window zone i >= n-101, whose
+// count is that of [n-202, n-2] (App. A Q1).
+__global__ void k_gc_hist_tail(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                               GcAccum* __restrict__ acc) {
+  if (blockIdx.x != 0 || threadIdx.x != 0 || (n & 3) == 0) return;
+  int g = 0;
+  for (int64_t i = n - 202; i <= n - 2; ++i) g += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
+  for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
+    const int v = depth[i];
+    atomicAdd(&acc->sum[g], (unsigned long long)(long long)v);
+    atomicAdd(&acc->cnt[g], 1ull);
+    if (v > 0) { atomicAdd(&acc->possum, (unsigned long long)v); atomicAdd(&acc->poscnt, 1ull); }
+    if (v < 0) atomicOr(&acc->negatives, 1u);
+  }
+}
+
+// Tail of the 20-slice write-back (gccontent.cpp:156-175; App. A Q2/Q3) and the ragged last quad
+// that the streaming kernel leaves out.  One thread.  adjust = 0: only the ragged quad's values are
+// added to the histogram (the -NOGC path has no slices).
 __global__ void k_gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
-                                const double* __restrict__ table, double rdmean, int32_t* __restrict__ out,
+                                const double* __restrict__ table, double rdmean, int adjust, int32_t* __restrict__ out,
                                 uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const int64_t S = n / 20, r = n - 20 * S;
-  if (r == 0) return;
-  auto hist_move = [&](int from, int to) {
-    if (from == to) return;
-    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
-    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
+  const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
+  auto hist_add = [&](int to) {
     if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
     else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
     else atomicOr(&aux->negatives, 1u);
   };
+  auto hist_sub = [&](int from) {
+    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
+    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
+  };
+  if (!adjust) {
+    for (int64_t i = ragged; i < n; ++i) hist_add(depth[i]);
+    return;
+  }
+  const int64_t S = n / 20, r = n - 20 * S;   // r >= n % 4, so the ragged bases are among the last r
   if (r >= 2) {
     int gtail = 0;   // fresh edge window [n-201, n-1]
     for (int64_t i = n - 201; i < n; ++i) gtail += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
     for (int64_t k = 0; k < r; ++k) {
       const int nv = (int)((double)depth[20 * S + k] * rdmean / table[gtail] + 0.5);
       const int64_t idx = n - 201 + k;
-      hist_move(out[idx], nv);
+      hist_sub(out[idx]); hist_add(nv);
       out[idx] = nv;
     }
   }
   for (int64_t k = 0; k < r; ++k) {   // the last r bases keep their unadjusted depth
     const int64_t idx = 20 * S + k;
-    hist_move(out[idx], depth[idx]);
+    if (idx < ragged) hist_sub(out[idx]);
+    hist_add(depth[idx]);
     out[idx] = depth[idx];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // K4  cap_compact_bin.  One workgroup per tile of TB bins (TB*m compacted bases) staged in LDS.
-__device__ inline int upper_bound_i64(const int64_t* a, int n, int64_t key) {   // first index with a[idx] > key
-  int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
-  return lo;
+//
+// Compaction is a piecewise shift: compacted index p maps to source index p + cum[k], k = number of
+// removed regions with cbreak <= p.  A tile that no region cuts (nearly all of them) is one
+// contiguous source range; its 16-byte loads (destination-aligned, so the compacted copy leaves as
+// 16-byte stores straight from registers) are requested one tile ahead of use, i.e. the loads of
+// tile t+1 are in flight while the medians of tile t are computed.
+// Tiles cut by a region take the generic segment loop.
+//
+// Per value: cap, LDS store, one LDS atomic into the [value][MAD residue class] histogram.
+// Sum / sum of squares / median of the chromosome are all derived from that histogram on the host.
+struct __attribute__((packed, aligned(4))) Quad4 { int x, y, z, w; };   // 16 bytes, dword-aligned
+constexpr int kRegLds = 256;   // removed regions mirrored in LDS (the list is short; more stay in HBM)
+
+struct RegionTable {
+  const int64_t* cbreak; const int64_t* cum; int nreg;
+  int64_t* s_break; int64_t* s_cum;   // LDS mirror of the first kRegLds entries (+1 for cum)
+  __device__ int64_t brk(int k) const { return k < kRegLds ? s_break[k] : cbreak[k]; }
+  __device__ int64_t shift(int k) const { return k <= kRegLds ? s_cum[k] : cum[k]; }
+};
+
+// rare path (values outside the LDS range, partial quads): kept out of line
+__device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int x, int cls) {
+  if (x >= 0 && x < vr) atomicAdd(&s_hist[x * kResClasses + cls], 1u);
+  else if (x >= 0 && x < kHistValues) atomicAdd(&res_hist[(size_t)x * kResClasses + cls], 1u);
+  else { atomicAdd(&acc->big, 1ull); atomicMax(&acc->vmax, (unsigned int)x); }
 }
 
-__global__ __launch_bounds__(kThreads) void k_cap_compact_bin(
+// MAXV: 16-byte loads per thread and tile.  EPT: values per thread in the median phase held in
+// registers (4 threads per bin); EPT = 0 keeps them in LDS (any m / any thread split).
+template <int MAXV, int EPT>
+__global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_bin(
     const int32_t* __restrict__ src, int64_t n, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
     int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr /* LDS histogram value range, power of two */,
     int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
@@ -317,101 +493,161 @@ __global__ __launch_bounds__(kThreads) void k_cap_compact_bin(
   const int tile_elems = TB * m;
   const int tile_pad = (tile_elems + 3) & ~3;
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)tile_pad * 4);   // [vr][32]
+  __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
+  for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  __syncthreads();
+  const RegionTable R{cbreak, cum, nreg, s_break, s_cum};
 
   const int64_t lim31 = (ncompact / 31) * 31;
   const int64_t nb = ncompact / m;
   const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
-  unsigned long long t_sum = 0, t_sqlo = 0, t_sqhi = 0;
   const int parts = kThreads / TB;          // threads cooperating on one bin
   const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t P0 = tile * tile_elems;
-    const int64_t P1 = (P0 + tile_elems < ncompact) ? P0 + tile_elems : ncompact;
-    __syncthreads();   // s_val free (and s_hist zeroed on the first trip)
-    // ---- stage the tile: contiguous source segments between removed regions ----
-    int k = upper_bound_i64(cbreak, nreg, P0);   // regions already cut out before P0
-    int64_t seg = P0;
-    while (seg < P1) {
-      const int64_t nxt = (k < nreg && cbreak[k] < P1) ? cbreak[k] : P1;
-      const int64_t len = nxt - seg;
-      if (len > 0) {
-        const int64_t soff = seg + cum[k];
-        const int mis = (int)(soff & 3);
-        const int64_t a = soff - mis;
-        const int dst = (int)(seg - P0);
-        for (int64_t i4 = threadIdx.x; i4 * 4 < len + mis; i4 += kThreads) {
-          const int64_t s = a + 4 * i4;
-          int v[4];
-          if (s + 4 <= n) {
-            const int4 d = *reinterpret_cast<const int4*>(src + s);
-            v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w;
-          } else {
-            for (int j = 0; j < 4; ++j) v[j] = (s + j < n) ? src[s + j] : 0;
-          }
+  // tile geometry: k = regions cut out at or before P0; a tile is `plain` when no region cuts it
+  int k = 0;
+  auto geometry = [&](int64_t tile, int64_t& P0, int64_t& P1, bool& plain, int64_t& soff) {
+    P0 = tile * tile_elems;
+    P1 = (P0 + tile_elems < ncompact) ? P0 + tile_elems : ncompact;
+    while (k < nreg && R.brk(k) <= P0) ++k;   // tiles are visited in increasing order
+    plain = (k >= nreg) || (R.brk(k) >= P1);
+    soff = P0 + R.shift(k);
+  };
+  // Destination-aligned quads: thread idx owns compacted elements 4*idx .. 4*idx+3 of the tile and
+  // loads them with one 16-byte load from src + soff + 4*idx, which is only dword-aligned in the
+  // source (global_load_dwordx4 needs no more on gfx950).  Whole quads only; the partial quad at
+  // the end of the chromosome's last tile is fetched at consume time.
+  int4 regs[MAXV];
+  auto request = [&](int64_t soff, int cnt) {   // branch-free: quads outside the tile re-read quad 0 (ignored later)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int64_t e = 4 * i4 + j - mis;
-            if (e < 0 || e >= len) continue;
-            int x = v[j];
-            if (x > capval) x = capval;
-            s_val[dst + e] = x;
-            const int64_t p = seg + e;                       // compacted index
-            const int cls = p < lim31 ? (int)((uint32_t)p % 31u) : 31;   // n < 2^31 (checked by the caller)
-            if (x >= 0 && x < vr) atomicAdd(&s_hist[x * kResClasses + cls], 1u);
-            else if (x >= 0 && x < kHistValues) atomicAdd(&res_hist[(size_t)x * kResClasses + cls], 1u);
-            else { atomicAdd(&acc->big, 1ull); atomicMax(&acc->vmax, (unsigned int)x); }
-            const unsigned long long ux = (unsigned long long)(long long)x;
-            const unsigned long long sq = ux * ux;
-            t_sum += ux; t_sqlo += sq & 0xffffffffull; t_sqhi += sq >> 32;
-          }
+    for (int i = 0; i < MAXV; ++i) {
+      const int e0 = 4 * (i * kThreads + (int)threadIdx.x);
+      const Quad4 v = *reinterpret_cast<const Quad4*>(src + (e0 + 4 <= cnt ? soff + e0 : 0));
+      regs[i] = make_int4(v.x, v.y, v.z, v.w);
+    }
+  };
+
+  int64_t P0, P1, soff; bool plain;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) { geometry(tile, P0, P1, plain, soff); if (plain) request(soff, (int)(P1 - P0)); }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int cnt = (int)(P1 - P0);
+    __syncthreads();   // s_val free (and s_hist zeroed on the first trip)
+    if (plain) {
+      // ---- consume the requested quads: cap, LDS store (16 bytes), histogram, rdc store (16 bytes) ----
+      const uint32_t p0mod = (uint32_t)(P0 % 31);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int e0 = 4 * (i * kThreads + (int)threadIdx.x);   // tile-local index of the quad's first value
+        if (e0 >= cnt) continue;
+        int4 d = regs[i];
+        const bool whole = e0 + 4 <= cnt;
+        if (!whole) {   // the chromosome's last, partial quad
+          d.x = src[soff + e0]; d.y = e0 + 1 < cnt ? src[soff + e0 + 1] : 0; d.z = e0 + 2 < cnt ? src[soff + e0 + 2] : 0; d.w = 0;
+        }
+        d.x = d.x > capval ? capval : d.x; d.y = d.y > capval ? capval : d.y;
+        d.z = d.z > capval ? capval : d.z; d.w = d.w > capval ? capval : d.w;
+        *reinterpret_cast<int4*>(s_val + e0) = d;
+        if (whole) *reinterpret_cast<int4*>(rdc + P0 + e0) = d;
+        else { rdc[P0 + e0] = d.x; if (e0 + 1 < cnt) rdc[P0 + e0 + 1] = d.y; if (e0 + 2 < cnt) rdc[P0 + e0 + 2] = d.z; }
+        uint32_t c0 = (p0mod + (uint32_t)e0) % 31u;            // (P0 + e0) mod 31
+        const uint32_t c1 = c0 == 30u ? 0u : c0 + 1u, c2 = c1 == 30u ? 0u : c1 + 1u, c3 = c2 == 30u ? 0u : c2 + 1u;
+        if (whole && P0 + e0 + 3 < lim31 && ((unsigned)d.x | (unsigned)d.y | (unsigned)d.z | (unsigned)d.w) < (unsigned)vr) {
+          // the common case, branch-free: four LDS atomics into [value][residue class]
+          atomicAdd(&s_hist[d.x * kResClasses + c0], 1u); atomicAdd(&s_hist[d.y * kResClasses + c1], 1u);
+          atomicAdd(&s_hist[d.z * kResClasses + c2], 1u); atomicAdd(&s_hist[d.w * kResClasses + c3], 1u);
+        } else {
+          auto count = [&](int x, int e, uint32_t cls) {
+            if (e < cnt) hist_value(s_hist, res_hist, acc, vr, x, (P0 + e) < lim31 ? (int)cls : 31);
+          };
+          count(d.x, e0, c0); count(d.y, e0 + 1, c1); count(d.z, e0 + 2, c2); count(d.w, e0 + 3, c3);
         }
       }
-      seg = nxt;
-      if (k < nreg && cbreak[k] == nxt) ++k;
+    } else {
+      // ---- generic: contiguous source segments between removed regions ----
+      int kk = k;
+      int64_t seg = P0;
+      while (seg < P1) {
+        const int64_t nxt = (kk < nreg && R.brk(kk) < P1) ? R.brk(kk) : P1;
+        const int64_t len = nxt - seg;
+        if (len > 0) {
+          const int64_t so = seg + R.shift(kk);
+          const int dst = (int)(seg - P0);
+          for (int64_t e = threadIdx.x; e < len; e += kThreads) {
+            int x = src[so + e];
+            if (x > capval) x = capval;
+            s_val[dst + e] = x;
+            rdc[seg + e] = x;
+            const int64_t p = seg + e;
+            hist_value(s_hist, res_hist, acc, vr, x, p < lim31 ? (int)((uint32_t)p % 31u) : 31);
+          }
+        }
+        seg = nxt;
+        if (kk < nreg && R.brk(kk) == nxt) ++kk;
+      }
     }
     __syncthreads();
-    // ---- compacted, capped depth back to HBM (16-byte stores; P0 is a multiple of 4) ----
-    const int cnt = (int)(P1 - P0);
-    for (int i4 = threadIdx.x; i4 * 4 < cnt; i4 += kThreads) {
-      if (i4 * 4 + 4 <= cnt) *reinterpret_cast<int4*>(rdc + P0 + 4 * i4) = *reinterpret_cast<const int4*>(s_val + 4 * i4);
-      else for (int j = 4 * i4; j < cnt; ++j) rdc[P0 + j] = s_val[j];
-    }
+    // ---- request the next tile now: its loads fly during the store + median phase ----
+    const int64_t cur_tile = tile;
+    if (tile + gridDim.x < ntiles) { geometry(tile + gridDim.x, P0, P1, plain, soff); if (plain) request(soff, (int)(P1 - P0)); }
     // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin ----
     const int b_local = threadIdx.x / parts, part = threadIdx.x % parts;
-    const int64_t b = tile * TB + b_local;
-    const bool active = b < nb && b_local < TB;
+    const int64_t b = cur_tile * TB + b_local;
+    const bool active = b < nb;
     const int32_t* x = s_val + b_local * m;
     int lo = 0x7fffffff, hi = (int)0x80000000;
     long long ssum = 0;
-    if (active) for (int j = part; j < m; j += parts) { const int v = x[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; ssum += v; }
-    for (int d = 1; d < parts; d <<= 1) {
-      const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d);
-      const long long os = __shfl_xor(ssum, d);
-      lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; ssum += os;
-    }
-    // bisection on the value: smallest v with #{x <= v} >= kth
-    while (__any(active && lo < hi)) {
-      const int mid = (int)(((long long)lo + (long long)hi) >> 1);
-      int c = 0;
-      if (active && lo < hi) for (int j = part; j < m; j += parts) c += x[j] <= mid;
-      for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
-      if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
+    if (EPT > 0) {
+      // the thread's share of the bin in registers; slots past the bin hold INT_MAX (never <= mid)
+      int r[EPT > 0 ? EPT : 1];
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int j = part + parts * i;
+        r[i] = (active && j < m) ? x[j] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const bool in = active && part + parts * i < m;
+        const int v = r[i];
+        lo = (in && v < lo) ? v : lo; hi = (in && v > hi) ? v : hi; ssum += in ? v : 0;
+      }
+      for (int d = 1; d < parts; d <<= 1) {
+        const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d);
+        const long long os = __shfl_xor(ssum, d);
+        lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; ssum += os;
+      }
+      while (__any(active && lo < hi)) {   // bisection on the value: smallest v with #{x <= v} >= kth
+        const int mid = (int)(((long long)lo + (long long)hi) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) c += r[i] <= mid;
+        for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
+        if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
+      }
+    } else {
+      if (active) for (int j = part; j < m; j += parts) { const int v = x[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; ssum += v; }
+      for (int d = 1; d < parts; d <<= 1) {
+        const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d);
+        const long long os = __shfl_xor(ssum, d);
+        lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; ssum += os;
+      }
+      while (__any(active && lo < hi)) {
+        const int mid = (int)(((long long)lo + (long long)hi) >> 1);
+        int c = 0;
+        if (active && lo < hi) for (int j = part; j < m; j += parts) c += x[j] <= mid;
+        for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
+        if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
+      }
     }
     if (active && part == 0) { binmed[b] = lo; binsum[b] = ssum; }
   }
   __syncthreads();
-  // ---- flush the LDS histogram ----
+  // ---- flush the LDS histogram (same [value][class] layout as the global one) ----
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
     const unsigned int c = s_hist[e];
-    if (c) atomicAdd(&res_hist[e], c);   // same [value][class] layout as the global histogram
-  }
-  for (int d = 32; d >= 1; d >>= 1) {
-    t_sum += __shfl_xor(t_sum, d); t_sqlo += __shfl_xor(t_sqlo, d); t_sqhi += __shfl_xor(t_sqhi, d);
-  }
-  if (lane_id() == 0 && (t_sum | t_sqlo | t_sqhi)) {
-    atomicAdd(&acc->sum, t_sum); atomicAdd(&acc->sq_lo, t_sqlo); atomicAdd(&acc->sq_hi, t_sqhi);
+    if (c) atomicAdd(&res_hist[e], c);
   }
 }
 
@@ -434,8 +670,14 @@ void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list,
   hipLaunchKernelGGL(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
                      count, cap);
 }
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, hipStream_t stream) {
-  hipLaunchKernelGGL(k_gc_hist, dim3(grid_for(n, kTileBases)), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, acc);
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, hipStream_t stream) {
+  const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
+  int64_t grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
+  if (packed && grid * kGcMaxTilesPerWg < ntiles) grid = (ntiles + kGcMaxTilesPerWg - 1) / kGcMaxTilesPerWg;
+  if (grid < 1) grid = 1;
+  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, acc);
+  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, acc);
+  if (n & 3) hipLaunchKernelGGL(k_gc_hist_tail, dim3(1), dim3(64), 0, stream, depth, gcbits, n, acc);
 }
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
@@ -444,8 +686,9 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux);
 }
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
-                          int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
-  hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, rdmean, out, hist, aux);
+                          int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
+  if (!adjust && (n & 3) == 0) return;
+  hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, rdmean, adjust, out, hist, aux);
 }
 
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
@@ -460,9 +703,17 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   const size_t tile_pad = ((size_t)TB * m + 3) & ~(size_t)3;
   const size_t lds = tile_pad * 4 + (size_t)vr * kResClasses * 4;
   const int64_t ntiles = (ncompact + (int64_t)TB * m - 1) / ((int64_t)TB * m);
-  int grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
-  hipLaunchKernelGGL(k_cap_compact_bin, dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg, ncompact, capval,
-                     m, TB, vr, rdc, binmed, binsum, res_hist, acc);
+  const int grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
+  const int quads = (int)(tile_pad / 4);
+  const int maxv = (quads + kThreads - 1) / kThreads;          // 16-byte loads per thread and tile
+  const int parts = kThreads / TB, ept = (m + parts - 1) / parts;   // values per thread in the median phase
+#define RSI_K4(MV, EP) hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg, \
+                                          ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc)
+  if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
+  else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)
+  else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile
+  else RSI_K4(13, 0);
+#undef RSI_K4
 }
 
 }  // namespace rsik

@@ -7,10 +7,12 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -49,6 +51,21 @@ struct DevBuf {   // grow-only device allocation
 
 struct KernelTime { const char* name; hipEvent_t a, b; };
 
+// One GPU, several workers.  The HBM-bound per-base phase of a chromosome takes the gate
+// exclusively, so that each streaming launch has the whole chip and memory system (and its
+// HIP-event time is a clean roofline sample); bin-level kernels of other chromosomes share it.
+// Waiting streamers hold back new sharers, so the streaming phases are never starved.
+struct GpuGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int sharers = 0, streamers_waiting = 0;
+  bool streaming = false;
+  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !streaming && streamers_waiting == 0; }); ++sharers; }
+  void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
+  void lock() { std::unique_lock<std::mutex> lk(m); ++streamers_waiting; cv.wait(lk, [&] { return !streaming && sharers == 0; }); --streamers_waiting; streaming = true; }
+  void unlock() { { std::lock_guard<std::mutex> lk(m); streaming = false; } cv.notify_all(); }
+};
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -80,8 +97,12 @@ struct rsi_ctx {
   int last_scan_med = 0;
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
-  // when the context belongs to a pool: one streaming (HBM-bound) phase at a time per GPU
-  std::mutex* hbm_token = nullptr;
+  // when the context belongs to a pool: arbitration of the GPU between workers
+  void* pinned = nullptr;     // hipHostMalloc staging for device -> host transfers
+  int32_t* mirror = nullptr;  // host mirror of the compacted depth (DepthPager), grow-only
+  size_t mirror_cap = 0;
+  GpuGate* gate = nullptr;
+  bool gate_shared = false;   // also hold bin-level kernels back while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=1)
 };
 
 namespace {
@@ -117,6 +138,7 @@ constexpr int kMaxRegions = 4096;
 constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr uint32_t kMaxRunEntries = 1u << 20;
 constexpr int kMaxL = 2048;
+constexpr size_t kPinnedBytes = 8u << 20;   // pinned staging buffer per context
 
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
@@ -133,6 +155,13 @@ struct Timer {   // optional HIP-event bracket around one launch
 bool int_quantiles(const std::vector<uint64_t>& h, uint64_t total, rsih::Quantiles& q) {
   return rsih::hist_quantiles_int(h.data(), h.size(), total, q);
 }
+
+struct GateShared {   // RAII: a bin-level GPU section of a pooled context (only when the pool isolates streaming)
+  GpuGate* g;
+  explicit GateShared(rsi_ctx* ctx) : g(ctx->gate_shared ? ctx->gate : nullptr) { if (g) g->lock_shared(); }
+  void release() { if (g) { g->unlock_shared(); g = nullptr; } }
+  ~GateShared() { release(); }
+};
 
 struct Phase {   // wall-clock bracket of one pipeline phase (host view)
   rsi_ctx* ctx; const char* name; double t0; bool open = true;
@@ -302,6 +331,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int rc, cal_max;
   {
     Phase ph(ctx, "scan.quantiles");
+    GateShared gs(ctx);
     if (!use_med) {
       if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
     } else {
@@ -335,7 +365,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int32_t* d_st1 = ctx->status1.as<int32_t>();
   int32_t* d_st1f = ctx->status1f.as<int32_t>();
   int32_t* d_st2 = ctx->status2.as<int32_t>();
-  { Phase ph(ctx, "scan.pass"); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
@@ -361,6 +391,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       for (int l = nl - 1; l >= 0; --l) if (lsum[l] > m0 + dev) { leveladd = l + lo; break; }
       if (!(leveldel > 0 || leveladd < 0 || leveldel > leveladd)) {
         std::vector<Region> runs;
+        GateShared gs(ctx);
         if ((rc = marked_runs_device(ctx, d_st1, nb, runs)) != RSI_OK) return rc;
         if (!runs.empty()) {
           int32_t *d_rs, *d_re;
@@ -374,6 +405,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   ph_filter.stop();
   // ---- second-pass parameters on the unmarked bins (rsi.cpp:1307-1319 / 1457-1469) ----
   Phase ph_q2(ctx, "scan.quantiles");
+  GateShared gs_q2(ctx);
   double tmed2;
   uint64_t k = 0;
   if ((rc = grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k)) != RSI_OK) return rc;
@@ -386,8 +418,10 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
   ph_q2.stop();
-  { Phase ph(ctx, "scan.pass"); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
+  gs_q2.release();
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
   Phase ph_seg(ctx, "scan.segments");
+  GateShared gs_seg(ctx);
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
   out.status2.resize((size_t)nb);
@@ -466,13 +500,16 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->ktimes.clear();
   ctx->event_next = 0;
   ctx->phases.clear();
-  // The per-base kernels are HBM-bound: workers of a pool take turns through this phase so that
-  // each launch has the memory system to itself, while bin-level kernels, copies and host stages of
-  // other chromosomes overlap freely.
-  std::unique_lock<std::mutex> hbm_turn;
-  if (ctx->hbm_token) {
+  // The per-base kernels are HBM-bound: workers of a pool take turns through this phase (GpuGate).
+  struct StreamTurn {
+    GpuGate* g = nullptr;
+    ~StreamTurn() { if (g) g->unlock(); }
+    void release() { if (g) { g->unlock(); g = nullptr; } }
+  } hbm_turn;
+  if (ctx->gate) {
     Phase ph_wait(ctx, "wait.hbm_turn");
-    hbm_turn = std::unique_lock<std::mutex>(*ctx->hbm_token);
+    ctx->gate->lock();
+    hbm_turn.g = ctx->gate;
   }
   Phase ph_a1(ctx, "a1.classify+nruns");
   ctx->n = n; ctx->ncompact = 0; ctx->nb = 0; ctx->have_gc = ctx->have_nb = ctx->have_med = false;
@@ -483,20 +520,26 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   hipStream_t st = ctx->stream;
   const int64_t nwords = n / 64 + 1;
 
+  Phase ph_a1a(ctx, "a1a.ensure");
   HIPCHK(ctx->small.ensure(kSmallBytes));
   HIPCHK(ctx->gcbits.ensure((size_t)nwords * 8));
   HIPCHK(ctx->nbits.ensure((size_t)nwords * 8));
   HIPCHK(ctx->ntrans.ensure((size_t)kMaxTransitions * 8));
   HIPCHK(ctx->hist_val.ensure((size_t)kHistValues * 4));
   uint8_t* small = ctx->small.as<uint8_t>();
+  ph_a1a.stop();
+  Phase ph_a1b(ctx, "a1b.memset+launch");
   HIPCHK(hipMemsetAsync(small, 0, kOffTable, st));
 
   // ---- A1: GC mask, N runs (K1, K1b) ----
   uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
   { Timer t(ctx, "fasta_classify"); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
   { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, st); }
+  ph_a1b.stop();
+  Phase ph_a1c(ctx, "a1c.fetch");
   std::vector<Region> nruns;
   int rc = fetch_pairs(ctx, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, nruns, true);
+  ph_a1c.stop();
   if (rc != RSI_OK) return rc;
   std::vector<Region> noncode;   // get_noseq_regions, loaddata.cpp:243-273: pad, clamp, re-merge
   {
@@ -521,11 +564,17 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
   if (P.gcadjust) {
     GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
-    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, st); }
+    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, st); }
     GcAccum acc;
     HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (acc.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
+    if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
+      HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
+      { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, st); }
+      HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    if (acc.negatives & 1u) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112
     if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
     double table[kGcLevels];
@@ -538,13 +587,14 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     HIPCHK(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, st));
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
-    { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+    { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     HIPCHK(hipStreamSynchronize(st));   // table[] leaves scope
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   } else if (want_cap) {
     Timer t(ctx, "value_hist");
     launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
+    launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
   }
 
   ph_gc.stop();
@@ -606,20 +656,21 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   rsih::Quantiles qall;
   if (!int_quantiles(hall, (uint64_t)ncompact, qall)) return fail(ctx, RSI_ERR_INTERNAL, "empty depth histogram");
   const double RDmedian = qall.med;
-  {
-    const double s1 = (double)bacc.sum;
-    const unsigned __int128 sq = ((unsigned __int128)bacc.sq_hi << 32) + bacc.sq_lo;
-    const double s2 = (double)sq;
-    const double mean = s1 / double((int)ncompact);
-    S.RDsd = sqrt(s2 / double((int)ncompact) - mean * mean);
+  {   // variance(RD,...,-1), wufunctions.cpp:766-809: exact integer sums, one rounding each
+    unsigned __int128 s1 = 0, s2 = 0;
+    for (size_t v = 0; v < res_vals; ++v) { s1 += (unsigned __int128)v * hall[v]; s2 += (unsigned __int128)v * v * hall[v]; }
+    const double d1 = (double)s1, d2 = (double)s2;
+    const double mean = d1 / double((int)ncompact);
+    S.RDsd = sqrt(d2 / double((int)ncompact) - mean * mean);
   }
   S.RDmedian = RDmedian;
   ph_bins.stop();
-  if (hbm_turn.owns_lock()) hbm_turn.unlock();
+  hbm_turn.release();
 
   std::vector<Candidate> blocks, raw, kept, segs_all;
   if (!(RDmedian < 5)) {   // rsi.cpp:1809-1812
     Phase ph_nb(ctx, "a9-10.mad+nb");
+    GateShared gs_nb(ctx);
     // ---- A9: MAD of the 31 interleaved subsamples from their value histograms (rsi.cpp:1127-1143) ----
     double mads[31];
     const uint64_t sublen = (uint64_t)(ncompact / 31);
@@ -676,6 +727,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     ctx->have_nb = true;
 
     ph_nb.stop();
+    gs_nb.release();
     rsih::CallerInput in;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     std::vector<int> medint((size_t)nb);
@@ -713,7 +765,14 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       if ((rc = do_scan(false, more)) != RSI_OK) return rc;
       tested.insert(tested.end(), more.begin(), more.end());
     }
-    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st);
+    if (!ctx->pinned) { if (hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) ctx->pinned = nullptr; }
+    if (ctx->mirror_cap < (size_t)ncompact) {   // grow-only host mirror, pages are touched only where candidates are
+      free(ctx->mirror);
+      ctx->mirror_cap = (size_t)ncompact + (size_t)ncompact / 8 + 1024;
+      ctx->mirror = static_cast<int32_t*>(malloc(ctx->mirror_cap * sizeof(int32_t)));
+      if (!ctx->mirror) { ctx->mirror_cap = 0; return fail(ctx, RSI_ERR_INTERNAL, "out of host memory for the depth mirror"); }
+    }
+    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, ctx->pinned, ctx->pinned ? kPinnedBytes : 0);
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
   }
   const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
@@ -765,6 +824,8 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  free(ctx->mirror);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -887,7 +948,7 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
 struct rsi_pool {
   int device = 0;
   std::vector<rsi_ctx*> workers;
-  std::mutex hbm_token;
+  GpuGate gate;
   std::string err;
 };
 
@@ -905,7 +966,9 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
       delete pool;
       return nullptr;
     }
-    c->hbm_token = &pool->hbm_token;
+    c->gate = &pool->gate;
+    const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
+    c->gate_shared = iso && iso[0] == '1';
     pool->workers.push_back(c);
   }
   if (status) *status = RSI_OK;

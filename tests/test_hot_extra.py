@@ -112,6 +112,24 @@ def test_error_behaviour(hot, hotlib):
         hot.run(api.make_params(), depth[:-1], fasta)
 
 
+def test_huge_depth_values_take_the_wide_gc_path(hot, hotlib, oracle_cls):
+    """Depths of 2^21 and more invalidate the packed GC accumulators: the pipeline re-runs the wide
+    form and must still match the oracle (the cap removes the outliers afterwards)."""
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=400_003, seed=0xB16, model=0, n_events=4, gaps=1, max_len=15000, end_n=4000, gap_len=6000))
+    depth = depth.copy()
+    depth[[50_001, 123_457, 300_000, 399_990, 400_001]] = [3_000_000, 2_500_000, 70_000, 1 << 22, 99_999]
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert res.stats["gc_rdmean"] == O.f64("chrom")[3]
+    assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
+
+
 def test_properties_at_60mb(hot, hotlib):
     """BASELINE.json configs[1] size: checks that do not need the (slow) CPU path."""
     import torch
