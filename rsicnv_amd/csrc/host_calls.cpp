@@ -7,9 +7,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include "hostmath.h"
 
 namespace rsih {
+
+static inline double tick_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ------------------------------------------------------------------------------------------
 namespace {
@@ -61,11 +64,20 @@ double normal_cdf(double x) {
 }
 
 // ------------------------------------------------------------------------------------------
-DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging, size_t staging_bytes)
+DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging, size_t staging_bytes,
+                       hipEvent_t sync_event)
     : d_(d_ptr), n_(n), stream_(stream), mirror_(mirror), have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 0),
-      staging_(static_cast<int32_t*>(staging)), staging_elems_((int64_t)(staging_bytes / sizeof(int32_t))) {}
+      staging_(static_cast<int32_t*>(staging)), staging_elems_((int64_t)(staging_bytes / sizeof(int32_t))), sync_ev_(sync_event) {}
+
+void DepthPager::wait() {
+  if (!sync_ev_) { (void)hipStreamSynchronize(stream_); return; }
+  (void)hipEventRecord(sync_ev_, stream_);
+  for (int spin = 0; spin < 200; ++spin) if (hipEventQuery(sync_ev_) != hipErrorNotReady) return;
+  (void)hipEventSynchronize(sync_ev_);
+}
 
 void DepthPager::fetch(int64_t p0, int64_t p1) {
+  const double t0 = tick_ms();
   const int64_t lo = p0 << kBits;
   int64_t hi = ((p1 + 1) << kBits);
   if (hi > n_) hi = n_;
@@ -74,16 +86,17 @@ void DepthPager::fetch(int64_t p0, int64_t p1) {
       for (int64_t a = lo; a < hi; a += staging_elems_) {
         const int64_t k = std::min(staging_elems_, hi - a);
         (void)hipMemcpyAsync(staging_, d_ + a, (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
-        (void)hipStreamSynchronize(stream_);
+        wait();
         memcpy(mirror_ + a, staging_, (size_t)k * sizeof(int32_t));
       }
     } else {
       (void)hipMemcpyAsync(mirror_ + lo, d_ + lo, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
-      (void)hipStreamSynchronize(stream_);
+      wait();
     }
     fetched_ += (hi - lo) * (int64_t)sizeof(int32_t);
   }
   for (int64_t p = p0; p <= p1; ++p) have_[(size_t)p] = 1;
+  fetch_ms_ += tick_ms() - t0;
 }
 
 void DepthPager::prefetch(int64_t lo, int64_t hi) {
@@ -107,30 +120,46 @@ struct VecView {   // bin-space arrays
   int64_t size() const { return (int64_t)v->size(); }
   int operator[](int64_t i) const { return (*v)[(size_t)i]; }
   void prefetch(int64_t, int64_t) const {}
+  const int* raw() const { return v->data(); }   // whole array
 };
 struct PagedView {
   DepthPager* p;
   int64_t size() const { return p->size(); }
   int operator[](int64_t i) const { return (*p)[i]; }
   void prefetch(int64_t lo, int64_t hi) const { p->prefetch(lo, hi); }
+  const int* raw() const { return p->raw(); }    // valid only inside ranges that were prefetched
 };
 
 // ---- isitcnv (rsi.cpp:101-172): statistics of the candidate against its neighbourhood ----
 void judge(const CallerInput& in, const std::vector<int>& ref, const std::vector<int>& body, Candidate& c) {
+  const double t0 = tick_ms();
   const int width = (int)body.size();
   const int nwin = (int)ref.size() - width;
   std::vector<float> winmean(nwin > 0 ? (size_t)nwin : 0);
+  // running mean of width `width` (rsi.cpp:113-124); its minimum, maximum, mean and second moment are
+  // accumulated in the same index order as the reference's separate passes would
   double acc = 0;
   for (int i = 0; i < width; ++i) acc += ref[i];
-  if (nwin > 0) winmean[0] = (float)(acc / double(width));
-  for (int i = 1; i < nwin; ++i) {
-    acc = acc - ref[i - 1] + ref[i - 1 + width];
-    winmean[i] = (float)(acc / double(width));
+  float flo = 0, fhi = 0;
+  double msum = 0, s1 = 0, s2 = 0;
+  for (int i = 0; i < nwin; ++i) {
+    if (i > 0) acc = acc - ref[i - 1] + ref[i - 1 + width];
+    const float w = (float)(acc / double(width));
+    winmean[i] = w;
+    if (i == 0) { flo = fhi = w; }
+    flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi;
+    msum += w;                                   // partition_stat_tp's mean (wufunctions.cpp:372-378)
+    s1 += (double)w; s2 += (double)w * (double)w;   // variancetp (wufunctions.cpp:790-796)
   }
-  const Quantiles qr = grid_quantiles(winmean.data(), winmean.size());
-  double spread = sqrt(variance_pop(winmean.data(), winmean.size()));
+  const double t1 = tick_ms();
+  const Quantiles qr = grid_quantiles_f32_known(winmean.data(), winmean.size(), flo, fhi, msum);
+  const double t2 = tick_ms();
+  const double mu = s1 / double(nwin);
+  double spread = sqrt(s2 / double(nwin) - mu * mu);
   if (spread < 1E-3) spread = qr.med / 40.0 + 1E-3;
+  const double t3 = tick_ms();
   const Quantiles qc = grid_quantiles(body.data(), body.size());
+  if (in.prof) { in.prof->winmean += t1 - t0; in.prof->quantiles += (t2 - t1) + (tick_ms() - t3); in.prof->variance += t3 - t2; in.prof->tests++; }
   c.length = c.end - c.start + 1;
   c.cnvmed = qc.med;
   c.cnvsd = sqrt(variance_pop(body.data(), body.size()));
@@ -170,6 +199,7 @@ void test_candidate(const CallerInput& in, const View& A, std::vector<Candidate>
   int d = body_len;
   if (N == span_all) { if (d < P.m * P.minmlen) d = (int)(P.m * P.minmlen); }
   if (N < span_all / 2) { if (d < P.minmlen) d = (int)P.minmlen + 1; }
+  const double tg0 = tick_ms();
   const int capacity = (int)(P.chklen * d * 2);
   std::vector<int> ref((size_t)capacity, 0);
   const double too_high = in.RDmedian * 3.0, too_low = in.RDmedian * 0.15;
@@ -238,6 +268,7 @@ void test_candidate(const CallerInput& in, const View& A, std::vector<Candidate>
     for (int i = 0; i < nbody; ++i) thin[i] = body[(size_t)(int)(double(i) / double(nbody) * double(body.size()))];
     body.swap(thin);
   }
+  if (in.prof) in.prof->gather += tick_ms() - tg0;
   judge(in, ref, body, list[ci]);
 }
 
@@ -292,6 +323,10 @@ void order_by_start(std::vector<Candidate>& L) {
 }
 
 // ---- optimize_with_derivative (rsi.cpp:889-944) ----
+// The reference builds the whole vector dd[i] = (sum of the len values left of from+i) - (sum of
+// the len values from from+i on) and then looks for its first maximum / minimum (DEL) or minimum /
+// maximum (DUP) over the first and the last 2*reach entries.  The sums are integers below 2^53, so
+// they are tracked exactly in int64 and both searches run in the same sweep without storing dd.
 template <class View>
 void sharpen_edges(const View& A, Candidate& c) {
   const int len = c.end - c.start + 1;
@@ -300,29 +335,28 @@ void sharpen_edges(const View& A, Candidate& c) {
   if (from < 2 * len) return;
   if (to > A.size() - 2 * len) return;
   A.prefetch((int64_t)from - len - 1, (int64_t)to + len + 1);
-  std::vector<double> step;
-  step.reserve((size_t)(to - from));
-  double diff = 0.0;
-  for (int k = from - len; k < from; ++k) diff += A[k];
-  for (int k = from; k < from + len; ++k) diff -= A[k];
-  step.push_back(diff);
-  for (int i = from + 1; i < to; ++i) {
-    diff = diff - A[i - 1 - len] + A[i - 1] + A[i - 1] - A[i - 1 + len];
-    step.push_back(diff);
+  const int* p = A.raw();
+  int64_t diff = 0;
+  for (int k = from - len; k < from; ++k) diff += p[k];
+  for (int k = from; k < from + len; ++k) diff -= p[k];
+  const int nstep = to - from;                 // dd.size()
+  const int tail0 = nstep - 2 * reach;         // first index of the second search
+  const bool del = c.type == kDel, dup = c.type == kDup;
+  int best_lo = -1, best_hi = -1;
+  int64_t ext_lo = 0, ext_hi = 0;
+  for (int i = 0; i < nstep; ++i) {
+    if (i > 0) { const int q = from + i; diff = diff - p[q - 1 - len] + 2 * (int64_t)p[q - 1] - p[q - 1 + len]; }
+    if (i < 2 * reach) {
+      if (del && diff > ext_lo) { ext_lo = diff; best_lo = i; }
+      if (dup && diff < ext_lo) { ext_lo = diff; best_lo = i; }
+    }
+    if (i >= tail0) {
+      if (del && diff < ext_hi) { ext_hi = diff; best_hi = i; }
+      if (dup && diff > ext_hi) { ext_hi = diff; best_hi = i; }
+    }
   }
-  const int nstep = (int)step.size();
-  int best = -1; double ext = 0;
-  for (int i = 0; i < 2 * reach; ++i) {
-    if (c.type == kDel && step[i] > ext) { ext = step[i]; best = i; }
-    if (c.type == kDup && step[i] < ext) { ext = step[i]; best = i; }
-  }
-  if (best > 0) c.start = from + best;
-  best = -1; ext = 0;
-  for (int i = nstep - 2 * reach; i < nstep; ++i) {
-    if (c.type == kDel && step[i] < ext) { ext = step[i]; best = i; }
-    if (c.type == kDup && step[i] > ext) { ext = step[i]; best = i; }
-  }
-  if (best > 0) c.end = to - nstep + best;
+  if (best_lo > 0) c.start = from + best_lo;
+  if (best_hi > 0) c.end = to - nstep + best_hi;
 }
 
 template <class View>
@@ -450,9 +484,12 @@ void call_from_segments(const CallerInput& in, std::vector<Candidate> segs, Dept
     c.length = c.end - c.start + 1;
     L.push_back(c);
   }
+  const double ts0 = tick_ms();
   for (int pass = 0; pass < 2; ++pass) for (Candidate& c : L) sharpen_edges(bases, c);
   order_by_start(L);
+  const double ts1 = tick_ms();
   merge_neighbours(in, bases, L);
+  if (in.prof) { in.prof->sharpen += ts1 - ts0; in.prof->merge += tick_ms() - ts1; }
   order_by_start(L);
   raw.clear();
   for (int i = 0; i < (int)L.size(); ++i) {

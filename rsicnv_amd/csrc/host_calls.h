@@ -28,7 +28,7 @@ class DepthPager {
   // mirror: host buffer of at least n elements owned by the caller (reused across chromosomes, so
   // no address space is mapped and unmapped per call); staging: optional pinned buffer for the DMA.
   DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging = nullptr,
-             size_t staging_bytes = 0);
+             size_t staging_bytes = 0, hipEvent_t sync_event = nullptr);
   DepthPager(const DepthPager&) = delete;
   DepthPager& operator=(const DepthPager&) = delete;
   int64_t size() const { return n_; }
@@ -37,7 +37,9 @@ class DepthPager {
     return mirror_[i];
   }
   void prefetch(int64_t lo, int64_t hi);   // [lo, hi] clipped to the array, one copy per missing stretch
+  const int32_t* raw() const { return mirror_; }   // valid only inside prefetched ranges
   int64_t bytes_fetched() const { return fetched_; }
+  double fetch_ms() const { return fetch_ms_; }
  private:
   static constexpr int kBits = 14;
   void fetch(int64_t p0, int64_t p1);
@@ -48,11 +50,18 @@ class DepthPager {
   std::vector<unsigned char> have_;
   int32_t* staging_ = nullptr;         // pinned, owned by the context
   int64_t staging_elems_ = 0;
+  hipEvent_t sync_ev_ = nullptr;       // blocking-sync event for the waits (no busy spinning), optional
+  void wait();
   int64_t fetched_ = 0;
+  double fetch_ms_ = 0;
 };
+
+// wall-clock split of the candidate stages (ms), filled when CallerInput::prof is set
+struct CallProfile { double fetch = 0, gather = 0, winmean = 0, quantiles = 0, variance = 0, sharpen = 0, merge = 0; int tests = 0; };
 
 struct CallerInput {
   rsi_params P;
+  CallProfile* prof = nullptr;
   double RDmedian, RDsd;
   int64_t ncompact;                 // rsi::end with rsi::start = 1
   const std::vector<Region>* noncode;

@@ -76,16 +76,13 @@ inline Quantiles grid_quantiles<int>(const int* x, size_t n) {
   }
   return q;
 }
-// float: the mean is accumulated in index order as the reference does (double += float).
-template <>
-inline Quantiles grid_quantiles<float>(const float* x, size_t n) {
+// float, with minimum / maximum / running sum already known (accumulated in index order by the
+// caller, double += float as the reference does).
+inline Quantiles grid_quantiles_f32_known(const float* x, size_t n, float flo, float fhi, double sum) {
   const double dy = 0.01;
-  float flo = x[0], fhi = x[0];
-  double acc = 0;
-  for (size_t i = 0; i < n; ++i) { acc += x[i]; flo = x[i] < flo ? x[i] : flo; fhi = x[i] > fhi ? x[i] : fhi; }
   const double lo = flo, hi = fhi;
-  Quantiles q{lo, acc / (double)n, hi};
-  if ((hi - lo) < dy) return q;
+  Quantiles q{lo, sum / (double)n, hi};
+  if (n == 0 || (hi - lo) < dy) return q;
   const size_t buckets = (size_t)((hi - lo) / dy + 2);
   std::vector<uint32_t> cnt(buckets + 1, 0), idx(n);
   bucket_indices_f32(x, n, lo, dy, idx.data());
@@ -100,6 +97,13 @@ inline Quantiles grid_quantiles<float>(const float* x, size_t n) {
     seen = upto;
   }
   return q;
+}
+template <>
+inline Quantiles grid_quantiles<float>(const float* x, size_t n) {
+  float flo = x[0], fhi = x[0];
+  double acc = 0;
+  for (size_t i = 0; i < n; ++i) { acc += x[i]; flo = x[i] < flo ? x[i] : flo; fhi = x[i] > fhi ? x[i] : fhi; }
+  return grid_quantiles_f32_known(x, n, flo, fhi, acc);
 }
 
 // The same walk over an integer histogram built on the device: hist[v] = multiplicity of value v,

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// K7  RSI scan.  One workgroup per tile of kScanTile bins.  The tile plus a halo of Lmax/2+1 bins
+// K7  RSI scan.  One workgroup per tile of kScanTile bins (one per thread).  The tile plus a halo of Lmax/2+1 bins
 // each side is staged in LDS: an exact double prefix of the transformed values (so the window sum
 // for any (bin, L) is one subtraction), the values and bin medians themselves for the trim walks,
 // and two integer prefixes that turn the exact window-median test into a count difference.  The
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
 // sum <= thr_del[L] / sum >= thr_dup[L]).  Every lane owns a bin and walks L = 1..Lmax; a hit marks
 // its trimmed interval with atomicMin(L) in LDS ("smallest L wins", App. A Q14) and the tile's
 // marks are merged into HBM at the end.  Nothing in the hit path leaves LDS.
-constexpr int kScanTile = 1024;
+constexpr int kScanTile = 256;    // one bin per lane: the tile's critical path is one lane's walk over L
 constexpr uint32_t kUnmarked = 0xffffffffu;
 
 struct ScanLds {
@@ -198,12 +198,15 @@ __device__ inline uint32_t lane_hit(const ScanLds& S, int w0, int L, bool is_del
     if ((i1 >= vhi && at_end) || (i2 < vlo && at_start)) atomicAdd(&counters[0], 1u);
     i1 = 1; i2 = 0;
   }
-  for (int j = w0; j < w0 + L; ++j) {
+  // mark the trimmed interval; the window's largest mark is only worth knowing when the interval
+  // covers the whole window (otherwise the untouched rest keeps the lane from skipping anyway)
+  const bool full = i1 == w0 && i2 == w0 + L - 1;
+  for (int j = i1; j <= i2; ++j) {
     uint32_t v = F[j];
-    if (j >= i1 && j <= i2 && v > (uint32_t)L) { atomicMin(&F[j], (uint32_t)L); v = (uint32_t)L; }
+    if (v > (uint32_t)L) { atomicMin(&F[j], (uint32_t)L); v = (uint32_t)L; }
     wmax = v > wmax ? v : wmax;
   }
-  return wmax;
+  return full ? wmax : kUnmarked;
 }
 
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,

@@ -82,6 +82,7 @@ struct rsi_result {
 struct rsi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
   std::string err;
   bool timing = false;
   std::vector<KernelTime> ktimes;
@@ -116,6 +117,21 @@ namespace {
       return RSI_ERR_HIP;                                                                     \
     }                                                                                         \
   } while (0)
+
+// Wait for the context's stream without burning a core: poll briefly (most waits are a few
+// microseconds), then sleep on a blocking-sync event.  With one busy-spinning thread per worker a
+// 16-CPU quota is exhausted by the waits alone and the whole process gets throttled.
+hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
+  hipError_t e = hipEventRecord(ev, stream);
+  if (e != hipSuccess) return e;
+  for (int spin = 0; spin < 200; ++spin) {
+    e = hipEventQuery(ev);
+    if (e == hipSuccess) return hipSuccess;
+    if (e != hipErrorNotReady) return e;
+  }
+  return hipEventSynchronize(ev);
+}
+#define CTX_SYNC() stream_wait(ctx->stream, ctx->sync_ev)
 
 int fail(rsi_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -193,7 +209,7 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   { Timer t(ctx, "minmax_f32"); launch_minmax_f32(d_x, d_mask, nb, use_abs, center, reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->stream); }
   MinMaxF mm;
   HIPCHK(hipMemcpyAsync(&mm, small + kOffMinMax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   if (mm.min_bits == 0xffffffffu) { *count = 0; *med = 0; return RSI_OK; }
   if (mm.nonfinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
   auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
@@ -207,7 +223,7 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   { Timer t(ctx, "hist_f32"); launch_hist_f32(d_x, d_mask, nb, use_abs, center, ymin, ctx->hist_f.as<uint32_t>(), (uint32_t)np, ctx->stream); }
   std::vector<uint32_t> h(np);
   HIPCHK(hipMemcpyAsync(h.data(), ctx->hist_f.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   uint64_t total = 0;
   for (uint32_t c : h) total += c;
   *count = total;
@@ -233,13 +249,13 @@ int fetch_pairs(rsi_ctx* ctx, const uint64_t* d_list, const uint32_t* d_count, u
                 bool end_exclusive) {
   uint32_t cnt = 0;
   HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   out.clear();
   if (cnt == 0) return RSI_OK;
   if (cnt > cap) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
   std::vector<uint64_t> raw(cnt);
   HIPCHK(hipMemcpyAsync(raw.data(), d_list, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   std::vector<int64_t> s, e;
   for (uint64_t v : raw) ((v & 1) ? e : s).push_back((int64_t)(v >> 1));
   if (s.size() != e.size()) return fail(ctx, RSI_ERR_INTERNAL, "unbalanced run boundaries");
@@ -267,7 +283,7 @@ int upload_runs(rsi_ctx* ctx, const std::vector<Region>& runs, int32_t** d_start
   std::vector<int32_t> se(2 * k);
   for (size_t i = 0; i < k; ++i) { se[i] = runs[i].start; se[k + i] = runs[i].end; }
   HIPCHK(hipMemcpyAsync(ctx->run_se.p, se.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));   // se goes out of scope
+  HIPCHK(CTX_SYNC());   // se goes out of scope
   *d_start = ctx->run_se.as<int32_t>();
   *d_end = ctx->run_se.as<int32_t>() + k;
   return RSI_OK;
@@ -307,14 +323,14 @@ int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t n
   HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
   { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_del.as<uint32_t>(), nullptr, 0, nb, Lmax, d_lh, ctx->stream); }
   HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   stop_level(ldel);
   HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
   { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_dup.as<uint32_t>(), ctx->first_del.as<uint32_t>(), ldel, nb, Lmax, d_lh, ctx->stream); }
   HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
   uint32_t cnts[2];
   HIPCHK(hipMemcpyAsync(cnts, d_counters, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   stop_level(ldup);
   *escapes += cnts[0];
   *inexact = cnts[1];
@@ -375,7 +391,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(hipMemcpyAsync(hT.data(), d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(hst.data(), d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   {
     int lo = hst[0], hi = hst[0];
     for (int64_t i = 0; i < nb; ++i) { lo = std::min(lo, hst[i]); hi = std::max(hi, hst[i]); }
@@ -457,7 +473,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
   std::vector<BestSeg> best(items.size());
   HIPCHK(hipMemcpyAsync(best.data(), ctx->best.p, items.size() * sizeof(BestSeg), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   std::vector<BestSeg> per_run(runs.size(), BestSeg{-1.0, 0, 0});
   for (size_t i = 0; i < items.size(); ++i) {   // items of a run are in increasing L: strict > keeps the earliest
     BestSeg& b = per_run[(size_t)items[i].run];
@@ -567,12 +583,12 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, st); }
     GcAccum acc;
     HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(CTX_SYNC());
     if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
       HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
       { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, st); }
       HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(CTX_SYNC());
     }
     if (acc.negatives & 1u) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112
@@ -588,7 +604,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
-    HIPCHK(hipStreamSynchronize(st));   // table[] leaves scope
+    HIPCHK(CTX_SYNC());   // table[] leaves scope
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   } else if (want_cap) {
@@ -606,7 +622,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     ValueHistAux aux;
     HIPCHK(hipMemcpyAsync(h32.data(), ctx->hist_val.p, (size_t)kHistValues * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&aux, d_aux, sizeof(aux), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(CTX_SYNC());
     if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     std::vector<uint64_t> h(h32.begin(), h32.end());
     uint64_t inrange = 0;
@@ -648,7 +664,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   std::vector<uint32_t> hres(res_vals * kResClasses);
   HIPCHK(hipMemcpyAsync(&bacc, d_bacc, sizeof(bacc), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(hres.data(), ctx->hist_res.p, hres.size() * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));   // also covers cbreak/cum going out of use
+  HIPCHK(CTX_SYNC());   // also covers cbreak/cum going out of use
   if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");
   // chromosome median / SD (rsi.cpp:2202-2203)
   std::vector<uint64_t> hall(res_vals, 0);
@@ -707,7 +723,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     { Timer t(ctx, "nb_raw"); launch_nb_raw(ctx->binsum.as<int64_t>(), nb, P.m, ncompact, r, ctx->tnb.as<float>(), d_rawmin, st); }
     uint32_t minkey;
     HIPCHK(hipMemcpyAsync(&minkey, d_rawmin, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(CTX_SYNC());
     float tminf;
     { uint32_t b = (minkey & 0x80000000u) ? (minkey & 0x7fffffffu) : ~minkey; memcpy(&tminf, &b, 4); }
     const double tmin = tminf;
@@ -732,7 +748,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     std::vector<int> medint((size_t)nb);
     HIPCHK(hipMemcpyAsync(medint.data(), ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(CTX_SYNC());
     in.binmedint = &medint;
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
@@ -772,15 +788,25 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       ctx->mirror = static_cast<int32_t*>(malloc(ctx->mirror_cap * sizeof(int32_t)));
       if (!ctx->mirror) { ctx->mirror_cap = 0; return fail(ctx, RSI_ERR_INTERNAL, "out of host memory for the depth mirror"); }
     }
-    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, ctx->pinned, ctx->pinned ? kPinnedBytes : 0);
+    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, ctx->pinned, ctx->pinned ? kPinnedBytes : 0, ctx->sync_ev);
+    rsih::CallProfile prof;
+    in.prof = &prof;
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
+    ctx->phases.push_back({"calls.fetch", pager.fetch_ms()});
+    ctx->phases.push_back({"calls.gather(incl fetch)", prof.gather});
+    ctx->phases.push_back({"calls.winmean", prof.winmean});
+    ctx->phases.push_back({"calls.quantiles", prof.quantiles});
+    ctx->phases.push_back({"calls.variance", prof.variance});
+    ctx->phases.push_back({"calls.sharpen", prof.sharpen});
+    ctx->phases.push_back({"calls.merge(incl tests)", prof.merge});
+    ctx->phases.push_back({"calls.ntests", (double)prof.tests});
   }
   const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
   for (int w = 0; w < 4; ++w) {
     res->lists[w].resize(lists[w]->size());
     for (size_t i = 0; i < lists[w]->size(); ++i) to_call((*lists[w])[i], &res->lists[w][i]);
   }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(CTX_SYNC());
   S.t_device_ms = now_ms() - t_begin;
   if (ctx->timing) {
     double tot = 0;
@@ -810,7 +836,8 @@ rsi_ctx* rsi_hot_create(int device, int* status) {
   }
   rsi_ctx* ctx = new rsi_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
     set_global_error("hipSetDevice / hipStreamCreate failed");
     if (status) *status = RSI_ERR_HIP;
     delete ctx;
@@ -826,6 +853,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   free(ctx->mirror);
+  if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -851,7 +879,7 @@ int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const u
   HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
   HIPCHK(hipMemcpyAsync(ctx->in_depth.p, depth, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(CTX_SYNC());
   return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
 }
 
@@ -882,7 +910,7 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   if (out) {
     const int64_t k = std::min(cnt, cap);
     HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(CTX_SYNC());
   }
   return cnt;
 }
@@ -896,7 +924,7 @@ int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t ca
   if (out) {
     const int64_t k = std::min(cnt, cap);
     HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(CTX_SYNC());
   }
   return cnt;
 }
@@ -907,7 +935,7 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
   if (out) {
     const int64_t k = std::min(ctx->nb, cap);
     HIPCHK(hipMemcpyAsync(out, ctx->binsum.p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(CTX_SYNC());
   }
   return ctx->nb;
 }
