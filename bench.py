@@ -33,6 +33,20 @@ ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1
                        "value_hist": 4.0}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 MAX_CALLS = 256         # per-chromosome slots in the gathered result block
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py --json
+
+
+def pmc_traffic_per_base(kernel):
+    """HBM bytes per base of a streaming kernel from the committed rocprofv3 PMC passes (FETCH_SIZE
+    and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md section
+    HBM prescribes for wide coalesced reads on gfx950).  None when no measurement is committed."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / d["bases_per_launch"]
+    except Exception:
+        return None
 
 
 def log(*a):
@@ -48,7 +62,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink chromosome lengths (debug only; invalidates the metric)")
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=8, help="host threads / HIP streams per GPU (chromosomes in flight)")
+    ap.add_argument("--workers", type=int, default=12, help="host threads / HIP streams per GPU (chromosomes in flight)")
     args = ap.parse_args()
 
     import numpy as np
@@ -143,8 +157,10 @@ def main():
         ms, cnt, bases = per_kernel[dom]
         byts = ALGO_BYTES_PER_BASE[dom] * bases
         achieved = byts / (ms * 1e-3) / 1e9
+        tpb = pmc_traffic_per_base(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None if tpb is None else round(tpb * bases / cnt),
                     "avg_launch_ms": round(ms / cnt, 4), "launches": int(cnt),
                     "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[dom],
                     "algorithmic_bytes_per_launch": round(byts / cnt)}

@@ -31,15 +31,19 @@ struct GcAccum {
 };
 // packed = 1: one LDS atomic per base (count and sum in one 64-bit word), valid for depths < 2^21;
 // when the result carries flag bit 1 the caller zeroes acc and launches again with packed = 0.
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, hipStream_t stream);
+// slabs: scratch of gc_hist_slab_bytes(n) bytes (per-workgroup partial results, folded by a second tiny kernel).
+size_t gc_hist_slab_bytes(int64_t n);
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, void* slabs,
+                    hipStream_t stream);
 
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
 // adjust=0 copies depth through unchanged (the -NOGC path only needs the histogram).
 // hist[kHistValues] counts output values < kHistValues; *big counts the rest, *vmax their maximum.
 struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int negatives; };
+size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
-                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
+                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream);
 // Must follow launch_gc_rescale: tail quirks of the 20-slice write-back fixed
 // in out[] and hist[], plus the last n % 4 bases, which the streaming kernel leaves out.
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
@@ -57,9 +61,11 @@ struct BinAccum {
 // index cbreak[k] (cum[nreg] = total).  res_hist: [kHistValues][kResClasses] counts of value by
 // class (compacted index mod 31, or 31 for the tail beyond 31*floor(n'/31)); the chromosome's sum,
 // sum of squares and median all derive from it.
+// slabs: scratch of cap_compact_slab_bytes(...) bytes for the per-workgroup histograms.
+size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact);
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
-                            uint32_t* res_hist, BinAccum* acc, hipStream_t stream);
+                            uint32_t* res_hist, BinAccum* acc, void* slabs, hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =

@@ -204,107 +204,196 @@ __device__ inline void tile_window_counts(const GcTile& gt, unsigned char* s_g, 
 }
 
 // ------------------------------------------------------------------------------------------
-// K2  gc_hist.  PACKED: one 64-bit LDS atomic per base adds (1 << 40) + depth, i.e. count and sum
-// together; valid while every depth is below 2^21 and a workgroup sees at most 64 tiles (sum field
-// < 2^40, count field < 2^24).  Larger depths raise flag bit 1 and the host re-runs the two-atomic
-// form (PACKED = false).
-constexpr int kGcRep = 16;  // LDS replicas per GC level, selected by lane & 15: lanes sharing a replica are 64 bases
-                            // apart, where the window count has usually moved on (neighbouring bases share it)
-constexpr int kGcMaxTilesPerWg = 64;
+// K2  gc_hist, wave-autonomous.  Each wave owns sub-tiles of 1024 bases (16 consecutive bases per
+// lane) and never meets a workgroup barrier inside its loop: its GC words (16 + margins) go to a
+// per-wave LDS slot, a lane derives its 16 window counts from two rank queries plus one
+// leaving/entering bit pair per base, and adds its depths straight from registers into the
+// workgroup's LDS accumulators.  The 64 bytes a lane needs are four 16-byte loads, requested one
+// sub-tile ahead (two register sets used alternately).
+//
+// PACKED: one 64-bit LDS atomic adds (1 << 40) + depth, i.e. count and sum together; valid while
+// every depth is below 2^21 and a workgroup sees at most 2^18 bases (sum field < 2^40, count field
+// < 2^24).  Larger depths raise flag bit 1 and the host re-runs the two-atomic form.
+constexpr int kGcRep = 16;  // LDS replicas per GC level, selected by lane & 15
+constexpr int kSubBases = 1024;                       // bases per wave trip
+constexpr int kSubWords = kSubBases / 64;             // 16
+constexpr int kSubLds = kGcLeft + kSubWords + kGcRight;   // 22 staged words per wave
+constexpr int kGcMaxSubPerWg = 256;                   // 2^18 bases per workgroup at most (packed fields)
+
+struct WaveGc {            // per-wave LDS slot
+  uint64_t word[kSubLds + 2];
+  uint32_t pre[kSubLds + 2];
+};
+
+__device__ inline uint32_t wgc_rank(const WaveGc& t, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  const uint64_t m = b ? (t.word[k] & ((1ull << b) - 1)) : 0;
+  return t.pre[k] + (uint32_t)__popcll(m);
+}
+__device__ inline uint32_t wgc_field16(const WaveGc& t, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  uint64_t v = t.word[k] >> b;
+  if (b > 48) v |= t.word[k + 1] << (64 - b);
+  return (uint32_t)v & 0xffffu;
+}
+
+struct SubRegs { int4 q[4]; uint64_t gw; };
+
+__device__ inline void sub_request(SubRegs& r, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
+                                   int64_t nwords, int64_t base, int64_t n, int lane) {
+  const int64_t i0 = base + 16 * (int64_t)lane;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // branch-free: quads not wholly inside the array read quad 0 (ignored later)
+    const int64_t q = i0 + 4 * k;
+    r.q[k] = *reinterpret_cast<const int4*>(depth + (q + 4 <= n ? q : 0));
+  }
+  const int64_t w = base / 64 - kGcLeft + lane;
+  r.gw = gcbits[(lane < kSubLds && w >= 0 && w < nwords) ? w : 0];
+}
+
+// Workgroup results leave as one plain, coalesced slab per workgroup (kGcSlab 64-bit words:
+// sum[202], cnt[202], possum, poscnt, flags) and are folded by k_gc_hist_reduce.  Thousands of
+// workgroups adding into the same ~400 global words with atomics serialise on those words and
+// cost more than the whole streaming pass.
+constexpr int kGcSlab = 2 * kGcLevels + 4;
 
 template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict__ depth,
                                                       const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
-                                                      GcAccum* __restrict__ acc) {
-  __shared__ GcTile gt;
-  __shared__ __align__(16) unsigned char s_g[kTileBases];
+                                                      unsigned long long* __restrict__ slabs) {
+  __shared__ WaveGc s_gc[kThreads / 64];
+  __shared__ unsigned long long s_tail[3 * (kThreads / 64)];
   __shared__ unsigned long long s_sum[kGcLevels * kGcRep];
   __shared__ unsigned int s_cnt[PACKED ? 1 : kGcLevels * kGcRep];
   for (int e = threadIdx.x; e < kGcLevels * kGcRep; e += kThreads) { s_sum[e] = 0; if (!PACKED) s_cnt[e] = 0; }
-  unsigned long long possum = 0, poscnt = 0;
-  unsigned int neg = 0;
-  int vmax = 0;
-  const int rep = threadIdx.x & (kGcRep - 1);
-  const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
-  // Two register sets used alternately (no copies): the set requested during trip t is consumed in
-  // trip t+1, after that trip's window counts, so a request has a whole trip to land.
-  auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
-    const int64_t base = tile * kTileBases;
-    const int64_t first_bit = base - kGcLeft * 64;
-    __syncthreads();   // previous tile's consumers are done with gt / s_g (and the zeroing above)
-    gc_tile_commit(gt, gcur, nwords, base / 64);
-    __syncthreads();
-    tile_window_counts(gt, s_g, base, n, first_bit);
-    if (tile + gridDim.x < ntiles) {
-      tile_request(nxt, depth, (tile + gridDim.x) * kTileBases, n);
-      gc_tile_request(gnxt, gcbits, nwords, (tile + gridDim.x) * kGcWords);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kTileBases / (4 * kThreads); ++k) {
-      const int li = 4 * (k * kThreads + threadIdx.x);
-      const int64_t q = base + li;
-      if (q + 4 > n) continue;
-      const uint32_t g4 = *reinterpret_cast<const uint32_t*>(s_g + li);
-      // Consecutive bases often share the window count: values of equal count inside the quad are
-      // merged before the LDS atomic.  Named components only (a runtime-indexed array would live in
-      // scratch memory).
-      unsigned long long pend = 0; uint32_t pend_g = 0xffffffffu; unsigned int pend_c = 0;
-      auto flush = [&]() {
-        if (pend_g == 0xffffffffu) return;
-        if (PACKED) atomicAdd(&s_sum[pend_g * kGcRep + rep], pend);
-        else { atomicAdd(&s_sum[pend_g * kGcRep + rep], pend); atomicAdd(&s_cnt[pend_g * kGcRep + rep], pend_c); }
-      };
-      auto one = [&](int val, uint32_t g) {
-        if (g != pend_g) { flush(); pend_g = g; pend = 0; pend_c = 0; }
-        pend += PACKED ? (1ull << 40) + (unsigned long long)(unsigned int)val : (unsigned long long)(long long)val;
-        pend_c += 1;
-        if (val > 0) { possum += (unsigned long long)val; poscnt += 1; }
-        if (val < 0) neg = 1;
-        vmax = val > vmax ? val : vmax;
-      };
-      one(cur.q[k].x, g4 & 0xffu);
-      one(cur.q[k].y, (g4 >> 8) & 0xffu);
-      one(cur.q[k].z, (g4 >> 16) & 0xffu);
-      one(cur.q[k].w, g4 >> 24);
-      flush();
-    }
-  };
-  TileRegs ra, rb;
-  GcRegs ga = {0, 0}, gb = {0, 0};
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) {
-    tile_request(ra, depth, tile * kTileBases, n);
-    gc_tile_request(ga, gcbits, nwords, tile * kGcWords);
-  }
-  while (tile < ntiles) {
-    trip(ra, ga, rb, gb, tile);
-    tile += gridDim.x;
-    if (tile >= ntiles) break;
-    trip(rb, gb, ra, ga, tile);
-    tile += gridDim.x;
-  }
-  if (PACKED && vmax >= (1 << 21)) neg |= 2;   // packed fields could overflow: results of this launch are discarded
   __syncthreads();
-  for (int g = threadIdx.x; g < kGcLevels; g += kThreads) {
-    unsigned long long s = 0, c = 0;
-    for (int r = 0; r < kGcRep; ++r) {
-      const unsigned long long w = s_sum[g * kGcRep + r];
-      if (PACKED) { s += w & ((1ull << 40) - 1); c += w >> 40; }
-      else { s += w; c += s_cnt[g * kGcRep + r]; }
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  WaveGc& G = s_gc[wave];
+  const int rep = lane & (kGcRep - 1);
+  unsigned long long possum = 0, poscnt = 0;
+  int vmax = 0, vmin = 0;
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+
+  auto trip = [&](const SubRegs& cur, SubRegs& nxt, int64_t sub) {
+    const int64_t base = sub * kSubBases;
+    const int64_t first_bit = base - kGcLeft * 64;
+    // ---- commit this sub-tile's GC words + popcount prefix to the wave's LDS slot ----
+    {
+      const int64_t w = base / 64 - kGcLeft + lane;
+      const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
+      uint32_t c = __popcll(word), incl = c;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      if (lane < kSubLds + 1) { G.word[lane] = word; G.pre[lane] = incl - c; }
     }
-    if (c) { atomicAdd(&acc->sum[g], s); atomicAdd(&acc->cnt[g], c); }
+    if (sub + stride < nsub) sub_request(nxt, depth, gcbits, nwords, (sub + stride) * kSubBases, n, lane);
+    __builtin_amdgcn_wave_barrier();
+    // ---- the lane's 16 window counts ----
+    const int64_t i0 = base + 16 * (int64_t)lane;
+    uint32_t cnt0, leave, enter;
+    const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102;   // no edge clamping in this sub-tile
+    if (interior) {
+      const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
+      cnt0 = wgc_rank(G, rel + 201) - wgc_rank(G, rel);
+      leave = wgc_field16(G, rel); enter = wgc_field16(G, rel + 201);
+    } else {
+      cnt0 = leave = enter = 0;
+    }
+    uint32_t cnt = cnt0;
+    unsigned long long pend = 0; uint32_t pend_g = 0xffffffffu; unsigned int pend_c = 0;
+    auto flush = [&]() {
+      if (pend_g == 0xffffffffu) return;
+      if (PACKED) atomicAdd(&s_sum[pend_g * kGcRep + rep], pend);
+      else { atomicAdd(&s_sum[pend_g * kGcRep + rep], pend); atomicAdd(&s_cnt[pend_g * kGcRep + rep], pend_c); }
+      pend_g = 0xffffffffu;
+    };
+    auto add = [&](int val, uint32_t g) {
+      if (g != pend_g) { flush(); pend_g = g; pend = 0; pend_c = 0; }
+      pend += PACKED ? (1ull << 40) + (unsigned long long)(unsigned int)val : (unsigned long long)(long long)val;
+      pend_c += 1;
+      const int pos = val > 0 ? val : 0;
+      possum += (unsigned long long)pos; poscnt += val > 0;
+      vmax = val > vmax ? val : vmax; vmin = val < vmin ? val : vmin;
+    };
+    if (interior) {   // every sub-tile but the first and the last one or two: straight-line code
+      auto one = [&](int val, int j) {
+        add(val, cnt);
+        cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+      };
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { one(cur.q[k].x, 4 * k); one(cur.q[k].y, 4 * k + 1); one(cur.q[k].z, 4 * k + 2); one(cur.q[k].w, 4 * k + 3); }
+    } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only
+      for (int j = 0; j < 16; ++j) {
+        const int64_t i = i0 + j;
+        if ((i & ~(int64_t)3) + 4 > n) break;
+        int64_t lo = i - 100;
+        if (lo < 0) lo = 0;
+        if (lo > n - 202) lo = n - 202;
+        const uint32_t rel = (uint32_t)(lo - first_bit);
+        add(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+      }
+    }
+    flush();
+    __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
+  };
+
+  SubRegs ra, rb;
+  int64_t sub = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+  if (sub < nsub) sub_request(ra, depth, gcbits, nwords, sub * kSubBases, n, lane);
+  while (sub < nsub) {
+    trip(ra, rb, sub);
+    sub += stride;
+    if (sub >= nsub) break;
+    trip(rb, ra, sub);
+    sub += stride;
   }
-  // wave reduction of the positive-depth sums, one atomic per wave
+  unsigned int neg = vmin < 0 ? 1u : 0u;
+  if (PACKED && vmax >= (1 << 21)) neg |= 2;   // packed fields could overflow: results of this launch are discarded
   for (int d = 32; d >= 1; d >>= 1) {
     possum += __shfl_xor(possum, d);
     poscnt += __shfl_xor(poscnt, d);
     neg |= __shfl_xor(neg, d);
   }
-  if (lane_id() == 0) {
-    if (poscnt) { atomicAdd(&acc->possum, possum); atomicAdd(&acc->poscnt, poscnt); }
-    if (neg) atomicOr(&acc->negatives, neg);
+  if (lane == 0) { s_tail[3 * wave] = possum; s_tail[3 * wave + 1] = poscnt; s_tail[3 * wave + 2] = neg; }
+  __syncthreads();
+  unsigned long long* slab = slabs + (size_t)blockIdx.x * kGcSlab;
+  for (int g = threadIdx.x; g < kGcLevels; g += kThreads) {
+    unsigned long long s2 = 0, c = 0;
+    for (int r = 0; r < kGcRep; ++r) {
+      const unsigned long long w = s_sum[g * kGcRep + r];
+      if (PACKED) { s2 += w & ((1ull << 40) - 1); c += w >> 40; }
+      else { s2 += w; c += s_cnt[g * kGcRep + r]; }
+    }
+    slab[g] = s2; slab[kGcLevels + g] = c;
   }
+  if (threadIdx.x == 0) {
+    unsigned long long ps = 0, pc = 0, fl = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { ps += s_tail[3 * w]; pc += s_tail[3 * w + 1]; fl |= s_tail[3 * w + 2]; }
+    slab[2 * kGcLevels] = ps; slab[2 * kGcLevels + 1] = pc; slab[2 * kGcLevels + 2] = fl; slab[2 * kGcLevels + 3] = 0;
+  }
+}
+
+// Fold the per-workgroup slabs into GcAccum.  grid.y splits the slabs into groups of kFoldGroup;
+// each thread sums one word over its group (coalesced across threads) and adds the partial sum with
+// one atomic: a few dozen atomics per word instead of thousands.
+constexpr int kFoldGroup = 32;
+
+__global__ __launch_bounds__(kThreads) void k_gc_hist_reduce(const unsigned long long* __restrict__ slabs, int nslabs,
+                                                             GcAccum* __restrict__ acc) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= kGcSlab) return;
+  const int k0 = blockIdx.y * kFoldGroup, k1 = k0 + kFoldGroup < nslabs ? k0 + kFoldGroup : nslabs;
+  unsigned long long t = 0;
+  const bool is_flag = e == 2 * kGcLevels + 2;
+#pragma unroll 8
+  for (int k = k0; k < k1; ++k) { const unsigned long long v = slabs[(size_t)k * kGcSlab + e]; t = is_flag ? (t | v) : (t + v); }
+  if (!t) return;
+  if (e < kGcLevels) atomicAdd(&acc->sum[e], t);
+  else if (e < 2 * kGcLevels) atomicAdd(&acc->cnt[e - kGcLevels], t);
+  else if (e == 2 * kGcLevels) atomicAdd(&acc->possum, t);
+  else if (e == 2 * kGcLevels + 1) atomicAdd(&acc->poscnt, t);
+  else if (is_flag) atomicOr(&acc->negatives, (unsigned int)t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,7 +414,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          const uint64_t* __restrict__ gcbits, int64_t n,
                                                          int64_t nwords, const double* __restrict__ table,
                                                          double rdmean, int32_t* __restrict__ out,
-                                                         uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
+                                                         uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
+                                                         unsigned int* __restrict__ hist_slabs) {
   __shared__ GcTile gt;
   __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
   __shared__ double s_table[kGcLevels];
@@ -388,10 +478,11 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
     tile += gridDim.x;
   }
   __syncthreads();
+  // per-workgroup slab of kValLds counters, folded by k_hist_slab_reduce (no same-address atomics)
   for (int v = threadIdx.x; v < kValLds; v += kThreads) {
     unsigned int c = 0;
     for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
-    if (c) atomicAdd(&ghist[v], c);
+    hist_slabs[(size_t)blockIdx.x * kValLds + v] = c;
   }
 }
 
@@ -487,7 +578,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     const int32_t* __restrict__ src, int64_t n, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
     int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr /* LDS histogram value range, power of two */,
     int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
-    uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc) {
+    uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc, unsigned int* __restrict__ hist_slabs) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t* s_val = reinterpret_cast<int32_t*>(smem);                       // TB*m values (padded to 4)
   const int tile_elems = TB * m;
@@ -644,11 +735,24 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     if (active && part == 0) { binmed[b] = lo; binsum[b] = ssum; }
   }
   __syncthreads();
-  // ---- flush the LDS histogram (same [value][class] layout as the global one) ----
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
-    const unsigned int c = s_hist[e];
-    if (c) atomicAdd(&res_hist[e], c);
-  }
+  // ---- the LDS histogram leaves as this workgroup's slab (plain coalesced stores); k_hist_slab_reduce
+  // folds the slabs into res_hist.  Atomics from every workgroup into the same few thousand words
+  // would serialise on them. ----
+  unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) slab[e] = s_hist[e];
+}
+
+// out[e] += sum over slabs of slab[e], e < width: grid.y splits the slabs into groups of kFoldGroup,
+// one atomic per (entry, group) with a non-zero partial sum.
+__global__ __launch_bounds__(kThreads) void k_hist_slab_reduce(const unsigned int* __restrict__ slabs, int nslabs, int width,
+                                                               uint32_t* __restrict__ out) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= width) return;
+  const int k0 = blockIdx.y * kFoldGroup, k1 = k0 + kFoldGroup < nslabs ? k0 + kFoldGroup : nslabs;
+  unsigned int t = 0;
+#pragma unroll 8
+  for (int k = k0; k < k1; ++k) t += slabs[(size_t)k * width + e];
+  if (t) atomicAdd(&out[e], t);
 }
 
 inline int grid_for(int64_t items, int per_block) {
@@ -670,20 +774,34 @@ void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list,
   hipLaunchKernelGGL(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
                      count, cap);
 }
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, hipStream_t stream) {
-  const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
-  int64_t grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
-  if (packed && grid * kGcMaxTilesPerWg < ntiles) grid = (ntiles + kGcMaxTilesPerWg - 1) / kGcMaxTilesPerWg;
-  if (grid < 1) grid = 1;
-  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, acc);
-  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, acc);
+size_t gc_hist_slab_bytes(int64_t n) {
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  int64_t grid = (nsub + 3) / 4;
+  if (grid > kMaxGrid) grid = kMaxGrid;
+  const int64_t need = (nsub + kGcMaxSubPerWg - 1) / kGcMaxSubPerWg;
+  if (grid < need) grid = need;
+  return (size_t)(grid < 1 ? 1 : grid) * kGcSlab * 8;
+}
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, void* slabs,
+                    hipStream_t stream) {
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  const int grid = (int)(gc_hist_slab_bytes(n) / (kGcSlab * 8));
+  unsigned long long* sl = static_cast<unsigned long long*>(slabs);
+  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
+  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
+  (void)nsub;
+  hipLaunchKernelGGL(k_gc_hist_reduce, dim3((kGcSlab + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, acc);
   if (n & 3) hipLaunchKernelGGL(k_gc_hist_tail, dim3(1), dim3(64), 0, stream, depth, gcbits, n, acc);
 }
+size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
-                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
-  const dim3 g(grid_for(n, kTileBases)), b(kThreads);
-  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux);
-  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux);
+                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream) {
+  const int grid = grid_for(n, kTileBases);
+  const dim3 g(grid), b(kThreads);
+  unsigned int* sl = static_cast<unsigned int*>(slabs);
+  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
+  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
+  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((kValLds + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, kValLds, hist);
 }
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                           int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
@@ -691,29 +809,39 @@ void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t 
   hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, rdmean, adjust, out, hist, aux);
 }
 
+static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {
+  TB = 64;   // bins per tile: as many as fit ~48 KB of values, 4..64, power of two
+  while (TB > 4 && (size_t)TB * m * 4 > 48 * 1024) TB >>= 1;
+  vr = 64;   // LDS histogram range: covers the capped values when the cap is active, 64..256
+  while (vr < 256 && vr <= capval) vr <<= 1;
+  const int64_t ntiles = (ncompact + (int64_t)TB * m - 1) / ((int64_t)TB * m);
+  grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
+}
+size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact) {
+  int TB, vr, grid;
+  k4_geometry(m, capval, ncompact, TB, vr, grid);
+  return (size_t)grid * vr * kResClasses * 4;
+}
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
-                            uint32_t* res_hist, BinAccum* acc, hipStream_t stream) {
-  // TB bins per tile: as many as fit ~48 KB of values, 4..64, power of two
-  int TB = 64;
-  while (TB > 4 && (size_t)TB * m * 4 > 48 * 1024) TB >>= 1;
-  // LDS histogram range: covers the capped values when the cap is active, 64..256
-  int vr = 64;
-  while (vr < 256 && vr <= capval) vr <<= 1;
+                            uint32_t* res_hist, BinAccum* acc, void* slabs, hipStream_t stream) {
+  int TB, vr, grid;
+  k4_geometry(m, capval, ncompact, TB, vr, grid);
   const size_t tile_pad = ((size_t)TB * m + 3) & ~(size_t)3;
   const size_t lds = tile_pad * 4 + (size_t)vr * kResClasses * 4;
-  const int64_t ntiles = (ncompact + (int64_t)TB * m - 1) / ((int64_t)TB * m);
-  const int grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
   const int quads = (int)(tile_pad / 4);
   const int maxv = (quads + kThreads - 1) / kThreads;          // 16-byte loads per thread and tile
   const int parts = kThreads / TB, ept = (m + parts - 1) / parts;   // values per thread in the median phase
+  unsigned int* sl = static_cast<unsigned int*>(slabs);
 #define RSI_K4(MV, EP) hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg, \
-                                          ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc)
+                                          ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
   else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)
   else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile
   else RSI_K4(13, 0);
 #undef RSI_K4
+  const int width = vr * kResClasses;
+  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((width + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, width, res_hist);
 }
 
 }  // namespace rsik

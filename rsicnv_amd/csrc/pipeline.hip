@@ -91,6 +91,7 @@ struct rsi_ctx {
   // workspace
   DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
   DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del, first_dup;
+  DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
@@ -103,7 +104,7 @@ struct rsi_ctx {
   int32_t* mirror = nullptr;  // host mirror of the compacted depth (DepthPager), grow-only
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
-  bool gate_shared = false;   // also hold bin-level kernels back while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=1)
+  bool gate_shared = true;    // bin-level kernels wait while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=0 disables)
 };
 
 namespace {
@@ -580,13 +581,14 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
   if (P.gcadjust) {
     GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
-    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, st); }
+    HIPCHK(ctx->slabs.ensure(gc_hist_slab_bytes(n)));
+    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, ctx->slabs.p, st); }
     GcAccum acc;
     HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
     HIPCHK(CTX_SYNC());
     if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
       HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
-      { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, st); }
+      { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, ctx->slabs.p, st); }
       HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
       HIPCHK(CTX_SYNC());
     }
@@ -602,14 +604,16 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     double* d_table = reinterpret_cast<double*>(small + kOffTable);
     HIPCHK(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, st));
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-    { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+    HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
+    { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
     { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     HIPCHK(CTX_SYNC());   // table[] leaves scope
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   } else if (want_cap) {
+    HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
     Timer t(ctx, "value_hist");
-    launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
+    launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st);
     launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
   }
 
@@ -659,7 +663,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   const size_t res_vals = want_cap && capval < kHistValues - 1 ? (size_t)std::max(capval, 0) + 1 : (size_t)kHistValues;
   HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, res_vals * kResClasses * 4, st));
   BinAccum* d_bacc = reinterpret_cast<BinAccum*>(small + kOffBinAcc);
-  { Timer t(ctx, "cap_compact_bin"); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, st); }
+  HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
+  { Timer t(ctx, "cap_compact_bin"); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, ctx->slabs.p, st); }
   BinAccum bacc;
   std::vector<uint32_t> hres(res_vals * kResClasses);
   HIPCHK(hipMemcpyAsync(&bacc, d_bacc, sizeof(bacc), hipMemcpyDeviceToHost, st));
@@ -996,7 +1001,7 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
     }
     c->gate = &pool->gate;
     const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
-    c->gate_shared = iso && iso[0] == '1';
+    c->gate_shared = !(iso && iso[0] == '0');   // default on; RSI_HOT_ISOLATE_STREAMING=0 lets everything overlap
     pool->workers.push_back(c);
   }
   if (status) *status = RSI_OK;

@@ -25,3 +25,17 @@ print("kernel," + ",".join(names) + ",launches")
 for k in sorted(acc):
     n = max(v[1] for v in acc[k].values())
     print(k + "," + ",".join(f"{acc[k][c][0] / acc[k][c][1]:.4g}" if c in acc[k] else "" for c in names) + f",{n}")
+
+# --json OUT BASES: also write the per-launch FETCH/WRITE sizes of the streaming kernels for bench.py
+if "--json" in sys.argv:
+    import json
+    out, bases = sys.argv[sys.argv.index("--json") + 1], int(sys.argv[sys.argv.index("--json") + 2])
+    names_map = {"k_gc_hist": "gc_hist", "k_gc_rescale": "gc_rescale", "k_cap_compact_bin": "cap_compact_bin",
+                 "k_fasta_classify": "fasta_classify"}
+    d = {"source": os.path.basename(root.rstrip("/")), "bases_per_launch": bases, "kernels": {}}
+    for k, short in names_map.items():
+        if k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+            d["kernels"][short] = {"FETCH_SIZE_KB": acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1],
+                                   "WRITE_SIZE_KB": acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]}
+    with open(out, "w") as f:
+        json.dump(d, f, indent=1)
