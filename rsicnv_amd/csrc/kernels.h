@@ -35,6 +35,8 @@ struct GcAccum {
 size_t gc_hist_slab_bytes(int64_t n);
 void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, void* slabs,
                     hipStream_t stream);
+// folds the slabs into acc and adds the last n % 4 bases; must follow launch_gc_hist
+void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, const void* slabs, hipStream_t stream);
 
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
@@ -44,6 +46,7 @@ struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int ne
 size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream);
+void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream);   // must follow launch_gc_rescale
 // Must follow launch_gc_rescale: tail quirks of the 20-slice write-back fixed
 // in out[] and hist[], plus the last n % 4 bases, which the streaming kernel leaves out.
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
@@ -66,6 +69,7 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact);
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
                             uint32_t* res_hist, BinAccum* acc, void* slabs, hipStream_t stream);
+void launch_cap_compact_fold(int m, int32_t capval, int64_t ncompact, uint32_t* res_hist, const void* slabs, hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =

@@ -790,7 +790,11 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
   if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
   else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
   (void)nsub;
-  hipLaunchKernelGGL(k_gc_hist_reduce, dim3((kGcSlab + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, acc);
+}
+void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, const void* slabs, hipStream_t stream) {
+  const int grid = (int)(gc_hist_slab_bytes(n) / (kGcSlab * 8));
+  hipLaunchKernelGGL(k_gc_hist_reduce, dim3((kGcSlab + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
+                     static_cast<const unsigned long long*>(slabs), grid, acc);
   if (n & 3) hipLaunchKernelGGL(k_gc_hist_tail, dim3(1), dim3(64), 0, stream, depth, gcbits, n, acc);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
@@ -801,7 +805,11 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
   else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
-  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((kValLds + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, kValLds, hist);
+}
+void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream) {
+  const int grid = grid_for(n, kTileBases);
+  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((kValLds + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
+                     static_cast<const unsigned int*>(slabs), grid, kValLds, hist);
 }
 void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                           int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
@@ -840,8 +848,13 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile
   else RSI_K4(13, 0);
 #undef RSI_K4
+}
+void launch_cap_compact_fold(int m, int32_t capval, int64_t ncompact, uint32_t* res_hist, const void* slabs, hipStream_t stream) {
+  int TB, vr, grid;
+  k4_geometry(m, capval, ncompact, TB, vr, grid);
   const int width = vr * kResClasses;
-  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((width + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream, sl, grid, width, res_hist);
+  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((width + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
+                     static_cast<const unsigned int*>(slabs), grid, width, res_hist);
 }
 
 }  // namespace rsik

@@ -583,12 +583,14 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
     HIPCHK(ctx->slabs.ensure(gc_hist_slab_bytes(n)));
     { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, ctx->slabs.p, st); }
+    { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
     GcAccum acc;
     HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
     HIPCHK(CTX_SYNC());
     if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
       HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
       { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, ctx->slabs.p, st); }
+      { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
       HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
       HIPCHK(CTX_SYNC());
     }
@@ -606,14 +608,15 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
     { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+    { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
     { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     HIPCHK(CTX_SYNC());   // table[] leaves scope
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   } else if (want_cap) {
     HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-    Timer t(ctx, "value_hist");
-    launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st);
+    { Timer t(ctx, "value_hist"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+    launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st);
     launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
   }
 
@@ -665,6 +668,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   BinAccum* d_bacc = reinterpret_cast<BinAccum*>(small + kOffBinAcc);
   HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
   { Timer t(ctx, "cap_compact_bin"); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, ctx->slabs.p, st); }
+  { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, ctx->hist_res.as<uint32_t>(), ctx->slabs.p, st); }
   BinAccum bacc;
   std::vector<uint32_t> hres(res_vals * kResClasses);
   HIPCHK(hipMemcpyAsync(&bacc, d_bacc, sizeof(bacc), hipMemcpyDeviceToHost, st));

@@ -15,5 +15,5 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
   timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pass$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py $@ > $OUT/pass$i.json 2> $OUT/pass$i.err || { tail -5 $OUT/pass$i.err; exit 1; }
   echo "pass $i done: $C"
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT --json $OUT/pmc_traffic.json ${PMC_BASES:-60000000} > $OUT/summary.txt
 cat $OUT/summary.txt
