@@ -72,7 +72,7 @@ DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int3
 void DepthPager::wait() {
   if (!sync_ev_) { (void)hipStreamSynchronize(stream_); return; }
   (void)hipEventRecord(sync_ev_, stream_);
-  for (int spin = 0; spin < 200; ++spin) if (hipEventQuery(sync_ev_) != hipErrorNotReady) return;
+  for (int spin = 0; spin < 2000; ++spin) if (hipEventQuery(sync_ev_) != hipErrorNotReady) return;
   (void)hipEventSynchronize(sync_ev_);
 }
 

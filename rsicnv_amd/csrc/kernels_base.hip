@@ -508,7 +508,8 @@ __global__ void k_gc_hist_tail(const int32_t* __restrict__ depth, const uint64_t
 __global__ void k_gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
                                 const double* __restrict__ table, double rdmean, int adjust, int32_t* __restrict__ out,
                                 uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave; lane k handles tail cell k (r <= 19)
+  const int lane = threadIdx.x;
   const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
   auto hist_add = [&](int to) {
     if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
@@ -520,22 +521,27 @@ __global__ void k_gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_
     else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
   };
   if (!adjust) {
-    for (int64_t i = ragged; i < n; ++i) hist_add(depth[i]);
+    if (ragged + lane < n) hist_add(depth[ragged + lane]);
     return;
   }
   const int64_t S = n / 20, r = n - 20 * S;   // r >= n % 4, so the ragged bases are among the last r
-  if (r >= 2) {
-    int gtail = 0;   // fresh edge window [n-201, n-1]
-    for (int64_t i = n - 201; i < n; ++i) gtail += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
-    for (int64_t k = 0; k < r; ++k) {
-      const int nv = (int)((double)depth[20 * S + k] * rdmean / table[gtail] + 0.5);
-      const int64_t idx = n - 201 + k;
-      hist_sub(out[idx]); hist_add(nv);
-      out[idx] = nv;
-    }
+  if (r == 0) return;
+  // fresh edge window [n-201, n-1]: 201 mask bits counted with four ballots
+  int gtail = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int64_t i = n - 201 + 64 * c + lane;
+    const bool bit = i < n && ((gcbits[i >> 6] >> (i & 63)) & 1);
+    gtail += __popcll(__ballot(bit));
   }
-  for (int64_t k = 0; k < r; ++k) {   // the last r bases keep their unadjusted depth
-    const int64_t idx = 20 * S + k;
+  // the two groups of cells are disjoint (n-201+k < 20S), and each lane owns one cell of each
+  if (r >= 2 && lane < r) {
+    const int nv = (int)((double)depth[20 * S + lane] * rdmean / table[gtail] + 0.5);
+    const int64_t idx = n - 201 + lane;
+    hist_sub(out[idx]); hist_add(nv);
+    out[idx] = nv;
+  }
+  if (lane < r) {   // the last r bases keep their unadjusted depth
+    const int64_t idx = 20 * S + lane;
     if (idx < ragged) hist_sub(out[idx]);
     hist_add(depth[idx]);
     out[idx] = depth[idx];

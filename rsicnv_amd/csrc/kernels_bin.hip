@@ -104,20 +104,35 @@ __global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict
   }
 }
 
-constexpr uint32_t kLdsBins = 12288;   // 48 KB of LDS counters
+constexpr uint32_t kLdsBins = 32768;   // 128 KB of LDS counters (one workgroup per CU): covers a value range of 327
+
+// Each thread takes kHistRun consecutive elements and merges equal neighbouring buckets before the
+// atomic: bin medians (-MED) are small integers, so long runs land in one bucket and a plain
+// one-atomic-per-element histogram serialises on it (271 ms per 3 Gb step with global atomics).
+constexpr int kHistRun = 8;
 
 __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                        int64_t nb, int use_abs, double center, double ymin,
                                                        uint32_t* __restrict__ hist, uint32_t np, int use_lds) {
   extern __shared__ unsigned int s_h[];
   if (use_lds) { for (uint32_t e = threadIdx.x; e < np; e += kThreads) s_h[e] = 0; __syncthreads(); }
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
-    if (mask && mask[i] != 0) continue;
-    const float v = sel_value(x, i, use_abs, center);
-    const double idx = ((double)v - ymin) / 0.01 + 0.5;      // wufunctions.cpp:396
-    uint32_t k = (uint32_t)(unsigned long long)idx;
-    if (k >= np) k = np - 1;                                 // cannot happen (np = range/dy + 2)
-    if (use_lds) atomicAdd(&s_h[k], 1u); else atomicAdd(&hist[k], 1u);
+  const int64_t nchunks = (nb + kHistRun - 1) / kHistRun;
+  for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
+    uint32_t pend_k = 0xffffffffu, pend_c = 0;
+    const int64_t i0 = c * kHistRun, i1 = i0 + kHistRun < nb ? i0 + kHistRun : nb;
+    for (int64_t i = i0; i < i1; ++i) {
+      if (mask && mask[i] != 0) continue;
+      const float v = sel_value(x, i, use_abs, center);
+      const double idx = ((double)v - ymin) / 0.01 + 0.5;      // wufunctions.cpp:396
+      uint32_t k = (uint32_t)(unsigned long long)idx;
+      if (k >= np) k = np - 1;                                 // cannot happen (np = range/dy + 2)
+      if (k != pend_k) {
+        if (pend_c) { if (use_lds) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+        pend_k = k; pend_c = 0;
+      }
+      ++pend_c;
+    }
+    if (pend_c) { if (use_lds) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
   }
   if (use_lds) {
     __syncthreads();
@@ -474,8 +489,12 @@ void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin, uint32_t* hist,
                      uint32_t np, hipStream_t stream) {
   const int use_lds = np <= kLdsBins;
-  hipLaunchKernelGGL(k_hist_f32, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), use_lds ? (size_t)np * 4 : 0, stream, x, mask,
-                     nb, use_abs, center, ymin, hist, np, use_lds);
+  const size_t lds = use_lds ? (size_t)np * 4 : 0;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // few, long-lived workgroups: every one flushes np counters at the end
+  int grid = grid_for(nb, kThreads * kHistRun * 8);
+  if (grid > 128) grid = 128;
+  hipLaunchKernelGGL(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del, const double* thr_dup,
                      uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {

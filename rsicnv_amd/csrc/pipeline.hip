@@ -100,8 +100,7 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
-  void* pinned = nullptr;     // hipHostMalloc staging for device -> host transfers
-  int32_t* mirror = nullptr;  // host mirror of the compacted depth (DepthPager), grow-only
+  int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
   bool gate_shared = true;    // bin-level kernels wait while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=0 disables)
@@ -125,7 +124,7 @@ namespace {
 hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
   hipError_t e = hipEventRecord(ev, stream);
   if (e != hipSuccess) return e;
-  for (int spin = 0; spin < 200; ++spin) {
+  for (int spin = 0; spin < 2000; ++spin) {
     e = hipEventQuery(ev);
     if (e == hipSuccess) return hipSuccess;
     if (e != hipErrorNotReady) return e;
@@ -155,7 +154,6 @@ constexpr int kMaxRegions = 4096;
 constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr uint32_t kMaxRunEntries = 1u << 20;
 constexpr int kMaxL = 2048;
-constexpr size_t kPinnedBytes = 8u << 20;   // pinned staging buffer per context
 
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
@@ -790,14 +788,16 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       if ((rc = do_scan(false, more)) != RSI_OK) return rc;
       tested.insert(tested.end(), more.begin(), more.end());
     }
-    if (!ctx->pinned) { if (hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) ctx->pinned = nullptr; }
-    if (ctx->mirror_cap < (size_t)ncompact) {   // grow-only host mirror, pages are touched only where candidates are
-      free(ctx->mirror);
+    if (ctx->mirror_cap < (size_t)ncompact) {   // grow-only pinned host mirror: transfers land in it directly
+      if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+      ctx->mirror = nullptr;
       ctx->mirror_cap = (size_t)ncompact + (size_t)ncompact / 8 + 1024;
-      ctx->mirror = static_cast<int32_t*>(malloc(ctx->mirror_cap * sizeof(int32_t)));
-      if (!ctx->mirror) { ctx->mirror_cap = 0; return fail(ctx, RSI_ERR_INTERNAL, "out of host memory for the depth mirror"); }
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mirror), ctx->mirror_cap * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        ctx->mirror = nullptr; ctx->mirror_cap = 0;
+        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the depth mirror");
+      }
     }
-    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, ctx->pinned, ctx->pinned ? kPinnedBytes : 0, ctx->sync_ev);
+    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, nullptr, 0, ctx->sync_ev);
     rsih::CallProfile prof;
     in.prof = &prof;
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
@@ -860,8 +860,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  free(ctx->mirror);
+  if (ctx->mirror) (void)hipHostFree(ctx->mirror);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
