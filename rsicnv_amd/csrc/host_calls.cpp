@@ -4,6 +4,7 @@
 // candidates survive, so they have to round like the reference's x86-64 build.
 #include "host_calls.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -64,9 +65,9 @@ double normal_cdf(double x) {
 }
 
 // ------------------------------------------------------------------------------------------
-DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging, size_t staging_bytes,
+DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, std::function<int32_t*()> mirror, void* staging, size_t staging_bytes,
                        hipEvent_t sync_event)
-    : d_(d_ptr), n_(n), stream_(stream), mirror_(mirror), have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 0),
+    : d_(d_ptr), n_(n), stream_(stream), mirror_source_(std::move(mirror)), have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 0),
       staging_(static_cast<int32_t*>(staging)), staging_elems_((int64_t)(staging_bytes / sizeof(int32_t))), sync_ev_(sync_event) {}
 
 void DepthPager::wait() {
@@ -78,6 +79,10 @@ void DepthPager::wait() {
 
 void DepthPager::fetch(int64_t p0, int64_t p1) {
   const double t0 = tick_ms();
+  if (!mirror_) {
+    mirror_ = mirror_source_ ? mirror_source_() : nullptr;
+    if (!mirror_) { fprintf(stderr, "rsi_hot: no host memory for the depth mirror\n"); abort(); }
+  }
   const int64_t lo = p0 << kBits;
   int64_t hi = ((p1 + 1) << kBits);
   if (hi > n_) hi = n_;
@@ -130,6 +135,36 @@ struct PagedView {
   const int* raw() const { return p->raw(); }    // valid only inside ranges that were prefetched
 };
 
+// ---- isitcnv's decision part (rsi.cpp:126-169) from the statistics of the two arrays ----
+void finish_judgement(const CallerInput& in, const TestStats& st, Candidate& c) {
+  double spread = sqrt(st.ref_var);
+  if (spread < 1E-3) spread = st.ref_med / 40.0 + 1E-3;
+  c.length = c.end - c.start + 1;
+  c.cnvmed = st.cnv_med;
+  c.cnvsd = sqrt(st.cnv_var);
+  c.cnviqr = st.cnv_uqt - st.cnv_lqt;
+  c.refmed = st.ref_med;
+  c.refiqr = st.ref_uqt - st.ref_lqt;
+  c.refsd = c.refiqr / 1.349;
+  c.geno = 1;
+  c.status = 1;
+  const int observed = c.cnvmed > in.RDmedian ? kDup : kDel;
+  if (c.type == kUnknown) c.type = observed;
+  if (c.type != observed) { c.status = -9; return; }   // "basic assignment error"
+  if (c.type == kDel) {
+    double level = std::min(st.ref_med, in.RDmedian);
+    level = std::max(level, 0.8 * in.RDmedian);
+    const double nu = (3.0 * c.cnvmed - 2.0 * level) / spread;
+    c.p1 = normal_cdf(nu);
+    if (nu > 0) { c.status = -9; c.geno = 0; }
+  } else {
+    const double level = std::max(st.ref_med, in.RDmedian);
+    const double nu = (2.5 * c.cnvmed - 3.0 * level) / spread / 1.5;
+    c.p1 = 1.0 - normal_cdf(nu);
+    if (nu < 0) { c.status = -9; c.geno = 0; }
+  }
+}
+
 // ---- isitcnv (rsi.cpp:101-172): statistics of the candidate against its neighbourhood ----
 void judge(const CallerInput& in, const std::vector<int>& ref, const std::vector<int>& body, Candidate& c) {
   const double t0 = tick_ms();
@@ -160,30 +195,11 @@ void judge(const CallerInput& in, const std::vector<int>& ref, const std::vector
   const double t3 = tick_ms();
   const Quantiles qc = grid_quantiles(body.data(), body.size());
   if (in.prof) { in.prof->winmean += t1 - t0; in.prof->quantiles += (t2 - t1) + (tick_ms() - t3); in.prof->variance += t3 - t2; in.prof->tests++; }
-  c.length = c.end - c.start + 1;
-  c.cnvmed = qc.med;
-  c.cnvsd = sqrt(variance_pop(body.data(), body.size()));
-  c.cnviqr = qc.uqt - qc.lqt;
-  c.refmed = qr.med;
-  c.refiqr = qr.uqt - qr.lqt;
-  c.refsd = c.refiqr / 1.349;
-  c.geno = 1;
-  c.status = 1;
-  const int observed = c.cnvmed > in.RDmedian ? kDup : kDel;
-  if (c.type == kUnknown) c.type = observed;
-  if (c.type != observed) { c.status = -9; return; }   // "basic assignment error"
-  if (c.type == kDel) {
-    double level = std::min(qr.med, in.RDmedian);
-    level = std::max(level, 0.8 * in.RDmedian);
-    const double nu = (3.0 * c.cnvmed - 2.0 * level) / spread;
-    c.p1 = normal_cdf(nu);
-    if (nu > 0) { c.status = -9; c.geno = 0; }
-  } else {
-    const double level = std::max(qr.med, in.RDmedian);
-    const double nu = (2.5 * c.cnvmed - 3.0 * level) / spread / 1.5;
-    c.p1 = 1.0 - normal_cdf(nu);
-    if (nu < 0) { c.status = -9; c.geno = 0; }
-  }
+  TestStats st;
+  st.cnv_lqt = qc.lqt; st.cnv_med = qc.med; st.cnv_uqt = qc.uqt; st.cnv_var = variance_pop(body.data(), body.size());
+  st.ref_lqt = qr.lqt; st.ref_med = qr.med; st.ref_uqt = qr.uqt; st.ref_var = s2 / double(nwin) - mu * mu;
+  (void)spread;
+  finish_judgement(in, st, c);
 }
 
 // ---- isitcnvwrap (rsi.cpp:175-287): collect the reference neighbourhood around list[ci] ----
@@ -270,6 +286,100 @@ void test_candidate(const CallerInput& in, const View& A, std::vector<Candidate>
   }
   if (in.prof) in.prof->gather += tick_ms() - tg0;
   judge(in, ref, body, list[ci]);
+}
+
+// ---- the list-only part of isitcnvwrap (rsi.cpp:175-257) for a device test of list[ci] on an array of N values ----
+constexpr int kChainMax = 48;   // neighbour intervals handed to the device per side; it reports when it needs more
+TestPlan plan_test(const CallerInput& in, int64_t N, const std::vector<Candidate>& list, int ci, int* cut) {
+  const rsi_params& P = in.P;
+  const int count = (int)list.size();
+  const Candidate& me = list[ci];
+  const int body_len = me.end - me.start + 1;
+  const int span_all = (int)in.ncompact;
+  int d = body_len;
+  if (N == span_all) { if (d < P.m * P.minmlen) d = (int)(P.m * P.minmlen); }
+  if (N < span_all / 2) { if (d < P.minmlen) d = (int)P.minmlen + 1; }
+  TestPlan T;
+  T.start = me.start; T.end = me.end; T.kind = me.type;
+  T.capacity = (int)(P.chklen * d * 2);
+  T.margin = int(body_len * P.buffer + 1);
+  T.top = (int)(P.chklen * d - 1);
+  if (N - me.end < P.chklen * d) T.top = T.capacity - 1 - (int)N + me.end;
+  T.right_cap = 2 * P.chklen * d;
+  T.budget = P.maxchkbp * 10;
+  *cut = 0;
+  // left: the neighbours the downward walk meets, in the order its `idx` pointer visits them
+  int pos = me.start - T.margin;
+  int nb = ci - 1;
+  while (pos > 0 && nb > 0 && pos < list[nb].start) --nb;
+  while (nb > 0 && list[nb].status == -9) --nb;
+  while (nb >= 0 && (int)T.left_chain.size() < kChainMax) {
+    T.left_chain.push_back({list[nb].start, list[nb].end});
+    --nb;
+    while (nb > 0 && list[nb].status == -9) --nb;
+  }
+  if (nb >= 0) *cut |= 1;
+  // right
+  pos = me.end + T.margin;
+  nb = ci + 1;
+  while (pos < N - 2 && nb < count && pos > list[nb].end) ++nb;
+  while (nb < count - 1 && list[nb].status == -9) ++nb;
+  while (nb < count && (int)T.right_chain.size() < kChainMax) {
+    T.right_chain.push_back({list[nb].start, list[nb].end});
+    ++nb;
+    while (nb < count - 1 && list[nb].status == -9) ++nb;
+  }
+  if (nb < count) *cut |= 2;
+  T.cut = *cut;
+  return T;
+}
+
+bool same_plan(const TestPlan& a, const TestPlan& b) {
+  return a.start == b.start && a.end == b.end && a.kind == b.kind && a.margin == b.margin && a.capacity == b.capacity &&
+         a.top == b.top && a.budget == b.budget && a.right_cap == b.right_cap && a.cut == b.cut && a.left_chain == b.left_chain &&
+         a.right_chain == b.right_chain;
+}
+
+// Results of tests launched ahead of the list logic that decides whether they are needed: a result is
+// used only if the plan built from the list as it really is at that moment equals the guessed one.
+struct Speculation {
+  std::vector<TestPlan> plans;
+  std::vector<TestStats> stats;
+  std::vector<int> reach;
+  std::vector<char> ok, have;
+  void run(const CallerInput& in) {
+    if (plans.empty()) return;
+    if (!in.tester->test(plans, stats, reach, ok)) ok.assign(plans.size(), 0);
+    have.assign(plans.size(), 1);
+  }
+};
+
+// test of list[ci] against the per-base depth: on the device when a tester is attached (using a
+// speculative result when its plan still holds), else -- or when the device declines -- on the host
+void test_bases(const CallerInput& in, const PagedView& A, std::vector<Candidate>& list, int ci, const Speculation* spec = nullptr,
+                int slot = -1) {
+  if (!in.tester) { test_candidate(in, A, list, ci); return; }
+  const double t0 = tick_ms();
+  int cut = 0;
+  TestPlan plan = plan_test(in, A.size(), list, ci, &cut);
+  TestStats st{};
+  bool ok = false;
+  if (spec && slot >= 0 && slot < (int)spec->plans.size() && spec->have[slot] && same_plan(plan, spec->plans[slot])) {
+    ok = spec->ok[slot] != 0;
+    st = spec->stats[slot];
+    if (in.prof) in.prof->spec_hits++;
+  } else {
+    std::vector<TestPlan> one(1, plan);
+    std::vector<TestStats> sts;
+    std::vector<int> reach;
+    std::vector<char> oks;
+    ok = in.tester->test(one, sts, reach, oks) && oks[0];
+    if (ok) st = sts[0];
+    if (in.prof) in.prof->single_tests++;
+  }
+  if (in.prof) { in.prof->device_ms += tick_ms() - t0; in.prof->tests++; }
+  if (!ok) { if (in.prof) in.prof->host_fallbacks++; test_candidate(in, A, list, ci); return; }
+  finish_judgement(in, st, list[ci]);
 }
 
 // ---- get_continuous_segments (rsi.cpp:291-327): runs of equal-sign marks, last run not emitted ----
@@ -374,8 +484,7 @@ void drop_deleted(std::vector<Candidate>& L) {
 }
 
 // ---- mergesegments (rsi.cpp:694-885) ----
-template <class View>
-void merge_neighbours(const CallerInput& in, const View& A, std::vector<Candidate>& L) {
+void merge_neighbours(const CallerInput& in, const PagedView& A, std::vector<Candidate>& L) {
   const rsi_params& P = in.P;
   std::vector<Candidate> T;
   // overlapping neighbours of one type
@@ -386,12 +495,12 @@ void merge_neighbours(const CallerInput& in, const View& A, std::vector<Candidat
     joined.start = std::min(L[i].start, L[i + 1].start);
     joined.end = std::max(L[i].end, L[i + 1].end);
     T = L; T[i] = joined; T[i + 1] = joined; T[i + 1].status = -9;
-    test_candidate(in, A, T, i);
+    test_bases(in, A, T, i);
     if (T[i].geno == 0) {   // the union fails: test each on its own
       T = L; T[i + 1].status = -9;
-      test_candidate(in, A, T, i);
+      test_bases(in, A, T, i);
       T[i].status = -9; T[i + 1].status = 0;
-      test_candidate(in, A, T, i + 1);
+      test_bases(in, A, T, i + 1);
       if (T[i + 1].p1 < T[i].p1) T[i] = T[i + 1];
       if (T[i].p1 > P.p) { L[i].status = -9; L[i + 1].status = -9; }
     }
@@ -402,21 +511,70 @@ void merge_neighbours(const CallerInput& in, const View& A, std::vector<Candidat
   drop_deleted(L);
   if (!P.merge) return;
   // nearby neighbours of one type
-  for (int i = 0; i + 1 < (int)L.size(); ++i) {
-    if (L[i].type != L[i + 1].type) continue;
-    if (L[i].geno == 0 || L[i + 1].geno == 0) continue;
+  auto near_pair = [&](int i) {
+    if (L[i].type != L[i + 1].type) return false;
+    if (L[i].geno == 0 || L[i + 1].geno == 0) return false;
     const int gap = L[i + 1].start - L[i].end;
     const int w1 = L[i].end - L[i].start, w2 = L[i + 1].end - L[i + 1].start;
-    if (gap > w1 * P.chklen * 0.7 && gap > w2 * P.chklen * 0.7) continue;
-    const double m1 = range_mean(A, L[i].start, L[i].end), m2 = range_mean(A, L[i + 1].start, L[i + 1].end);
+    return !(gap > w1 * P.chklen * 0.7 && gap > w2 * P.chklen * 0.7);
+  };
+  // With a device tester the three range sums of every pair that qualifies on the list as it stands
+  // are taken in one launch, and the joined candidates that pass the depth rule are tested in a
+  // second one; a pair whose members changed through an earlier merge is redone on its own.
+  const int npairs = std::max(0, (int)L.size() - 1);
+  std::vector<int64_t> sums;
+  std::vector<int> sum_slot((size_t)npairs, -1);
+  std::vector<std::pair<int, int>> ranges;
+  if (in.tester) {
+    for (int i = 0; i < npairs; ++i) {
+      if (!near_pair(i)) continue;
+      sum_slot[i] = (int)ranges.size();
+      ranges.push_back({L[i].start, L[i].end});
+      ranges.push_back({L[i + 1].start, L[i + 1].end});
+      ranges.push_back({L[i].start, L[i + 1].end});
+    }
+    if (!ranges.empty() && !in.tester->range_sums(ranges, sums)) { sums.clear(); std::fill(sum_slot.begin(), sum_slot.end(), -1); }
+  }
+  auto mean_of = [&](int slot, int lo, int hi) -> double {   // mean_tp, wufunctions.cpp:666-690 (integer sums are exact in double)
+    if (slot >= 0 && ranges[slot].first == lo && ranges[slot].second == hi) return (double)sums[slot] / double(hi - lo + 1);
+    if (in.tester) {
+      std::vector<std::pair<int, int>> one(1, {lo, hi});
+      std::vector<int64_t> s1;
+      if (in.tester->range_sums(one, s1)) return (double)s1[0] / double(hi - lo + 1);
+    }
+    return range_mean(A, lo, hi);
+  };
+  auto depth_rule = [&](int i, int slot) {   // true: the pair may be joined (rsi.cpp:775-790)
+    const int w1 = L[i].end - L[i].start, w2 = L[i + 1].end - L[i + 1].start;
+    const double m1 = mean_of(slot, L[i].start, L[i].end), m2 = mean_of(slot < 0 ? -1 : slot + 1, L[i + 1].start, L[i + 1].end);
     const double both = (m1 * w1 + m2 * w2) / (w1 + w2);
-    const double across = range_mean(A, L[i].start, L[i + 1].end);
-    if (L[i].type == kDel && across > both + 1.5 * L[i + 1].refsd + 1.5 * L[i].refsd) continue;
-    if (L[i].type == kDup && across < both - 1.5 * L[i + 1].refsd - 1.5 * L[i].refsd) continue;
+    const double across = mean_of(slot < 0 ? -1 : slot + 2, L[i].start, L[i + 1].end);
+    if (L[i].type == kDel && across > both + 1.5 * L[i + 1].refsd + 1.5 * L[i].refsd) return false;
+    if (L[i].type == kDup && across < both - 1.5 * L[i + 1].refsd - 1.5 * L[i].refsd) return false;
+    return true;
+  };
+  auto joined_list = [&](int i) {
     Candidate joined = L[i];
     joined.end = L[i + 1].end;
     T = L; T[i] = joined; T[i + 1] = joined; T[i + 1].status = -9;
-    test_candidate(in, A, T, i);
+  };
+  Speculation spec;
+  std::vector<int> spec_slot((size_t)npairs, -1);
+  if (in.tester) {
+    for (int i = 0; i < npairs; ++i) {
+      if (sum_slot[i] < 0 || !depth_rule(i, sum_slot[i])) continue;
+      joined_list(i);
+      int cut = 0;
+      spec_slot[i] = (int)spec.plans.size();
+      spec.plans.push_back(plan_test(in, A.size(), T, i, &cut));
+    }
+    spec.run(in);
+  }
+  for (int i = 0; i + 1 < (int)L.size(); ++i) {
+    if (!near_pair(i)) continue;
+    if (!depth_rule(i, in.tester ? sum_slot[i] : -1)) continue;
+    joined_list(i);
+    test_bases(in, A, T, i, &spec, spec_slot[i]);
     if (T[i].geno == 0) continue;
     L[i] = T[i]; L[i + 1] = T[i]; L[i].status = -9;
   }
@@ -485,21 +643,32 @@ void call_from_segments(const CallerInput& in, std::vector<Candidate> segs, Dept
     L.push_back(c);
   }
   const double ts0 = tick_ms();
-  for (int pass = 0; pass < 2; ++pass) for (Candidate& c : L) sharpen_edges(bases, c);
+  if (!(in.tester && in.tester->sharpen(L)))
+    for (int pass = 0; pass < 2; ++pass) for (Candidate& c : L) sharpen_edges(bases, c);
   order_by_start(L);
   const double ts1 = tick_ms();
   merge_neighbours(in, bases, L);
-  if (in.prof) { in.prof->sharpen += ts1 - ts0; in.prof->merge += tick_ms() - ts1; }
+  const double ts2 = tick_ms();
   order_by_start(L);
+  // final tests (rsi.cpp:1893-1913).  Test i sees which earlier candidates were just rejected, so with
+  // a device tester all tests are first run against the list as it stands, and a result is replaced
+  // only where a rejection changed the plan of a later test.
+  Speculation spec;
+  if (in.tester) {
+    int cut = 0;
+    for (int i = 0; i < (int)L.size(); ++i) spec.plans.push_back(plan_test(in, bases.size(), L, i, &cut));
+    spec.run(in);
+  }
   raw.clear();
   for (int i = 0; i < (int)L.size(); ++i) {
     const double nbins = double(L[i].end - L[i].start + 1) / double(m);
-    test_candidate(in, bases, L, i);
+    test_bases(in, bases, L, i, &spec, i);
     L[i].score = (L[i].cnvmed - in.RDmedian) * sqrt(nbins);
     const int r1 = to_reference(*in.noncode, L[i].start), r2 = to_reference(*in.noncode, L[i].end);
     for (const Region& g : *in.noncode) if (std::max(r1, g.start) <= std::min(r2, g.end)) L[i].status = -9;
     if (L[i].status != -9) raw.push_back(L[i]);
   }
+  if (in.prof) { in.prof->sharpen += ts1 - ts0; in.prof->merge += ts2 - ts1; in.prof->final_tests += tick_ms() - ts2; }
   for (Candidate& c : raw) { c.start = to_reference(*in.noncode, c.start); c.end = to_reference(*in.noncode, c.end); }
 
   kept.clear();

@@ -5,7 +5,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <memory>
+#include <utility>
 #include <vector>
 #include "../../include/rsi_hot.h"
 
@@ -25,9 +27,11 @@ struct Region { int start, end; };   // inclusive, reference coordinates (rsi::n
 // (about 0.1-1 % of a chromosome around the candidates), in one transfer per missing stretch.
 class DepthPager {
  public:
-  // mirror: host buffer of at least n elements owned by the caller (reused across chromosomes, so
-  // no address space is mapped and unmapped per call); staging: optional pinned buffer for the DMA.
-  DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, int32_t* mirror, void* staging = nullptr,
+  // mirror: provider of a host buffer of at least n elements owned by the caller (reused across
+  // chromosomes, so no address space is mapped and unmapped per call), asked for on the first page
+  // fetch only -- with the candidate stages on the device it is normally never needed; staging:
+  // optional pinned buffer for the DMA.
+  DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, std::function<int32_t*()> mirror, void* staging = nullptr,
              size_t staging_bytes = 0, hipEvent_t sync_event = nullptr);
   DepthPager(const DepthPager&) = delete;
   DepthPager& operator=(const DepthPager&) = delete;
@@ -46,7 +50,8 @@ class DepthPager {
   const int32_t* d_;
   int64_t n_;
   hipStream_t stream_;
-  int32_t* mirror_ = nullptr;          // malloc'ed, untouched until a page is fetched
+  std::function<int32_t*()> mirror_source_;
+  int32_t* mirror_ = nullptr;          // obtained from mirror_source_ on the first fetch
   std::vector<unsigned char> have_;
   int32_t* staging_ = nullptr;         // pinned, owned by the context
   int64_t staging_elems_ = 0;
@@ -57,11 +62,40 @@ class DepthPager {
 };
 
 // wall-clock split of the candidate stages (ms), filled when CallerInput::prof is set
-struct CallProfile { double fetch = 0, gather = 0, winmean = 0, quantiles = 0, variance = 0, sharpen = 0, merge = 0; int tests = 0; };
+struct CallProfile {
+  double fetch = 0, gather = 0, winmean = 0, quantiles = 0, variance = 0, sharpen = 0, merge = 0, final_tests = 0, device_ms = 0;
+  int tests = 0, spec_hits = 0, single_tests = 0, host_fallbacks = 0;
+};
+
+// Statistics of one neighbourhood test (what isitcnv derives from its two arrays, rsi.cpp:113-147).
+struct TestStats { double cnv_lqt, cnv_med, cnv_uqt, cnv_var, ref_lqt, ref_med, ref_uqt, ref_var; };
+
+// One prepared neighbourhood test: the part of isitcnvwrap (rsi.cpp:175-257) that only looks at
+// the candidate list -- sizes, margins and the neighbour intervals the two walks may jump over, in
+// the order the reference's `idx` pointer visits them.
+struct TestPlan {
+  int start, end, kind, margin, capacity, top, budget, cut;
+  double right_cap;
+  std::vector<std::pair<int, int>> left_chain, right_chain;   // (start, end)
+};
+
+// Per-base tests executed on the device (kernels_cand.hip); implemented next to the pipeline.
+class NeighbourTester {
+ public:
+  virtual ~NeighbourTester() {}
+  // optimize_with_derivative twice for every candidate (rsi.cpp:1876-1877)
+  virtual bool sharpen(std::vector<Candidate>& L) = 0;
+  // ok[k] = 0: the device could not serve plan k (histogram range); the caller uses the host path
+  virtual bool test(const std::vector<TestPlan>& plans, std::vector<TestStats>& stats, std::vector<int>& left_reach,
+                    std::vector<char>& ok) = 0;
+  // exact sums of the depth over inclusive ranges (mean_tp in mergesegments, rsi.cpp:775-779)
+  virtual bool range_sums(const std::vector<std::pair<int, int>>& ranges, std::vector<int64_t>& sums) = 0;
+};
 
 struct CallerInput {
   rsi_params P;
   CallProfile* prof = nullptr;
+  NeighbourTester* tester = nullptr;   // when set, per-base candidate work runs on the device
   double RDmedian, RDsd;
   int64_t ncompact;                 // rsi::end with rsi::start = 1
   const std::vector<Region>* noncode;

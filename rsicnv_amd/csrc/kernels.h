@@ -131,4 +131,35 @@ void launch_best_items(const void* items, int nitems, const int64_t* poff, const
 void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, int nruns,
                       double delthr, double addthr, hipStream_t stream);
 
+// ---- candidate stages on the device (kernels_cand.hip) ----
+constexpr unsigned kCandHistBins = 16384;   // LDS counters of the per-test quantile histograms
+struct EdgeJob {            // optimize_with_derivative for one candidate, both passes; start/end updated in place
+  int32_t start, end, type, scratch_len;   // scratch_len: int64 words available at scratch_off
+  int64_t scratch_off;
+};
+struct CandJob {            // one isitcnvwrap test, prepared on the host from the candidate list
+  int32_t start, end;       // the candidate (compacted coordinates, inclusive)
+  int32_t kind;             // 0 DEL, 1 DUP
+  int32_t margin;           // int(len*buffer + 1)
+  int32_t capacity;         // (int)(chklen*d*2): slots of the neighbourhood array
+  int32_t top;              // slot the left side starts filling from (downwards)
+  int32_t nleft, nright;    // neighbour intervals the walk may have to jump over, in pointer order
+  int32_t left_off, right_off;   // offsets into the chain array (int2 start,end)
+  int32_t budget;           // maxchkbp*10: thinning threshold
+  int32_t cut;              // bit 0 / 1: the left / right chain was cut short by the host (the kernel reports when it runs out)
+  double right_cap;         // 2*chklen*d (the right side appends while used < right_cap)
+  int64_t iscratch_off;     // int32 scratch: (top+1) + capacity + min(capacity, budget)
+  int64_t lscratch_off;     // int64 scratch: capacity + 1
+};
+struct CandOut {
+  int32_t flags;            // 1: empty neighbourhood, 2: body value range beyond the LDS histogram, 4: same for the window means, 8: cut chain used up
+  int32_t nref, nbody, nwin, left_reach, right_reach, body_min, body_max;
+  double body_q[3], body_s1, body_s2;   // lower quartile / median / upper quartile (partition_stat_tp), sum, sum of squares
+  double ref_q[3], ref_s1, ref_s2;      // the same for the window means
+};
+void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* scratch, hipStream_t stream);
+void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+                           int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
+
 }  // namespace rsik

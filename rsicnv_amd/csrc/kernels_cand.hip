@@ -1,0 +1,369 @@
+// kernels_cand.hip -- candidate stages on the device: boundary refinement
+// (optimize_with_derivative, rsi.cpp:889-944) and the neighbourhood test (isitcnvwrap + isitcnv,
+// rsi.cpp:175-287, 101-172) directly on the compacted depth in HBM, one workgroup per candidate.
+// The host keeps the list logic (who is whose neighbour, what is deleted, merge decisions); the
+// device does every array-sized step, so the per-base depth never has to be paged to the host.
+//
+// Exactness: all sums of depths are integers (int64); window means are (float)((double)S/width)
+// as in the reference; quantiles come from integer histograms on the reference's grids.  The one
+// deviation is the second moment of the window means, summed here as a tree of doubles instead of
+// sequentially (relative difference ~1e-15; it only enters the p-value).
+#include "kernels.h"
+
+namespace rsik {
+
+namespace {
+
+constexpr int kThreads = 256;
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+
+// ---- block-wide helpers (256 threads) --------------------------------------------------------
+template <class T, class Op>
+__device__ inline T block_reduce(T v, Op op, T* s_tmp /* kThreads/64 + 1 */) {
+  for (int d = 32; d >= 1; d >>= 1) v = op(v, __shfl_xor(v, d));
+  __syncthreads();
+  if (lane_id() == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T r = s_tmp[0];
+  for (int w = 1; w < kThreads / 64; ++w) r = op(r, s_tmp[w]);
+  __syncthreads();
+  return r;
+}
+// exclusive prefix of one int per thread; returns the thread's offset, *total = sum over the block
+__device__ inline int block_exscan(int v, int* s_tmp /* kThreads/64 */, int* total) {
+  int incl = v;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane_id() >= d) incl += up; }
+  __syncthreads();
+  if (lane_id() == 63) s_tmp[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kThreads / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) base += s_tmp[w]; tot += s_tmp[w]; }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+// exact int64 prefix of f(0..len-1) into P[0..len] (P[0] = 0): serial chunk per thread + scan of the totals
+template <class F>
+__device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f, long long* s_tot /* kThreads */) {
+  const int chunk = (len + kThreads - 1) / kThreads;
+  const int c0 = threadIdx.x * chunk;
+  long long run = 0;
+  for (int e = c0; e < c0 + chunk && e < len; ++e) run += f(e);
+  s_tot[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    long long carry = 0;
+    for (int k = 0; k < kThreads / 64; ++k) {
+      const long long mine = s_tot[k * 64 + threadIdx.x];
+      long long incl = mine;
+      for (int d = 1; d < 64; d <<= 1) { const long long up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
+      s_tot[k * 64 + threadIdx.x] = carry + incl - mine;
+      carry += __shfl(incl, 63);
+    }
+  }
+  __syncthreads();
+  run = s_tot[threadIdx.x];
+  if (threadIdx.x == 0) P[0] = 0;
+  for (int e = c0; e < c0 + chunk && e < len; ++e) { run += f(e); P[e + 1] = run; }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Boundary refinement, both passes (rsi.cpp:1876-1877 calls it twice).  dd[i] = sum of the len values
+// left of q = from+i minus the sum of the len values from q on; first maximum / minimum over the first
+// and the last 2*reach entries.  Arg-extremes keep the smallest index (the reference's strict >).
+struct ArgBest { long long v; int i; };
+__device__ inline ArgBest arg_pick(ArgBest a, ArgBest b, bool want_max) {
+  if (b.i < 0) return a;
+  if (a.i < 0) return b;
+  if (a.v != b.v) return (want_max ? (b.v > a.v) : (b.v < a.v)) ? b : a;
+  return b.i < a.i ? b : a;
+}
+
+__global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __restrict__ rdc, int64_t ncompact,
+                                                            EdgeJob* __restrict__ jobs, long long* __restrict__ scratch) {
+  __shared__ long long s_tot[kThreads];
+  __shared__ long long s_v[kThreads / 64];
+  __shared__ int s_i[kThreads / 64];
+  EdgeJob job = jobs[blockIdx.x];
+  long long* P = scratch + job.scratch_off;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int len = job.end - job.start + 1;
+    const int reach = len / 4 > 250 ? len / 4 : 250;
+    const int from = job.start - reach, to = job.end + reach;
+    if (job.type > 1) break;                  // untyped candidate: the reference moves nothing
+    if (from < 2 * len || (int64_t)to > ncompact - 2 * (int64_t)len) break;   // too close to the ends: unchanged (and so in pass 2)
+    const int base = from - len;              // prefix covers [from-len, to+len)
+    const int plen = (to - from) + 2 * len;
+    if (plen + 1 > job.scratch_len) break;    // cannot happen: the host sizes the scratch for both passes
+    block_prefix_i64(P, plen, [&](int e) { return (long long)rdc[base + e]; }, s_tot);
+    const int nstep = to - from, tail0 = nstep - 2 * reach;
+    const bool del = job.type == 0;
+    ArgBest lo{0, -1}, hi{0, -1};
+    for (int i = threadIdx.x; i < nstep; i += kThreads) {
+      const int q = from + i - base;          // prefix index of position from+i
+      const long long dd = (P[q] - P[q - len]) - (P[q + len] - P[q]);
+      if (i < 2 * reach && (del ? dd > 0 : dd < 0)) lo = arg_pick(lo, ArgBest{dd, i}, del);
+      if (i >= tail0 && (del ? dd < 0 : dd > 0)) hi = arg_pick(hi, ArgBest{dd, i}, !del);
+    }
+    // block arg-reduction (values first, then smallest index)
+    auto reduce = [&](ArgBest b, bool want_max) {
+      for (int d = 32; d >= 1; d >>= 1) { ArgBest o; o.v = __shfl_xor(b.v, d); o.i = __shfl_xor(b.i, d); b = arg_pick(b, o, want_max); }
+      __syncthreads();
+      if (lane_id() == 0) { s_v[threadIdx.x >> 6] = b.v; s_i[threadIdx.x >> 6] = b.i; }
+      __syncthreads();
+      ArgBest r{s_v[0], s_i[0]};
+      for (int w = 1; w < kThreads / 64; ++w) r = arg_pick(r, ArgBest{s_v[w], s_i[w]}, want_max);
+      __syncthreads();
+      return r;
+    };
+    lo = reduce(lo, del);
+    hi = reduce(hi, !del);
+    if (lo.i > 0) job.start = from + lo.i;
+    if (hi.i > 0) job.end = to - nstep + hi.i;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { jobs[blockIdx.x].start = job.start; jobs[blockIdx.x].end = job.end; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Neighbourhood test.  See CandJob in kernels.h for what the host prepares.
+constexpr int kWalkBlock = 4 * kThreads;   // positions examined per trip of a walk
+
+struct WalkShared { int s_scan[kThreads / 64]; int s_red[kThreads / 64 + 1]; };
+
+// One side of the reference gather (rsi.cpp:206-257).  dir = -1: left of the candidate, values land
+// in dst[fill], dst[fill-1], ...; dir = +1: right, values land in dst[used], dst[used+1], ...
+// Returns the number of values stored; *reach = last position examined.
+__device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int dir, int pos, int room /* slots left */,
+                                  int32_t* __restrict__ dst, int first_slot, const int2* __restrict__ chain, int nchain,
+                                  int kind, double too_high, double too_low, WalkShared& W, int* reach, int* chain_used) {
+  int stored = 0, ci = 0;
+  int last = pos;
+  while (room > 0 && (dir < 0 ? pos > 2 : (int64_t)pos < N - 2)) {
+    // positions of this trip in walk order: p_t = pos + dir*(1+t)
+    const int avail = dir < 0 ? pos - 2 : (int)(N - 2 - pos);     // how many positions the walk may still visit
+    const int cnt = avail < kWalkBlock ? avail : kWalkBlock;
+    const int2 cur = ci < nchain ? chain[ci] : make_int2(1, 0);   // empty interval when the chain is used up
+    int v[4]; bool acc[4]; int nacc = 0; int trig = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = 4 * threadIdx.x + j;
+      acc[j] = false; v[j] = 0;
+      if (t < cnt) {
+        const int p = pos + dir * (1 + t);
+        v[j] = A[p];
+        const bool ext = kind == 0 ? ((double)v[j] > too_high) : (kind == 1 ? ((double)v[j] < too_low) : false);
+        const bool inside = p >= cur.x && p <= cur.y;
+        if (!ext && inside && t < trig) trig = t;
+        acc[j] = !ext && !inside;
+      }
+    }
+    const int tstar = block_reduce(trig, [](int a, int b) { return a < b ? a : b; }, W.s_red);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (4 * (int)threadIdx.x + j >= tstar) acc[j] = false; nacc += acc[j]; }
+    int total;
+    int rank = block_exscan(nacc, W.s_scan, &total);
+    int my_last_t = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (acc[j]) {
+        if (rank < room) { dst[first_slot + dir * (stored + rank)] = v[j]; my_last_t = 4 * threadIdx.x + j; }
+        ++rank;
+      }
+    }
+    const int take = total < room ? total : room;
+    if (total >= room) {
+      // the walk stops right after the value that filled the last slot
+      const int tl = block_reduce(my_last_t, [](int a, int b) { return a > b ? a : b; }, W.s_red);
+      last = pos + dir * (1 + tl);
+      stored += take; room = 0;
+      break;
+    }
+    stored += take; room -= take;
+    if (tstar != 0x7fffffff) {      // jump over the neighbour (rsi.cpp:222-228 / 246-252)
+      last = pos + dir * (1 + tstar);
+      pos = dir < 0 ? cur.x - 1 : cur.y + 1;
+      ++ci;
+    } else {
+      pos += dir * cnt;
+      last = pos;
+    }
+  }
+  *reach = last;
+  *chain_used = ci;
+  return stored;
+}
+
+__global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __restrict__ A, int64_t N,
+                                                             const CandJob* __restrict__ jobs, const int2* __restrict__ chains,
+                                                             int32_t* __restrict__ iscratch, long long* __restrict__ lscratch,
+                                                             double RDmedian, CandOut* __restrict__ outs) {
+  extern __shared__ unsigned int s_hist[];   // kCandHistBins counters
+  __shared__ WalkShared W;
+  __shared__ long long s_tot[kThreads];
+  __shared__ double s_d[kThreads / 64 + 1];
+  __shared__ float s_f[kThreads / 64 + 1];
+  __shared__ long long s_l[kThreads / 64 + 1];
+  __shared__ int s_i2[kThreads / 64 + 1];
+  const CandJob J = jobs[blockIdx.x];
+  CandOut O;
+  O.flags = 0;
+  int32_t* left = iscratch + J.iscratch_off;              // J.top + 1 slots
+  int32_t* ref = left + (J.top + 1 > 0 ? J.top + 1 : 0);  // J.capacity slots
+  int32_t* thin = ref + J.capacity;                       // min(capacity, budget) slots
+  long long* P = lscratch + J.lscratch_off;               // capacity + 1
+  const double too_high = RDmedian * 3.0, too_low = RDmedian * 0.15;
+
+  // ---- gather: left side into left[top..], then ref = left part ++ right part ----
+  int lreach = J.start, rreach = J.end;
+  int lcnt = 0, lused = 0, rused = 0;
+  if (J.top >= 0)
+    lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
+  __syncthreads();
+  // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
+  const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
+  for (int j = threadIdx.x; j < used0; j += kThreads) ref[j] = left[J.top + 1 - used0 + j];
+  __syncthreads();
+  int room = J.capacity - used0;
+  {   // `used < 2*chklen*d` with the double right-hand side (rsi.cpp:243)
+    const int lim = (int)ceil(J.right_cap);
+    if (lim - used0 < room) room = lim - used0;
+    if (room < 0) room = 0;
+  }
+  const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, ref, used0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused);
+  __syncthreads();
+  // a chain the host cut short was consumed to its end: the walk may have missed a neighbour
+  if (((J.cut & 1) && lused >= J.nleft) || ((J.cut & 2) && rused >= J.nright)) O.flags |= 8;
+  int nref = used0 + rcnt;
+  int nbody = J.end - J.start + 1;
+  // ---- thinning to about `budget` points (rsi.cpp:264-282) ----
+  const int32_t* R = ref;
+  int body_len = nbody;       // source length of the body
+  bool thin_body = false;
+  int nbody_eff = nbody;
+  if (nref + nbody > J.budget) {
+    const int total = nref + nbody;
+    const int tref = (int)((double)nref / (double)total * (double)J.budget);
+    const int tbody = (int)((double)nbody / (double)total * (double)J.budget);
+    for (int q = threadIdx.x; q < tref; q += kThreads) thin[q] = ref[(int)((double)q / (double)tref * (double)nref)];
+    __syncthreads();
+    R = thin; nref = tref; thin_body = true; nbody_eff = tbody;
+  }
+  auto body_at = [&](int q) -> int {
+    return thin_body ? A[J.start + (int)((double)q / (double)nbody_eff * (double)body_len)] : A[J.start + q];
+  };
+  const int width = nbody_eff;
+  const int nwin = nref - width;
+  O.nref = nref; O.nbody = nbody_eff; O.nwin = nwin; O.left_reach = lreach; O.right_reach = rreach;
+  if (nwin <= 0 || width <= 0) { O.flags |= 1; if (threadIdx.x == 0) outs[blockIdx.x] = O; return; }
+
+  // ---- body statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
+  {
+    int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
+    for (int q = threadIdx.x; q < width; q += kThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
+    lo = block_reduce(lo, [](int a, int b) { return a < b ? a : b; }, s_i2);
+    hi = block_reduce(hi, [](int a, int b) { return a > b ? a : b; }, s_i2);
+    s1 = block_reduce(s1, [](long long a, long long b) { return a + b; }, s_l);
+    s2 = block_reduce(s2, [](long long a, long long b) { return a + b; }, s_l);
+    O.body_min = lo; O.body_max = hi; O.body_s1 = (double)s1; O.body_s2 = (double)s2;
+    O.body_q[0] = lo; O.body_q[1] = (double)s1 / (double)width; O.body_q[2] = hi;
+    if ((double)hi - (double)lo >= 1.0) {
+      const unsigned nbk = (unsigned)(hi - lo) + 2;
+      if (nbk > kCandHistBins) O.flags |= 2;
+      else {
+        for (unsigned e = threadIdx.x; e < nbk; e += kThreads) s_hist[e] = 0;
+        __syncthreads();
+        for (int q = threadIdx.x; q < width; q += kThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const size_t n = (size_t)width, r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
+          size_t seen = 0;
+          for (unsigned b = 0; b < nbk; ++b) {
+            const size_t upto = seen + s_hist[b];
+            if (seen < r1 && upto >= r1) O.body_q[0] = (double)lo + b * 1.0;
+            if (seen < r2 && upto >= r2) O.body_q[1] = (double)lo + b * 1.0;
+            if (seen < r3 && upto >= r3) O.body_q[2] = (double)lo + b * 1.0;
+            seen = upto;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // ---- running mean of width `width` over the neighbourhood (rsi.cpp:113-124): exact prefix, float means ----
+  block_prefix_i64(P, nref, [&](int e) { return (long long)R[e]; }, s_tot);
+  const double dw = (double)width;
+  auto wmean = [&](int i) -> float { return (float)((double)(P[i + width] - P[i]) / dw); };
+  {
+    float flo = 3.0e38f, fhi = -3.0e38f; double m1 = 0, m2 = 0;
+    for (int i = threadIdx.x; i < nwin; i += kThreads) { const float w = wmean(i); flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w; }
+    flo = block_reduce(flo, [](float a, float b) { return a < b ? a : b; }, s_f);
+    fhi = block_reduce(fhi, [](float a, float b) { return a > b ? a : b; }, s_f);
+    m1 = block_reduce(m1, [](double a, double b) { return a + b; }, s_d);
+    m2 = block_reduce(m2, [](double a, double b) { return a + b; }, s_d);
+    const double lo = flo, hi = fhi;
+    O.ref_s1 = m1; O.ref_s2 = m2;
+    O.ref_q[0] = lo; O.ref_q[1] = m1 / (double)nwin; O.ref_q[2] = hi;
+    if ((hi - lo) >= 0.01) {
+      const size_t nbk = (size_t)((hi - lo) / 0.01 + 2);
+      if (nbk > kCandHistBins) O.flags |= 4;
+      else {
+        for (unsigned e = threadIdx.x; e < nbk; e += kThreads) s_hist[e] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nwin; i += kThreads) {
+          const double idx = ((double)wmean(i) - lo) / 0.01 + 0.5;   // wufunctions.cpp:396
+          atomicAdd(&s_hist[(unsigned)(unsigned long long)idx], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const size_t n = (size_t)nwin, r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
+          size_t seen = 0;
+          for (size_t b = 0; b < nbk; ++b) {
+            const size_t upto = seen + s_hist[b];
+            if (seen < r1 && upto >= r1) O.ref_q[0] = lo + b * 0.01;
+            if (seen < r2 && upto >= r2) O.ref_q[1] = lo + b * 0.01;
+            if (seen < r3 && upto >= r3) O.ref_q[2] = lo + b * 0.01;
+            seen = upto;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (threadIdx.x == 0) outs[blockIdx.x] = O;
+}
+
+// Sums of depth over inclusive ranges (mean_tp of mergesegments, rsi.cpp:775-779): exact integers.
+__global__ __launch_bounds__(kThreads) void k_range_sums(const int32_t* __restrict__ A, const int2* __restrict__ ranges,
+                                                         long long* __restrict__ sums) {
+  __shared__ long long s_l[kThreads / 64 + 1];
+  const int2 r = ranges[blockIdx.x];
+  long long acc = 0;
+  for (int p = r.x + (int)threadIdx.x; p <= r.y; p += kThreads) acc += A[p];
+  acc = block_reduce(acc, [](long long a, long long b) { return a + b; }, s_l);
+  if (threadIdx.x == 0) sums[blockIdx.x] = acc;
+}
+
+}  // namespace
+
+void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long long* sums, hipStream_t stream) {
+  if (nranges <= 0) return;
+  hipLaunchKernelGGL(k_range_sums, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums);
+}
+
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* scratch, hipStream_t stream) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_sharpen_edges, dim3(njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, scratch);
+}
+void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+                           int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream) {
+  if (njobs <= 0) return;
+  const size_t lds = (size_t)kCandHistBins * 4;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_candidate_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(k_candidate_test, dim3(njobs), dim3(kThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch,
+                     lscratch, RDmedian, outs);
+}
+
+}  // namespace rsik

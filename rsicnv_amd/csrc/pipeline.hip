@@ -33,6 +33,12 @@ std::string g_last_error;   // last failure of any context (diagnostic; guarded 
 std::mutex g_err_mu;
 void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_last_error = m; }
 
+// Growth hint of the running thread: (largest chromosome its pool has been handed) / (this one).
+// A buffer that has to grow is sized for the largest chromosome right away, so that after a
+// worker's first chromosome no hipFree/hipMalloc -- a device-wide synchronisation that stalls every
+// other worker, and slow on recycled VRAM -- happens in steady state.
+thread_local double tl_grow = 1.0;
+
 struct DevBuf {   // grow-only device allocation
   void* p = nullptr;
   size_t cap = 0;
@@ -40,7 +46,8 @@ struct DevBuf {   // grow-only device allocation
     if (bytes <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
-    const size_t want = bytes + bytes / 8 + 256;
+    const size_t scaled = (size_t)((double)bytes * tl_grow);
+    const size_t want = scaled + scaled / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -93,6 +100,7 @@ struct rsi_ctx {
   DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del, first_dup;
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
+  DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64;   // candidate tests on the device (kernels_cand.hip)
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
   bool have_gc = false, have_nb = false, have_med = false;
@@ -100,9 +108,12 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
+  std::vector<float> h_T;     // host copies of the bin arrays for filterstatus, grow-only
+  std::vector<int> h_status;
   int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
+  int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
   bool gate_shared = true;    // bin-level kernels wait while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=0 disables)
 };
 
@@ -288,6 +299,147 @@ int upload_runs(rsi_ctx* ctx, const std::vector<Region>& runs, int32_t** d_start
   return RSI_OK;
 }
 
+// Candidate stages on the device: uploads the host-prepared jobs, launches one workgroup per job,
+// returns the statistics.  Jobs are grouped so that one launch's scratch stays below kCandScratchBytes.
+constexpr size_t kCandScratchBytes = size_t(512) << 20;
+class DeviceTester : public rsih::NeighbourTester {
+ public:
+  DeviceTester(rsi_ctx* c, const int32_t* rdc, int64_t n, double RDmedian) : ctx(c), d_rdc(rdc), N(n), median(RDmedian) {}
+  double kernel_wait_ms = 0;
+  int launches = 0;
+
+  bool sharpen(std::vector<Candidate>& L) override {
+    if (L.empty()) return true;
+    std::vector<EdgeJob> jobs(L.size());
+    size_t words = 0;
+    for (size_t i = 0; i < L.size(); ++i) {
+      const int64_t len = (int64_t)L[i].end - L[i].start + 1;
+      const int64_t grown = len + 2 * std::max<int64_t>(250, len / 4);        // the second pass may see this length
+      const int64_t need = 3 * grown + 2 * std::max<int64_t>(250, grown / 4) + 8;
+      jobs[i] = {L[i].start, L[i].end, L[i].type, (int32_t)std::min<int64_t>(need, INT32_MAX), (int64_t)words};
+      words += (size_t)need;
+    }
+    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(words * 8))) return false; }
+    GateShared gs(ctx);
+    Phase ph(ctx, "cand.sharpen");
+    if (!ok(hipMemcpyAsync(ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob), hipMemcpyHostToDevice, ctx->stream))) return false;
+    { Timer t(ctx, "sharpen_edges"); launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), (int)jobs.size(), ctx->cand_i64.as<long long>(), ctx->stream); }
+    if (!ok(hipMemcpyAsync(jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob), hipMemcpyDeviceToHost, ctx->stream))) return false;
+    if (!wait()) return false;
+    gs.release();
+    for (size_t i = 0; i < L.size(); ++i) { L[i].start = jobs[i].start; L[i].end = jobs[i].end; }
+    return true;
+  }
+
+  bool test(const std::vector<rsih::TestPlan>& plans, std::vector<rsih::TestStats>& stats, std::vector<int>& left_reach,
+            std::vector<char>& okv) override {
+    const size_t n = plans.size();
+    stats.assign(n, rsih::TestStats{});
+    left_reach.assign(n, 0);
+    okv.assign(n, 0);
+    size_t first = 0;
+    while (first < n) {
+      std::vector<CandJob> jobs;
+      std::vector<int32_t> chains;   // (start, end) pairs
+      size_t iwords = 0, lwords = 0, last = first;
+      for (; last < n; ++last) {
+        const rsih::TestPlan& T = plans[last];
+        if (T.capacity <= 0 || T.end < T.start || T.start < 0 || T.end >= N) break;   // left to the host path (ok stays 0)
+        const size_t iw = (size_t)std::max(T.top + 1, 0) + (size_t)T.capacity + (size_t)std::min(T.capacity, T.budget);
+        const size_t lw = (size_t)T.capacity + 1;
+        if (!jobs.empty() && (iwords + iw) * 4 + (lwords + lw) * 8 > kCandScratchBytes) break;
+        CandJob J{};
+        J.start = T.start; J.end = T.end; J.kind = T.kind; J.margin = T.margin; J.capacity = T.capacity; J.top = T.top;
+        J.nleft = (int)T.left_chain.size(); J.nright = (int)T.right_chain.size();
+        J.left_off = (int)(chains.size() / 2);
+        for (const auto& iv : T.left_chain) { chains.push_back(iv.first); chains.push_back(iv.second); }
+        J.right_off = (int)(chains.size() / 2);
+        for (const auto& iv : T.right_chain) { chains.push_back(iv.first); chains.push_back(iv.second); }
+        J.budget = T.budget; J.cut = T.cut; J.right_cap = T.right_cap;
+        J.iscratch_off = (int64_t)iwords; J.lscratch_off = (int64_t)lwords;
+        iwords += iw; lwords += lw;
+        jobs.push_back(J);
+      }
+      if (jobs.empty()) { ++first; continue; }   // plans[first] was declined
+      chains.push_back(0); chains.push_back(0);  // never an empty upload
+      std::vector<CandOut> outs(jobs.size());
+      {
+        Phase ph(ctx, "cand.ensure");
+        if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(CandJob))) || !ok(ctx->cand_chains.ensure(chains.size() * 4)) ||
+            !ok(ctx->cand_outs.ensure(outs.size() * sizeof(CandOut))) || !ok(ctx->cand_i32.ensure(iwords * 4)) ||
+            !ok(ctx->cand_i64.ensure(lwords * 8)))
+          return false;
+      }
+      GateShared gs(ctx);
+      Phase ph(ctx, "cand.test");
+      if (!ok(hipMemcpyAsync(ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(CandJob), hipMemcpyHostToDevice, ctx->stream))) return false;
+      if (!ok(hipMemcpyAsync(ctx->cand_chains.p, chains.data(), chains.size() * 4, hipMemcpyHostToDevice, ctx->stream))) return false;
+      {
+        Timer t(ctx, "candidate_test");
+        launch_candidate_test(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
+                              ctx->cand_i64.as<long long>(), median, ctx->cand_outs.as<CandOut>(), ctx->stream);
+      }
+      if (!ok(hipMemcpyAsync(outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut), hipMemcpyDeviceToHost, ctx->stream))) return false;
+      if (!wait()) return false;
+      gs.release();
+      ph.stop();
+      for (size_t k = 0; k < jobs.size(); ++k) {
+        const CandOut& O = outs[k];
+        if (O.flags != 0) continue;
+        rsih::TestStats& S = stats[first + k];
+        const double nb = (double)O.nbody, nw = (double)O.nwin;
+        S.cnv_lqt = O.body_q[0]; S.cnv_med = O.body_q[1]; S.cnv_uqt = O.body_q[2];
+        { const double mu = O.body_s1 / nb; S.cnv_var = O.body_s2 / nb - mu * mu; }     // variancetp, wufunctions.cpp:766-809
+        S.ref_lqt = O.ref_q[0]; S.ref_med = O.ref_q[1]; S.ref_uqt = O.ref_q[2];
+        { const double mu = O.ref_s1 / nw; S.ref_var = O.ref_s2 / nw - mu * mu; }
+        left_reach[first + k] = O.left_reach;
+        okv[first + k] = 1;
+      }
+      first += jobs.size();
+    }
+    return true;
+  }
+
+  bool range_sums(const std::vector<std::pair<int, int>>& ranges, std::vector<int64_t>& sums) override {
+    sums.assign(ranges.size(), 0);
+    if (ranges.empty()) return true;
+    std::vector<int32_t> flat;
+    for (const auto& r : ranges) {
+      if (r.first < 0 || r.second >= N || r.second < r.first) return false;
+      flat.push_back(r.first); flat.push_back(r.second);
+    }
+    if (!ok(ctx->cand_chains.ensure(flat.size() * 4)) || !ok(ctx->cand_outs.ensure(ranges.size() * 8))) return false;
+    if (!ok(hipMemcpyAsync(ctx->cand_chains.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream))) return false;
+    GateShared gs(ctx);
+    { Timer t(ctx, "range_sums"); launch_range_sums(d_rdc, ctx->cand_chains.p, (int)ranges.size(), ctx->cand_outs.as<long long>(), ctx->stream); }
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+    if (!ok(hipMemcpyAsync(sums.data(), ctx->cand_outs.p, ranges.size() * 8, hipMemcpyDeviceToHost, ctx->stream))) return false;
+    return wait();
+  }
+
+ private:
+  rsi_ctx* ctx;
+  const int32_t* d_rdc;
+  int64_t N;
+  double median;
+  bool ok(hipError_t e) {
+    if (e == hipSuccess) return true;
+    ctx->err = std::string("candidate stage: ") + hipGetErrorString(e);
+    set_global_error(ctx->err);
+    failed = true;
+    return false;
+  }
+  bool wait() {
+    const double t0 = now_ms();
+    const bool r = ok(stream_wait(ctx->stream, ctx->sync_ev));
+    kernel_wait_ms += now_ms() - t0;
+    ++launches;
+    return r;
+  }
+ public:
+  bool failed = false;
+};
+
 // One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status
 int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
               double tlamda, int Lmax, int32_t* d_status, uint32_t* escapes, uint32_t* inexact) {
@@ -385,8 +537,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
   // definition (App. A Q13) -> host; the edge trimming runs on the device, one thread per run ----
-  std::vector<float> hT((size_t)nb);
-  std::vector<int> hst((size_t)nb);
+  std::vector<float>& hT = ctx->h_T;       // context-owned: no 20 MB of fresh pages per chromosome
+  std::vector<int>& hst = ctx->h_status;
+  if (hT.size() < (size_t)nb) { hT.resize((size_t)((double)nb * tl_grow) + 16); hst.resize(hT.size()); }
   HIPCHK(hipMemcpyAsync(hT.data(), d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(hst.data(), d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -515,6 +668,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->ktimes.clear();
   ctx->event_next = 0;
   ctx->phases.clear();
+  tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
   // The per-base kernels are HBM-bound: workers of a pool take turns through this phase (GpuGate).
   struct StreamTurn {
     GpuGate* g = nullptr;
@@ -788,19 +942,33 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
       if ((rc = do_scan(false, more)) != RSI_OK) return rc;
       tested.insert(tested.end(), more.begin(), more.end());
     }
-    if (ctx->mirror_cap < (size_t)ncompact) {   // grow-only pinned host mirror: transfers land in it directly
-      if (ctx->mirror) (void)hipHostFree(ctx->mirror);
-      ctx->mirror = nullptr;
-      ctx->mirror_cap = (size_t)ncompact + (size_t)ncompact / 8 + 1024;
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mirror), ctx->mirror_cap * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
-        ctx->mirror = nullptr; ctx->mirror_cap = 0;
-        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the depth mirror");
+    auto mirror_source = [ctx, ncompact]() -> int32_t* {   // grow-only pinned host mirror: transfers land in it directly
+      if (ctx->mirror_cap < (size_t)ncompact) {
+        if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+        ctx->mirror = nullptr;
+        ctx->mirror_cap = (size_t)ncompact + (size_t)ncompact / 8 + 1024;
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mirror), ctx->mirror_cap * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+          ctx->mirror = nullptr; ctx->mirror_cap = 0;
+        }
       }
-    }
-    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, ctx->mirror, nullptr, 0, ctx->sync_ev);
+      return ctx->mirror;
+    };
+    rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, mirror_source, nullptr, 0, ctx->sync_ev);
     rsih::CallProfile prof;
     in.prof = &prof;
+    DeviceTester tester(ctx, ctx->rdc.as<int32_t>(), ncompact, RDmedian);
+    const char* host_env = getenv("RSI_HOT_HOST_CANDIDATES");   // debugging switch: candidate stages on the host
+    const bool host_tests = host_env && atoi(host_env) != 0;
+    in.tester = host_tests ? nullptr : &tester;
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
+    if (tester.failed) return RSI_ERR_HIP;
+    ctx->phases.push_back({"calls.device(wait)", tester.kernel_wait_ms});
+    ctx->phases.push_back({"calls.device_ms", prof.device_ms});
+    ctx->phases.push_back({"calls.final", prof.final_tests});
+    ctx->phases.push_back({"calls.launches", (double)tester.launches});
+    ctx->phases.push_back({"calls.spec_hits", (double)prof.spec_hits});
+    ctx->phases.push_back({"calls.single_tests", (double)prof.single_tests});
+    ctx->phases.push_back({"calls.host_fallbacks", (double)prof.host_fallbacks});
     ctx->phases.push_back({"calls.fetch", pager.fetch_ms()});
     ctx->phases.push_back({"calls.gather(incl fetch)", prof.gather});
     ctx->phases.push_back({"calls.winmean", prof.winmean});
@@ -1027,12 +1195,20 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
   if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
   std::vector<int> order((size_t)nchrom);
   for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
+  {
+    int64_t largest = 0;
+    for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
+    for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
+  }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
   std::atomic<int> next(0);
   std::vector<int> rcs((size_t)nchrom, RSI_OK);
   std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
   std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
   std::vector<std::vector<int64_t>> kbases(pool->workers.size());
+  static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
+  const double t_run0 = now_ms();
+  std::mutex trace_mu;
   auto work = [&](size_t w) {
     rsi_ctx* ctx = pool->workers[w];
     for (;;) {
@@ -1040,7 +1216,14 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
       if (k >= nchrom) break;
       const int i = order[(size_t)k];
       out[i] = nullptr;
+      const double t_a = now_ms();
       rcs[(size_t)i] = rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
+      if (trace) {
+        std::lock_guard<std::mutex> lk(trace_mu);
+        fprintf(stderr, "[trace] worker %zu chrom %d n %lld start %.2f end %.2f :", w, i, (long long)n[i], t_a - t_run0, now_ms() - t_run0);
+        for (const auto& ph : ctx->phases) fprintf(stderr, " %s=%.2f", ph.first, ph.second);
+        fprintf(stderr, "\n");
+      }
       if (times) {
         for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); ktimes[w].push_back({t.name, ms}); kbases[w].push_back(n[i]); }
         for (const auto& ph : ctx->phases) ptimes[w].push_back(ph);
