@@ -94,11 +94,13 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
 struct ScanParams {
   int64_t nb;
   int32_t Lmax;
-  int32_t pad;
+  int16_t pad;
+  int16_t kcap;      // set by launch_rsi_scan: highest block level of the mark tables
   double tmedian;
   double lim_del;    // 0.75 * RDmedian
   double lim_dup;    // 1.25 * RDmedian
 };
+constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable entries (-inf / +inf) after index Lmax
 // thr_del[L], thr_dup[L] (L = 1..Lmax, index L): a window of length L is a DEL hit iff
 // sum <= thr_del[L], a DUP hit iff sum >= thr_dup[L] (host-derived, see scan_thresholds()).
 // first_del / first_dup: smallest L that marks the bin, 0xffffffff when none.  counters[0] = trim

@@ -141,87 +141,212 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// K7  RSI scan.  One workgroup per tile of kScanTile bins (one per thread).  The tile plus a halo of Lmax/2+1 bins
-// each side is staged in LDS: an exact double prefix of the transformed values (so the window sum
-// for any (bin, L) is one subtraction), the values and bin medians themselves for the trim walks,
-// and two integer prefixes that turn the exact window-median test into a count difference.  The
-// per-L score test is folded on the host into a threshold on the window sum (hit iff
-// sum <= thr_del[L] / sum >= thr_dup[L]).  Every lane owns a bin and walks L = 1..Lmax; a hit marks
-// its trimmed interval with atomicMin(L) in LDS ("smallest L wins", App. A Q14) and the tile's
-// marks are merged into HBM at the end.  Nothing in the hit path leaves LDS.
+// K7  RSI scan.  One workgroup per tile of kScanTile bins (one per thread).  The tile plus a halo of
+// Lmax/2+1 bins each side is staged in LDS as prefix arrays only:
+//   P    exact double prefix of the transformed values: the window sum of any (bin, L) is one subtraction;
+//   CL/CG   counts of bins with median <= floor(0.75 RDmedian) / >= ceil(1.25 RDmedian): the exact
+//        window-median test is a count difference (the two middle elements are needed only when the
+//        count is exactly L/2; M keeps the medians for that case);
+//   CTd/CTu counts of bins with value <= tmedian / >= tmedian;
+//   R*   for each of the four predicates, the staged position of its r-th true bin, so that "next
+//        (previous) bin from x where the predicate holds" -- which is what each of the reference's four
+//        trim walks computes (rsi.cpp:1211-1214 / 1241-1244) -- is R[C[x]] (R[C[x+1]-1]): O(1).
+// The per-L score test is folded on the host into a threshold on the window sum (hit iff
+// sum <= thr_del[L] / sum >= thr_dup[L]).  Every lane owns a bin and walks L = 1..Lmax.  A hit marks
+// its trimmed interval [i1,i2] with "smallest L wins" (App. A Q14): instead of touching every bin
+// it drops L with atomicMin on the one or two power-of-two blocks that cover the interval (level k =
+// floor(log2(length)), capped at kcap, then ceil(length/2^kcap) blocks); after the sweep the levels
+// are pushed down to level 0 in kcap steps and the tile's marks are merged into HBM.  A hit costs a
+// dozen LDS operations whatever its length; nothing in the hit path leaves LDS.
 constexpr int kScanTile = 256;    // one bin per lane: the tile's critical path is one lane's walk over L
 constexpr uint32_t kUnmarked = 0xffffffffu;
 
-struct ScanLds {
+struct ScanLds {     // plain base pointers and one stride: nothing here is indexed at run time, so it stays in registers
   double* P;        // count + 1
-  double* tdel;     // Lmax + 1
-  double* tdup;     // Lmax + 1
   double* tot;      // kThreads
-  float* T;         // count
-  int* M;           // count
-  int* CL;          // count + 1: # staged bins before e with medint <= floor(lim_del)
-  int* CG;          // count + 1: # staged bins before e with medint >= ceil(lim_dup)
-  uint32_t* FD;     // count
-  uint32_t* FU;     // count
+  uint32_t* TB;     // mark levels: [DEL, DUP][kcap + 1 levels][count]
+  int* M;           // count: bin medians (the rare straddling median test reads the window)
+  uint16_t* CB;     // four prefix-count arrays CL, CG, CTd, CTu, `stride` apart (count + 1 used)
+  uint16_t* RB;     // four position-by-rank arrays, `stride` apart
+  uint16_t* PF;     // count: predicate bits of each staged bin (bit q = predicate q)
+  int stride;       // count + 2
+  int count, kcap;
+  __device__ uint16_t& C(int q, int x) const { return CB[q * stride + x]; }
+  __device__ uint16_t& R(int q, int r) const { return RB[q * stride + r]; }
+  __device__ uint32_t* level(int side, int k) const { return TB + ((size_t)side * (kcap + 1) + k) * count; }
 };
+enum { kCL = 0, kCG = 1, kCTd = 2, kCTu = 3 };
 
-// One sweep's hit for the lane's window [w0, w0+L-1] (staged indices).  DEL: is_del = true.
-// vlo/vhi: staged indices inside the chromosome are [vlo, vhi).  Returns the updated "largest mark
-// in the window" (see the skip rule in the caller).
-__device__ inline uint32_t lane_hit(const ScanLds& S, int w0, int L, bool is_del, int thr_int, double lim, double tmed,
-                                    int vlo, int vhi, bool at_start, bool at_end, uint32_t* F, uint32_t* counters) {
-  const int* C = is_del ? S.CL : S.CG;
-  const int c = C[w0 + L] - C[w0];
-  bool pass;
-  if (L & 1) {
-    pass = c >= (L + 1) / 2;                       // middle order statistic on the right side of the limit
-  } else {
-    const int hh = L / 2;
-    if (c >= hh + 1) pass = true;
-    else if (c <= hh - 1) pass = false;
-    else {                                         // the two middle elements straddle the limit: need their values
-      int a, b;
-      if (is_del) {                                // a = max{x <= thr}, b = min{x > thr}
-        a = (int)0x80000000; b = 0x7fffffff;
-        for (int j = w0; j < w0 + L; ++j) { const int x = S.M[j]; if (x <= thr_int) a = x > a ? x : a; else b = x < b ? x : b; }
-        pass = !(0.5 * ((double)a + (double)b) > lim);          // rsi.cpp:1206
-      } else {                                     // a = max{x < thr}, b = min{x >= thr}
-        a = (int)0x80000000; b = 0x7fffffff;
-        for (int j = w0; j < w0 + L; ++j) { const int x = S.M[j]; if (x >= thr_int) b = x < b ? x : b; else a = x > a ? x : a; }
-        pass = !(0.5 * ((double)a + (double)b) < lim);          // rsi.cpp:1236
-      }
-    }
-  }
-  if (!pass) return kUnmarked;   // no marks from this hit, and no knowledge of the window's marks
-  uint32_t wmax = 0;
-  // trim walks in the reference's order (rsi.cpp:1211-1214 / 1241-1244), bounded to the chromosome
-  int i1 = w0, i2 = w0 + L - 1;
-  if (is_del) {
-    while (i1 < vhi && (double)S.T[i1] > tmed) ++i1;
-    while (i1 < vhi && S.M[i1] > thr_int) ++i1;
-    while (i2 >= vlo && (double)S.T[i2] > tmed) --i2;
-    while (i2 >= vlo && S.M[i2] > thr_int) --i2;
-  } else {
-    while (i1 < vhi && (double)S.T[i1] < tmed) ++i1;
-    while (i1 < vhi && S.M[i1] < thr_int) ++i1;
-    while (i2 >= vlo && (double)S.T[i2] < tmed) --i2;
-    while (i2 >= vlo && S.M[i2] < thr_int) --i2;
-  }
+__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap) {
+  size_t b = ((size_t)(count + 1) + kThreads) * sizeof(double);
+  b += 2 * (size_t)(kcap + 1) * count * 4 + (size_t)count * 4;
+  b += 9 * (size_t)(count + 2) * 2;
+  return b;
+}
+__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap) {
+  S.count = count; S.kcap = kcap; S.stride = count + 2;
+  S.P = sm;
+  S.tot = S.P + count + 1;
+  S.TB = reinterpret_cast<uint32_t*>(S.tot + kThreads);
+  S.M = reinterpret_cast<int*>(S.TB + 2 * (size_t)(kcap + 1) * count);
+  S.CB = reinterpret_cast<uint16_t*>(S.M + count);
+  S.RB = S.CB + 4 * S.stride;
+  S.PF = S.RB + 4 * S.stride;
+}
+
+// first staged position >= x where predicate q holds, vhi when none; last position <= x, vlo-1 when none
+__device__ inline int scan_next(const ScanLds& S, int q, int x, int vhi) {
+  const int r = S.C(q, x);
+  return r < (int)S.C(q, S.count) ? (int)S.R(q, r) : vhi;
+}
+__device__ inline int scan_prev(const ScanLds& S, int q, int x, int vlo) {
+  const int r = S.C(q, x + 1);
+  return r > 0 ? (int)S.R(q, r - 1) : vlo - 1;
+}
+
+__device__ inline void scan_mark(const ScanLds& S, int side, int lo, int hi, int L) {
+  const int len = hi - lo + 1;
+  int k = 31 - __clz(len);
+  k = k > S.kcap ? S.kcap : k;
+  const int step = 1 << k;
+  uint32_t* tab = S.level(side, k);
+  for (int a = lo; a + step - 1 < hi; a += step) atomicMin(&tab[a], (uint32_t)L);
+  atomicMin(&tab[hi - step + 1], (uint32_t)L);
+}
+
+// Trim walks and marks of one hit that passed the median test, for the window [w0, w0+L-1] (staged
+// indices), when the lane has no run to continue (see scan_sweep).  side 0 = DEL, 1 = DUP; vlo/vhi:
+// staged indices inside the chromosome are [vlo, vhi); ends: bit 0 = the tile touches the chromosome
+// start, bit 1 = its end.  Returns i1 | i2 << 12 (the trimmed interval, possibly empty), or -1 when a
+// walk left the staged range.  Out of line: it is the rare case; it finds the tile's LDS through the
+// kernel's dynamic LDS symbol, so every access stays an LDS access.
+__device__ __noinline__ int scan_hit_slow(int count, int kcap, int w0, int L, int side, int vlo, int vhi, int ends,
+                                          uint32_t* counters) {
+  extern __shared__ __align__(16) double sm[];
+  ScanLds S;
+  scan_lds_carve(S, sm, count, kcap);
+  const int qm = side ? kCG : kCL, qt = side ? kCTu : kCTd;
+  // the four trim walks in the reference's order (rsi.cpp:1211-1214 / 1241-1244), bounded to the chromosome
+  int i1 = scan_next(S, qt, w0, vhi);
+  i1 = scan_next(S, qm, i1, vhi);
+  int i2 = scan_prev(S, qt, w0 + L - 1, vlo);
+  i2 = scan_prev(S, qm, i2, vlo);
   if (i1 >= vhi || i2 < vlo) {
     // left the staged range: the marked interval is empty either way.  Leaving the chromosome
     // itself is where the reference aborts (App. A Q12): count those.
-    if ((i1 >= vhi && at_end) || (i2 < vlo && at_start)) atomicAdd(&counters[0], 1u);
-    i1 = 1; i2 = 0;
+    if ((i1 >= vhi && (ends & 2)) || (i2 < vlo && (ends & 1))) atomicAdd(&counters[0], 1u);
+    return -1;
   }
-  // mark the trimmed interval; the window's largest mark is only worth knowing when the interval
-  // covers the whole window (otherwise the untouched rest keeps the lane from skipping anyway)
-  const bool full = i1 == w0 && i2 == w0 + L - 1;
-  for (int j = i1; j <= i2; ++j) {
-    uint32_t v = F[j];
-    if (v > (uint32_t)L) { atomicMin(&F[j], (uint32_t)L); v = (uint32_t)L; }
-    wmax = v > wmax ? v : wmax;
+  if (i1 <= i2) scan_mark(S, side, i1, i2, L);
+  return i1 | (i2 << 12);
+}
+
+struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; };
+
+// One lane's walk over L = 1..Lmax in groups of kScanPad (8): the eight prefix values a group needs
+// are independent LDS reads issued together, the sixteen thresholds are wave-uniform (scalar)
+// loads, so a group costs one memory latency instead of one per L.  Going from L-1 to L the window
+// gains one bin -- on the left for even L, on the right for odd L -- so one prefix value per step
+// is new.  The score tests of a group set bits; the (rare) set bits are then handled in a rolled
+// loop, in increasing L per side.  EDGE: some lanes stop before Lmax (chromosome ends).
+//
+// Hits come in runs: a bin inside an event hits at every L once its window is long enough, and
+// apart from those runs hits are rare (0.5 % of the (bin, L) pairs of a 30x genome, in 0.5 % of the
+// waves).  The lane therefore keeps, per side:
+//  * ScanRun: the trimmed interval [i1, i2] of its last hit and that hit's L.  When the next hit
+//    comes at L+1 the window has gained one bin g; the walk on the other side ends where it did, and
+//    on the side of g:
+//      value and median predicate hold at g   -> the interval now ends at g;
+//      the value predicate fails at g         -> the walk passes over g exactly as before: same end;
+//      only the median predicate fails at g   -> the end is the nearest median-predicate bin beyond g
+//                                                (one rank lookup; never inside the old interval).
+//    The interval only grows, its old part already carries marks <= L, so only the new bins get L.
+//    Without a run to continue the hit goes through scan_hit_slow.
+//  * ScanMid: for the exact median test when the count says the two middle elements straddle the
+//    limit (even L, exactly L/2 bins beyond it): a = the largest median on the near side, b = the
+//    smallest on the far side, over the window of length `upto`.  The lane's windows are nested, so
+//    the pair is extended by the bins gained since (a bin on an event's edge straddles at every even
+//    L: two reads per step instead of L).
+struct ScanRun { int lastL, i1, i2; };
+struct ScanMid { int upto, a, b; };
+
+template <bool EDGE>
+__device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const double* __restrict__ thr_del,
+                                  const double* __restrict__ thr_dup, int relc, int Lmax, int Lend, uint32_t* counters) {
+  double p_lo = S.P[relc], p_hi = 0.0;
+  ScanRun run_del = {-1, 0, 0}, run_dup = {-1, 0, 0};
+  ScanMid mid_del = {0, (int)0x80000000, 0x7fffffff}, mid_dup = {0, (int)0x80000000, 0x7fffffff};
+  for (int L0 = 1; L0 <= Lmax; L0 += kScanPad) {
+    double pv[kScanPad], td[kScanPad], tu[kScanPad];
+#pragma unroll
+    for (int u = 0; u < kScanPad; ++u) {
+      int L = L0 + u;
+      L = L > Lmax ? Lmax : L;                      // past Lmax the thresholds are unreachable; just stay in range
+      const int h = L >> 1;
+      pv[u] = S.P[(u & 1) ? relc - h : relc + h + 1];   // L0 is odd: odd u <=> even L <=> the window grew on the left
+      td[u] = thr_del[L0 + u];
+      tu[u] = thr_dup[L0 + u];
+    }
+    unsigned hits = 0;   // bit u: DEL score hit at L0+u, bit 8+u: DUP
+#pragma unroll
+    for (int u = 0; u < kScanPad; ++u) {
+      if (u & 1) p_lo = pv[u]; else p_hi = pv[u];
+      const double sum = p_hi - p_lo;
+      bool hd = sum <= td[u], hu = sum >= tu[u];
+      if (EDGE) { const bool live = L0 + u <= Lend; hd = hd && live; hu = hu && live; }
+      hits |= (hd ? 1u << u : 0u) | (hu ? 0x100u << u : 0u);
+    }
+    if (!__ballot(hits != 0)) continue;
+    while (hits) {
+      const int bit = __ffs(hits) - 1;
+      hits &= hits - 1u;
+      const int side = bit >> 3, L = L0 + (bit & 7);
+      const bool grew_left = !(L & 1);
+      const int qm = side ? kCG : kCL, qt = side ? kCTu : kCTd;
+      const int hh = L >> 1, w0 = relc - hh, e = w0 + L - 1;
+      const int c = (int)S.C(qm, w0 + L) - (int)S.C(qm, w0);
+      bool pass = c >= hh + 1;                         // enough bins beyond the limit for either parity
+      if (!pass && grew_left && c == hh) {             // even L, the two middle elements straddle the limit: need their values
+        ScanMid m = side ? mid_dup : mid_del;
+        const int thr = side ? t.ce_dup : t.fl_del;
+        const int ow0 = relc - (m.upto >> 1), oe = ow0 + m.upto - 1;   // window the pair covers (empty for upto = 0)
+        const int* M = S.M;
+        // DEL: a = max{x <= thr}, b = min{x > thr}; DUP: a = max{x < thr}, b = min{x >= thr}
+        auto fold = [&](int j) {
+          const int x = M[j];
+          const bool near = side ? x < thr : x <= thr;
+          if (near) m.a = x > m.a ? x : m.a; else m.b = x < m.b ? x : m.b;
+        };
+        for (int j = w0; j < ow0; ++j) fold(j);        // the bins gained on the left since ...
+        for (int j = oe + 1; j <= e; ++j) fold(j);     // ... and on the right
+        m.upto = L;
+        if (side) mid_dup = m; else mid_del = m;
+        const double mid = 0.5 * ((double)m.a + (double)m.b);
+        pass = side ? !(mid < t.lim_dup) : !(mid > t.lim_del);   // rsi.cpp:1236 / 1206
+      }
+      const ScanRun old = side ? run_dup : run_del;
+      ScanRun now = {-1, 0, 0};
+      if (pass && old.lastL == L - 1) {                // the run continues
+        const int g = grew_left ? w0 : e;
+        const unsigned bits = S.PF[g];
+        const bool vt = (bits >> qt) & 1u, vm = (bits >> qm) & 1u;
+        now.lastL = L; now.i1 = old.i1; now.i2 = old.i2;
+        int lo_m, hi_m;
+        if (grew_left) {
+          if (vt) now.i1 = vm ? g : scan_next(S, qm, g, t.vhi);
+          lo_m = now.i1; hi_m = now.i2 < old.i1 - 1 ? now.i2 : old.i1 - 1;
+        } else {
+          if (vt) now.i2 = vm ? g : scan_prev(S, qm, g, t.vlo);
+          lo_m = now.i1 > old.i2 + 1 ? now.i1 : old.i2 + 1; hi_m = now.i2;
+        }
+        if (lo_m <= hi_m) scan_mark(S, side, lo_m, hi_m, L);
+      } else if (pass) {
+        const int r = scan_hit_slow(S.count, S.kcap, w0, L, side, t.vlo, t.vhi, t.ends, counters);
+        if (r >= 0) { now.lastL = L; now.i1 = r & 0xfff; now.i2 = (r >> 12) & 0xfff; }
+      }
+      if (side) run_dup = now; else run_del = now;
+    }
   }
-  return full ? wmax : kUnmarked;
 }
 
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
@@ -230,20 +355,11 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
                                                        uint32_t* __restrict__ first_del, uint32_t* __restrict__ first_dup,
                                                        uint32_t* __restrict__ counters) {
   extern __shared__ __align__(16) double sm[];
-  const int Lmax = sp.Lmax;
+  const int Lmax = sp.Lmax, kcap = sp.kcap;
   const int halo = Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;          // staged bins
   ScanLds S;
-  S.P = sm;
-  S.tdel = S.P + count + 1;
-  S.tdup = S.tdel + Lmax + 1;
-  S.tot = S.tdup + Lmax + 1;
-  S.T = reinterpret_cast<float*>(S.tot + kThreads);
-  S.M = reinterpret_cast<int*>(S.T + count);
-  S.CL = S.M + count;
-  S.CG = S.CL + count + 1;
-  S.FD = reinterpret_cast<uint32_t*>(S.CG + count + 1);
-  S.FU = S.FD + count;
+  scan_lds_carve(S, sm, count, kcap);
   const int64_t tile_start = (int64_t)blockIdx.x * kScanTile;
   const int64_t lo = tile_start - halo;
   const int vlo = lo < 0 ? (int)(-lo) : 0;
@@ -251,12 +367,13 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   const bool at_start = lo <= 0, at_end = lo + count >= sp.nb;
   // integer forms of the median limits: x > lim_del <=> x > fl_del ; x < lim_dup <=> x < ce_dup
   const int fl_del = (int)floor(sp.lim_del), ce_dup = (int)ceil(sp.lim_dup);
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { S.tdel[e] = thr_del[e]; S.tdup[e] = thr_dup[e]; }
+  const double tmed = sp.tmedian;
+  for (int e = threadIdx.x; e < 2 * (kcap + 1) * count; e += kThreads) S.TB[e] = kUnmarked;
   // ---- stage + exact prefixes: serial chunk per thread, then a scan of the 256 chunk totals ----
   const int chunk = (count + kThreads - 1) / kThreads;
   const int c0 = threadIdx.x * chunk;
   double run = 0.0;
-  int runl = 0, rung = 0;
+  int rc[4] = {0, 0, 0, 0};
   unsigned int inexact = 0;
   for (int e = c0; e < c0 + chunk && e < count; ++e) {
     const bool in = e >= vlo && e < vhi;
@@ -265,74 +382,106 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
     // exact-sum precondition: 0, or 2^-10 <= |v| < 2^20; counted once, by the owning tile
     const float av = fabsf(v);
     if (!(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && e >= halo && e < halo + kScanTile) inexact++;
-    S.T[e] = v; S.M[e] = mi; S.FD[e] = kUnmarked; S.FU[e] = kUnmarked;
+    S.M[e] = mi;
     run += (double)v;
-    runl += (in && mi <= fl_del);
-    rung += (in && mi >= ce_dup);
-    S.P[e + 1] = run; S.CL[e + 1] = runl; S.CG[e + 1] = rung;
+    rc[kCL] += (in && mi <= fl_del);
+    rc[kCG] += (in && mi >= ce_dup);
+    rc[kCTd] += (in && !((double)v > tmed));       // where a DEL value walk stops (rsi.cpp:1211, 1213)
+    rc[kCTu] += (in && !((double)v < tmed));       // where a DUP value walk stops (rsi.cpp:1241, 1243)
+    S.P[e + 1] = run;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S.C(q, e + 1) = (uint16_t)rc[q];
   }
-  // pack the three chunk totals for the cross-thread scan (counts are exact in double)
+  __shared__ int s_c[4][kThreads];
   S.tot[threadIdx.x] = run;
-  __shared__ int s_cl[kThreads], s_cg[kThreads];
-  s_cl[threadIdx.x] = runl; s_cg[threadIdx.x] = rung;
-  if (threadIdx.x == 0) { S.P[0] = 0.0; S.CL[0] = 0; S.CG[0] = 0; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s_c[q][threadIdx.x] = rc[q];
+  if (threadIdx.x == 0) { S.P[0] = 0.0; for (int q = 0; q < 4; ++q) S.C(q, 0) = 0; }
   __syncthreads();
   if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
-    double carry = 0.0; int carl = 0, carg = 0;
+    double carry = 0.0;
+    int car[4] = {0, 0, 0, 0};
     for (int k = 0; k < kThreads / 64; ++k) {
       const int idx = k * 64 + threadIdx.x;
-      const double mine = S.tot[idx]; const int ml = s_cl[idx], mg = s_cg[idx];
-      double incl = mine; int il = ml, ig = mg;
+      const double mine = S.tot[idx];
+      double incl = mine;
+      int m4[4], i4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { m4[q] = s_c[q][idx]; i4[q] = m4[q]; }
       for (int d = 1; d < 64; d <<= 1) {
-        const double up = __shfl_up(incl, d); const int ul = __shfl_up(il, d), ug = __shfl_up(ig, d);
-        if ((int)threadIdx.x >= d) { incl += up; il += ul; ig += ug; }
+        const double up = __shfl_up(incl, d);
+        int u4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u4[q] = __shfl_up(i4[q], d);
+        if ((int)threadIdx.x >= d) {
+          incl += up;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) i4[q] += u4[q];
+        }
       }
-      S.tot[idx] = carry + incl - mine; s_cl[idx] = carl + il - ml; s_cg[idx] = carg + ig - mg;
-      carry += __shfl(incl, 63); carl += __shfl(il, 63); carg += __shfl(ig, 63);
+      S.tot[idx] = carry + incl - mine;
+      carry += __shfl(incl, 63);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += __shfl(i4[q], 63); }
     }
   }
   __syncthreads();
   {
-    const double off = S.tot[threadIdx.x]; const int ol = s_cl[threadIdx.x], og = s_cg[threadIdx.x];
-    for (int e = c0; e < c0 + chunk && e < count; ++e) { S.P[e + 1] += off; S.CL[e + 1] += ol; S.CG[e + 1] += og; }
+    const double off = S.tot[threadIdx.x];
+    int o4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o4[q] = s_c[q][threadIdx.x];
+    int before[4] = {o4[0], o4[1], o4[2], o4[3]};   // global count before element e
+    for (int e = c0; e < c0 + chunk && e < count; ++e) {
+      S.P[e + 1] += off;
+      unsigned bits = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int after = (int)S.C(q, e + 1) + o4[q];
+        S.C(q, e + 1) = (uint16_t)after;
+        if (after != before[q]) { S.R(q, before[q]) = (uint16_t)e; bits |= 1u << q; }   // e is the before[q]-th bin with predicate q
+        before[q] = after;
+      }
+      S.PF[e] = (uint16_t)bits;
+    }
   }
   for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
   if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
   __syncthreads();
 
-  // ---- every (bin, L) of the tile; lanes are independent ----
-  const double tmed = sp.tmedian;
+  // ---- every (bin, L) of the tile.  Going from L-1 to L the window gains one bin -- on the left for
+  // even L, on the right for odd L -- so one prefix value per step is new.  ----
+  ScanTile tile;
+  tile.vlo = vlo; tile.vhi = vhi; tile.fl_del = fl_del; tile.ce_dup = ce_dup;
+  tile.lim_del = sp.lim_del; tile.lim_dup = sp.lim_dup; tile.ends = (at_start ? 1 : 0) | (at_end ? 2 : 0);
+  const bool edge_tile = at_start || at_end;   // only there can a lane's L range be cut short
   for (int r = 0; r < kScanTile / kThreads; ++r) {
     const int64_t i = tile_start + r * kThreads + threadIdx.x;
     const int rel = (int)(i - lo);   // staged index of bin i
-    // skip rule: wd / wu hold the largest mark in the lane's window as of length ld / lu; while the
-    // window grows by one bin per L they are extended incrementally, otherwise recomputed by lane_hit.
-    // A hit whose whole window already carries marks <= L cannot change anything (the trimmed
-    // interval lies inside the window), so it is skipped.
-    uint32_t wd = kUnmarked, wu = kUnmarked; int ld = -1, lu = -1;
-    for (int L = 1; L <= Lmax; ++L) {
-      const int h = L / 2;
-      // the reference visits i in [L/2+1, nb-L/2-2] (rsi.cpp:1204)
-      if (!(i < sp.nb && i >= h + 1 && i < sp.nb - h - 1)) continue;
-      const int w0 = rel - h;
-      const double sum = S.P[w0 + L] - S.P[w0];
-      const int grown = (L & 1) ? w0 + L - 1 : w0;   // the bin the window gained going from L-1 to L
-      if (sum <= S.tdel[L]) {
-        if (ld == L - 1) { const uint32_t v = S.FD[grown]; wd = v > wd ? v : wd; } else wd = kUnmarked;
-        if (wd > (uint32_t)L) wd = lane_hit(S, w0, L, true, fl_del, sp.lim_del, tmed, vlo, vhi, at_start, at_end, S.FD, counters);
-        ld = L;
-      }
-      if (sum >= S.tdup[L]) {
-        if (lu == L - 1) { const uint32_t v = S.FU[grown]; wu = v > wu ? v : wu; } else wu = kUnmarked;
-        if (wu > (uint32_t)L) wu = lane_hit(S, w0, L, false, ce_dup, sp.lim_dup, tmed, vlo, vhi, at_start, at_end, S.FU, counters);
-        lu = L;
-      }
-    }
+    // the reference visits i in [L/2+1, nb-L/2-2] (rsi.cpp:1204): L/2 <= min(i-1, nb-i-2)
+    const int64_t hmax = (i - 1) < (sp.nb - i - 2) ? (i - 1) : (sp.nb - i - 2);
+    int Lend = (i < sp.nb && hmax >= 0) ? (int)(hmax < Lmax ? 2 * hmax + 1 : Lmax) : 0;
+    if (Lend > Lmax) Lend = Lmax;
+    const int relc = Lend > 0 ? rel : halo;   // lanes without a bin read a harmless address
+    if (edge_tile) scan_sweep<true>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, counters);
+    else scan_sweep<false>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, counters);
   }
   __syncthreads();
+  // ---- push the block levels down to single bins ----
+  for (int k = kcap; k >= 1; --k) {
+    const int half = 1 << (k - 1);
+    uint32_t* hd = S.level(0, k); uint32_t* ld = S.level(0, k - 1);
+    uint32_t* hu = S.level(1, k); uint32_t* lu = S.level(1, k - 1);
+    for (int e = threadIdx.x; e < count; e += kThreads) {
+      const uint32_t d = hd[e], u = hu[e];
+      if (d != kUnmarked) { atomicMin(&ld[e], d); atomicMin(&ld[e + half], d); }
+      if (u != kUnmarked) { atomicMin(&lu[e], u); atomicMin(&lu[e + half], u); }
+    }
+    __syncthreads();
+  }
   // ---- merge the tile's marks into HBM (halo bins are shared with the neighbouring tiles) ----
   for (int e = vlo + threadIdx.x; e < vhi; e += kThreads) {
-    const uint32_t d = S.FD[e], u = S.FU[e];
+    const uint32_t d = S.level(0, 0)[e], u = S.level(1, 0)[e];
     if (d != kUnmarked) atomicMin(&first_del[lo + e], d);
     if (u != kUnmarked) atomicMin(&first_dup[lo + e], u);
   }
@@ -496,11 +645,17 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
   if (grid > 128) grid = 128;
   hipLaunchKernelGGL(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
 }
-void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del, const double* thr_dup,
+void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
+  ScanParams sp = sp_in;
   const int halo = sp.Lmax / 2 + 1;
-  const size_t count = (size_t)kScanTile + 2 * halo;
-  const size_t lds = ((count + 1) + 2 * (size_t)(sp.Lmax + 1) + kThreads) * sizeof(double) + count * 4 * 4 + 2 * (count + 1) * 4;
+  const int count = kScanTile + 2 * halo;
+  // block-level cap: floor(log2(Lmax)), at most 6, lowered until the tile fits in LDS
+  int kcap = 0;
+  while ((2 << kcap) <= sp.Lmax && kcap < 6) ++kcap;
+  while (kcap > 0 && scan_lds_bytes(count, kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --kcap;
+  sp.kcap = kcap;
+  const size_t lds = scan_lds_bytes(count, kcap);
   const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rsi_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_rsi_scan, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters);

@@ -244,8 +244,10 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
 // Per-L thresholds on the exact window sum equivalent to the reference's score tests
 // (rsi.cpp:1204-1205, 1234-1235 with runmeantp's float mean, wufunctions.cpp:625-627).
 void scan_thresholds(double tmedian, double tlamda, int Lmax, std::vector<double>& del, std::vector<double>& dup) {
-  del.assign((size_t)Lmax + 1, -1.0);
-  dup.assign((size_t)Lmax + 1, INFINITY);
+  // kScanPad entries past Lmax that no sum can reach: the kernel walks L in unrolled groups
+  del.assign((size_t)Lmax + 1 + kScanPad, -INFINITY);
+  dup.assign((size_t)Lmax + 1 + kScanPad, INFINITY);
+  del[0] = -1.0;
   for (int L = 1; L <= Lmax; ++L) {
     const double dL = (double)L, sq = sqrt(dL);
     auto score = [&](double sum) { const float meanf = (float)(sum / dL); return ((double)meanf - tmedian) * sq; };
@@ -446,11 +448,12 @@ int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t n
   uint8_t* small = ctx->small.as<uint8_t>();
   std::vector<double> del, dup;
   scan_thresholds(tmedian, tlamda, Lmax, del, dup);
-  HIPCHK(ctx->thr.ensure((size_t)(Lmax + 1) * 16));
+  const size_t nthr = (size_t)Lmax + 1 + kScanPad;
+  HIPCHK(ctx->thr.ensure(nthr * 16));
   double* d_del = ctx->thr.as<double>();
-  double* d_dup = d_del + (Lmax + 1);
-  HIPCHK(hipMemcpyAsync(d_del, del.data(), (size_t)(Lmax + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_dup, dup.data(), (size_t)(Lmax + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  double* d_dup = d_del + nthr;
+  HIPCHK(hipMemcpyAsync(d_del, del.data(), nthr * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_dup, dup.data(), nthr * 8, hipMemcpyHostToDevice, ctx->stream));
   uint32_t* d_counters = reinterpret_cast<uint32_t*>(small + kOffCounters);
   HIPCHK(hipMemsetAsync(d_counters, 0, 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->first_del.p, 0xff, (size_t)nb * 4, ctx->stream));

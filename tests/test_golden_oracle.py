@@ -5,9 +5,11 @@ import numpy as np
 import pytest
 
 import golden_util as gu
-from conftest import calls_equal, small_cases
+from conftest import calls_equal, small_cases, wide_scan_cases
 
-NAMES = [c[0] for c in small_cases()]
+# one long-scan case pins the oracle there too (they take ~20 s of oracle time each; the GPU suite checks all three
+# against the same golden files)
+NAMES = [c[0] for c in small_cases()] + [wide_scan_cases()[0][0]]
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -182,3 +182,4 @@ def test_parity_20mb_vs_oracle(hot, hotlib, oracle_cls):
         ok, why = calls_equal(res.calls(which), O.calls({"segs": "segs_nb"}.get(which, which)))
         assert ok, f"{which}: {why}"
     assert len(res.calls("calls")) >= 15
+

@@ -3,10 +3,10 @@ import numpy as np
 import pytest
 
 import golden_util as gu
-from conftest import calls_equal, small_cases
+from conftest import calls_equal, small_cases, wide_scan_cases
 
 pytestmark = pytest.mark.gpu
-NAMES = [c[0] for c in small_cases()]
+NAMES = [c[0] for c in small_cases()] + [c[0] for c in wide_scan_cases()]
 
 
 @pytest.fixture(scope="module")

@@ -78,3 +78,4 @@ def test_whole_path_2mb(ref, oracle_cls, hotlib, flags):
         ok, why = calls_equal(O.calls(which), exp, rtol=0)
         assert ok, f"{which}: {why}"
     assert len(raw) >= 3
+

@@ -4,6 +4,7 @@ oracle/Makefile.ref from /root/reference).  Runs only where /root/reference exis
 it writes are data (seeded inputs' hashes + the reference's outputs), never reference source.
 
   python tools/make_golden.py            # all cases of tests/conftest.small_cases()
+  python tools/make_golden.py wide       # tests/conftest.wide_scan_cases() (minutes: long scans)
 
 Per case the file holds: the plan (JSON), sha256 of the generated FASTA / depth (guards against
 generator drift), the padded N regions, sha256 of the per-base arrays after GC adjust / cap /
@@ -36,13 +37,14 @@ def calls_array(calls):
 
 def main():
     import oracle
-    from conftest import make_case, small_cases
+    from conftest import make_case, small_cases, wide_scan_cases
     from rsicnv_amd import api
     lib = api.load_library()
     R = oracle.Ref()
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    for name, plan_kw, flag_kw in small_cases():
+    cases = wide_scan_cases() if (len(sys.argv) > 1 and sys.argv[1] == "wide") else small_cases()
+    for name, plan_kw, flag_kw in cases:
         plan, fasta, depth = make_case(lib, plan_kw)
         p = oracle.make_params(**flag_kw)
         R.load(p, depth, fasta)
