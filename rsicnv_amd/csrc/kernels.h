@@ -135,9 +135,8 @@ void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start,
 
 // ---- candidate stages on the device (kernels_cand.hip) ----
 constexpr unsigned kCandHistBins = 16384;   // LDS counters of the per-test quantile histograms
-struct EdgeJob {            // optimize_with_derivative for one candidate, both passes; start/end updated in place
-  int32_t start, end, type, scratch_len;   // scratch_len: int64 words available at scratch_off
-  int64_t scratch_off;
+struct EdgeJob {            // optimize_with_derivative for one candidate; start/end updated in place by each launch
+  int32_t start, end, type, pad;
 };
 struct CandJob {            // one isitcnvwrap test, prepared on the host from the candidate list
   int32_t start, end;       // the candidate (compacted coordinates, inclusive)
@@ -160,7 +159,11 @@ struct CandOut {
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
 };
 void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* scratch, hipStream_t stream);
+// one launch = one call of optimize_with_derivative for every job; part_v / part_i: sharpen_part_slots(njobs) entries, done: njobs
+// counters, zero before the first launch (each launch leaves them zero again)
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* part_v, int32_t* part_i,
+                          uint32_t* done, hipStream_t stream);
+size_t sharpen_part_slots(int njobs);
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
 

@@ -14,64 +14,82 @@ namespace rsik {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;        // boundary refinement, range sums
+constexpr int kTestThreads = 1024;   // neighbourhood test: one workgroup per candidate, so make it a big one
+constexpr int kMaxWaves = kTestThreads / 64;
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 
 // ---- block-wide helpers (256 threads) --------------------------------------------------------
 template <class T, class Op>
-__device__ inline T block_reduce(T v, Op op, T* s_tmp /* kThreads/64 + 1 */) {
+__device__ inline T block_reduce(T v, Op op, T* s_tmp /* kMaxWaves */) {
   for (int d = 32; d >= 1; d >>= 1) v = op(v, __shfl_xor(v, d));
   __syncthreads();
   if (lane_id() == 0) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();
   T r = s_tmp[0];
-  for (int w = 1; w < kThreads / 64; ++w) r = op(r, s_tmp[w]);
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = op(r, s_tmp[w]);
   __syncthreads();
   return r;
 }
 // exclusive prefix of one int per thread; returns the thread's offset, *total = sum over the block
-__device__ inline int block_exscan(int v, int* s_tmp /* kThreads/64 */, int* total) {
+__device__ inline int block_exscan(int v, int* s_tmp /* kMaxWaves */, int* total) {
   int incl = v;
   for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane_id() >= d) incl += up; }
   __syncthreads();
   if (lane_id() == 63) s_tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
   int base = 0, tot = 0;
-  for (int w = 0; w < kThreads / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) base += s_tmp[w]; tot += s_tmp[w]; }
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { if (w < (int)(threadIdx.x >> 6)) base += s_tmp[w]; tot += s_tmp[w]; }
   __syncthreads();
   *total = tot;
   return base + incl - v;
 }
-// exact int64 prefix of f(0..len-1) into P[0..len] (P[0] = 0): serial chunk per thread + scan of the totals
+// exact int64 prefix of f(0..len-1) into P[0..len] (P[0] = 0), in tiles of blockDim.x consecutive elements
+// (coalesced reads and writes) with a running carry
 template <class F>
-__device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f, long long* s_tot /* kThreads */) {
-  const int chunk = (len + kThreads - 1) / kThreads;
-  const int c0 = threadIdx.x * chunk;
-  long long run = 0;
-  for (int e = c0; e < c0 + chunk && e < len; ++e) run += f(e);
-  s_tot[threadIdx.x] = run;
+__device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f, long long* s_tmp /* kMaxWaves */);
+
+// exclusive prefix of one int64 per thread over the block; *total = block sum
+__device__ inline long long block_exscan_i64(long long v, long long* s_tmp /* kMaxWaves */, long long* total) {
+  long long incl = v;
+  for (int d = 1; d < 64; d <<= 1) { const long long up = __shfl_up(incl, d); if (lane_id() >= d) incl += up; }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    long long carry = 0;
-    for (int k = 0; k < kThreads / 64; ++k) {
-      const long long mine = s_tot[k * 64 + threadIdx.x];
-      long long incl = mine;
-      for (int d = 1; d < 64; d <<= 1) { const long long up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
-      s_tot[k * 64 + threadIdx.x] = carry + incl - mine;
-      carry += __shfl(incl, 63);
-    }
-  }
+  if (lane_id() == 63) s_tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
-  run = s_tot[threadIdx.x];
+  long long base = 0, tot = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { if (w < (int)(threadIdx.x >> 6)) base += s_tmp[w]; tot += s_tmp[w]; }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+template <class F>
+__device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f, long long* s_tmp) {
+  long long carry = 0;
   if (threadIdx.x == 0) P[0] = 0;
-  for (int e = c0; e < c0 + chunk && e < len; ++e) { run += f(e); P[e + 1] = run; }
+  for (int t0 = 0; t0 < len; t0 += (int)blockDim.x) {
+    const int e = t0 + (int)threadIdx.x;
+    const long long v = e < len ? f(e) : 0;
+    long long total;
+    const long long ex = block_exscan_i64(v, s_tmp, &total);
+    if (e < len) P[e + 1] = carry + ex + v;
+    carry += total;
+  }
   __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
-// Boundary refinement, both passes (rsi.cpp:1876-1877 calls it twice).  dd[i] = sum of the len values
-// left of q = from+i minus the sum of the len values from q on; first maximum / minimum over the first
-// and the last 2*reach entries.  Arg-extremes keep the smallest index (the reference's strict >).
+// Boundary refinement (optimize_with_derivative, rsi.cpp:889-944; detectcnv calls it twice, rsi.cpp:
+// 1876-1877: one launch per call).  dd[i] = sum of the len values left of q = from+i minus the sum of
+// the len values from q on; the new start is the first maximum (DEL) / minimum (DUP) of dd over its
+// first 2*reach entries, the new end the first minimum / maximum over its last 2*reach entries; only
+// strictly positive / negative values count and index 0 never moves anything.
+// Each of the two search windows of a candidate is cut into kEdgeChunks pieces, one workgroup each:
+// the workgroup gets dd at its first index directly (a reduction over 2*len values), then walks its
+// piece in tiles of 256 with dd[i+1] - dd[i] = -p[q-len] + 2 p[q] - p[q+len] and an exact int64 block
+// scan.  The last workgroup of a candidate to finish folds the pieces (smallest index wins ties, as
+// the reference's strict comparisons do) and writes the new coordinates.
+constexpr int kEdgeChunks = 16;
 struct ArgBest { long long v; int i; };
 __device__ inline ArgBest arg_pick(ArgBest a, ArgBest b, bool want_max) {
   if (b.i < 0) return a;
@@ -81,56 +99,78 @@ __device__ inline ArgBest arg_pick(ArgBest a, ArgBest b, bool want_max) {
 }
 
 __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __restrict__ rdc, int64_t ncompact,
-                                                            EdgeJob* __restrict__ jobs, long long* __restrict__ scratch) {
-  __shared__ long long s_tot[kThreads];
+                                                            EdgeJob* __restrict__ jobs, long long* __restrict__ part_v,
+                                                            int32_t* __restrict__ part_i, uint32_t* __restrict__ done) {
+  __shared__ long long s_l[kMaxWaves];
   __shared__ long long s_v[kThreads / 64];
   __shared__ int s_i[kThreads / 64];
-  EdgeJob job = jobs[blockIdx.x];
-  long long* P = scratch + job.scratch_off;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int len = job.end - job.start + 1;
-    const int reach = len / 4 > 250 ? len / 4 : 250;
-    const int from = job.start - reach, to = job.end + reach;
-    if (job.type > 1) break;                  // untyped candidate: the reference moves nothing
-    if (from < 2 * len || (int64_t)to > ncompact - 2 * (int64_t)len) break;   // too close to the ends: unchanged (and so in pass 2)
-    const int base = from - len;              // prefix covers [from-len, to+len)
-    const int plen = (to - from) + 2 * len;
-    if (plen + 1 > job.scratch_len) break;    // cannot happen: the host sizes the scratch for both passes
-    block_prefix_i64(P, plen, [&](int e) { return (long long)rdc[base + e]; }, s_tot);
-    const int nstep = to - from, tail0 = nstep - 2 * reach;
-    const bool del = job.type == 0;
-    ArgBest lo{0, -1}, hi{0, -1};
-    for (int i = threadIdx.x; i < nstep; i += kThreads) {
-      const int q = from + i - base;          // prefix index of position from+i
-      const long long dd = (P[q] - P[q - len]) - (P[q + len] - P[q]);
-      if (i < 2 * reach && (del ? dd > 0 : dd < 0)) lo = arg_pick(lo, ArgBest{dd, i}, del);
-      if (i >= tail0 && (del ? dd < 0 : dd > 0)) hi = arg_pick(hi, ArgBest{dd, i}, !del);
+  __shared__ int s_last;
+  const int jb = blockIdx.y;
+  const EdgeJob job = jobs[jb];
+  const int len = job.end - job.start + 1;
+  const int reach = len / 4 > 250 ? len / 4 : 250;
+  const int from = job.start - reach, to = job.end + reach;
+  if (job.type > 1) return;                                                  // untyped candidate: the reference moves nothing
+  if (from < 2 * len || (int64_t)to > ncompact - 2 * (int64_t)len) return;   // too close to the ends: unchanged
+  const int nstep = to - from;
+  const int win = blockIdx.x / kEdgeChunks, chunk = blockIdx.x % kEdgeChunks;   // win 0: start search, 1: end search
+  const int wlen = 2 * reach;
+  const int wbase = win == 0 ? 0 : nstep - wlen;
+  const int cs = (wlen + kEdgeChunks - 1) / kEdgeChunks;
+  const int i0 = wbase + chunk * cs;
+  int i1 = i0 + cs; if (i1 > wbase + wlen) i1 = wbase + wlen;
+  const bool del = job.type == 0;
+  const bool want_max = win == 0 ? del : !del;
+  ArgBest best{0, -1};
+  if (i0 < i1) {
+    // dd at the piece's first index
+    const int q0 = from + i0;
+    long long acc = 0;
+    for (int j = threadIdx.x; j < len; j += kThreads) acc += (long long)rdc[q0 - len + j] - (long long)rdc[q0 + j];
+    long long cur = block_reduce(acc, [](long long a, long long b) { return a + b; }, s_l);
+    for (int t0 = i0; t0 < i1; t0 += kThreads) {
+      const int i = t0 + (int)threadIdx.x;
+      long long delta = 0;
+      if (i < i1) { const int q = from + i; delta = -(long long)rdc[q - len] + 2ll * rdc[q] - (long long)rdc[q + len]; }
+      long long total;
+      const long long dd = cur + block_exscan_i64(delta, s_l, &total);
+      if (i < i1 && (want_max ? dd > 0 : dd < 0)) best = arg_pick(best, ArgBest{dd, i}, want_max);
+      cur += total;
     }
-    // block arg-reduction (values first, then smallest index)
-    auto reduce = [&](ArgBest b, bool want_max) {
-      for (int d = 32; d >= 1; d >>= 1) { ArgBest o; o.v = __shfl_xor(b.v, d); o.i = __shfl_xor(b.i, d); b = arg_pick(b, o, want_max); }
-      __syncthreads();
-      if (lane_id() == 0) { s_v[threadIdx.x >> 6] = b.v; s_i[threadIdx.x >> 6] = b.i; }
-      __syncthreads();
-      ArgBest r{s_v[0], s_i[0]};
-      for (int w = 1; w < kThreads / 64; ++w) r = arg_pick(r, ArgBest{s_v[w], s_i[w]}, want_max);
-      __syncthreads();
-      return r;
-    };
-    lo = reduce(lo, del);
-    hi = reduce(hi, !del);
-    if (lo.i > 0) job.start = from + lo.i;
-    if (hi.i > 0) job.end = to - nstep + hi.i;
-    __syncthreads();
   }
-  if (threadIdx.x == 0) { jobs[blockIdx.x].start = job.start; jobs[blockIdx.x].end = job.end; }
+  // block arg-reduction (values first, then smallest index)
+  for (int d = 32; d >= 1; d >>= 1) { ArgBest o; o.v = __shfl_xor(best.v, d); o.i = __shfl_xor(best.i, d); best = arg_pick(best, o, want_max); }
+  __syncthreads();
+  if (lane_id() == 0) { s_v[threadIdx.x >> 6] = best.v; s_i[threadIdx.x >> 6] = best.i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ArgBest r{s_v[0], s_i[0]};
+    for (int w = 1; w < kThreads / 64; ++w) r = arg_pick(r, ArgBest{s_v[w], s_i[w]}, want_max);
+    const size_t slot = (size_t)jb * 2 * kEdgeChunks + blockIdx.x;
+    part_v[slot] = r.v; part_i[slot] = r.i;
+    __threadfence();
+    s_last = atomicAdd(&done[jb], 1u) == 2 * kEdgeChunks - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {   // every piece of this candidate is in: fold them
+    __threadfence();
+    ArgBest lo{0, -1}, hi{0, -1};
+    for (int c = 0; c < kEdgeChunks; ++c) {
+      const size_t a = (size_t)jb * 2 * kEdgeChunks + c, b = a + kEdgeChunks;
+      lo = arg_pick(lo, ArgBest{part_v[a], part_i[a]}, del);
+      hi = arg_pick(hi, ArgBest{part_v[b], part_i[b]}, !del);
+    }
+    if (lo.i > 0) jobs[jb].start = from + lo.i;
+    if (hi.i > 0) jobs[jb].end = to - nstep + hi.i;
+    done[jb] = 0;   // ready for the second call
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // Neighbourhood test.  See CandJob in kernels.h for what the host prepares.
-constexpr int kWalkBlock = 4 * kThreads;   // positions examined per trip of a walk
+constexpr int kWalkBlock = 4 * kTestThreads;   // positions examined per trip of a walk
 
-struct WalkShared { int s_scan[kThreads / 64]; int s_red[kThreads / 64 + 1]; };
+struct WalkShared { int s_scan[kMaxWaves]; int s_red[kMaxWaves]; };
 
 // One side of the reference gather (rsi.cpp:206-257).  dir = -1: left of the candidate, values land
 // in dst[fill], dst[fill-1], ...; dir = +1: right, values land in dst[used], dst[used+1], ...
@@ -195,17 +235,40 @@ __device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int 
   return stored;
 }
 
-__global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __restrict__ A, int64_t N,
+// Buckets where the cumulated count first reaches n/4, n/2, 3n/4 (partition_stat_tp's walk,
+// wufunctions.cpp:398-420), -1 where it never does; every thread gets the result.
+__device__ inline void hist_ranks(const unsigned int* hist, unsigned nbk, size_t n, int* s_scan, int* s_q, int* out) {
+  const size_t r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
+  if (threadIdx.x < 3) s_q[threadIdx.x] = -1;
+  const unsigned chunk = (nbk + blockDim.x - 1) / blockDim.x;
+  const unsigned b0 = threadIdx.x * chunk;
+  int local = 0;
+  for (unsigned b = b0; b < b0 + chunk && b < nbk; ++b) local += (int)hist[b];
+  int total;
+  size_t seen = (size_t)block_exscan(local, s_scan, &total);   // syncs: s_q is initialised before any write below
+  for (unsigned b = b0; b < b0 + chunk && b < nbk; ++b) {
+    const size_t upto = seen + hist[b];
+    if (seen < r1 && upto >= r1) s_q[0] = (int)b;
+    if (seen < r2 && upto >= r2) s_q[1] = (int)b;
+    if (seen < r3 && upto >= r3) s_q[2] = (int)b;
+    seen = upto;
+  }
+  __syncthreads();
+  out[0] = s_q[0]; out[1] = s_q[1]; out[2] = s_q[2];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* __restrict__ A, int64_t N,
                                                              const CandJob* __restrict__ jobs, const int2* __restrict__ chains,
                                                              int32_t* __restrict__ iscratch, long long* __restrict__ lscratch,
                                                              double RDmedian, CandOut* __restrict__ outs) {
   extern __shared__ unsigned int s_hist[];   // kCandHistBins counters
   __shared__ WalkShared W;
-  __shared__ long long s_tot[kThreads];
-  __shared__ double s_d[kThreads / 64 + 1];
-  __shared__ float s_f[kThreads / 64 + 1];
-  __shared__ long long s_l[kThreads / 64 + 1];
-  __shared__ int s_i2[kThreads / 64 + 1];
+  __shared__ double s_d[kMaxWaves];
+  __shared__ float s_f[kMaxWaves];
+  __shared__ long long s_l[kMaxWaves];
+  __shared__ int s_i2[kMaxWaves];
+  __shared__ int s_q[3];
   const CandJob J = jobs[blockIdx.x];
   CandOut O;
   O.flags = 0;
@@ -223,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __re
   __syncthreads();
   // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
   const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
-  for (int j = threadIdx.x; j < used0; j += kThreads) ref[j] = left[J.top + 1 - used0 + j];
+  for (int j = threadIdx.x; j < used0; j += kTestThreads) ref[j] = left[J.top + 1 - used0 + j];
   __syncthreads();
   int room = J.capacity - used0;
   {   // `used < 2*chklen*d` with the double right-hand side (rsi.cpp:243)
@@ -246,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __re
     const int total = nref + nbody;
     const int tref = (int)((double)nref / (double)total * (double)J.budget);
     const int tbody = (int)((double)nbody / (double)total * (double)J.budget);
-    for (int q = threadIdx.x; q < tref; q += kThreads) thin[q] = ref[(int)((double)q / (double)tref * (double)nref)];
+    for (int q = threadIdx.x; q < tref; q += kTestThreads) thin[q] = ref[(int)((double)q / (double)tref * (double)nref)];
     __syncthreads();
     R = thin; nref = tref; thin_body = true; nbody_eff = tbody;
   }
@@ -261,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __re
   // ---- body statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
   {
     int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
-    for (int q = threadIdx.x; q < width; q += kThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
+    for (int q = threadIdx.x; q < width; q += kTestThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
     lo = block_reduce(lo, [](int a, int b) { return a < b ? a : b; }, s_i2);
     hi = block_reduce(hi, [](int a, int b) { return a > b ? a : b; }, s_i2);
     s1 = block_reduce(s1, [](long long a, long long b) { return a + b; }, s_l);
@@ -272,32 +335,26 @@ __global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __re
       const unsigned nbk = (unsigned)(hi - lo) + 2;
       if (nbk > kCandHistBins) O.flags |= 2;
       else {
-        for (unsigned e = threadIdx.x; e < nbk; e += kThreads) s_hist[e] = 0;
+        for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
         __syncthreads();
-        for (int q = threadIdx.x; q < width; q += kThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
+        for (int q = threadIdx.x; q < width; q += kTestThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
         __syncthreads();
-        if (threadIdx.x == 0) {
-          const size_t n = (size_t)width, r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
-          size_t seen = 0;
-          for (unsigned b = 0; b < nbk; ++b) {
-            const size_t upto = seen + s_hist[b];
-            if (seen < r1 && upto >= r1) O.body_q[0] = (double)lo + b * 1.0;
-            if (seen < r2 && upto >= r2) O.body_q[1] = (double)lo + b * 1.0;
-            if (seen < r3 && upto >= r3) O.body_q[2] = (double)lo + b * 1.0;
-            seen = upto;
-          }
-        }
+        int qb[3];
+        hist_ranks(s_hist, nbk, (size_t)width, W.s_scan, s_q, qb);
+        if (qb[0] >= 0) O.body_q[0] = (double)lo + qb[0] * 1.0;
+        if (qb[1] >= 0) O.body_q[1] = (double)lo + qb[1] * 1.0;
+        if (qb[2] >= 0) O.body_q[2] = (double)lo + qb[2] * 1.0;
         __syncthreads();
       }
     }
   }
   // ---- running mean of width `width` over the neighbourhood (rsi.cpp:113-124): exact prefix, float means ----
-  block_prefix_i64(P, nref, [&](int e) { return (long long)R[e]; }, s_tot);
+  block_prefix_i64(P, nref, [&](int e) { return (long long)R[e]; }, s_l);
   const double dw = (double)width;
   auto wmean = [&](int i) -> float { return (float)((double)(P[i + width] - P[i]) / dw); };
   {
     float flo = 3.0e38f, fhi = -3.0e38f; double m1 = 0, m2 = 0;
-    for (int i = threadIdx.x; i < nwin; i += kThreads) { const float w = wmean(i); flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w; }
+    for (int i = threadIdx.x; i < nwin; i += kTestThreads) { const float w = wmean(i); flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w; }
     flo = block_reduce(flo, [](float a, float b) { return a < b ? a : b; }, s_f);
     fhi = block_reduce(fhi, [](float a, float b) { return a > b ? a : b; }, s_f);
     m1 = block_reduce(m1, [](double a, double b) { return a + b; }, s_d);
@@ -309,24 +366,18 @@ __global__ __launch_bounds__(kThreads) void k_candidate_test(const int32_t* __re
       const size_t nbk = (size_t)((hi - lo) / 0.01 + 2);
       if (nbk > kCandHistBins) O.flags |= 4;
       else {
-        for (unsigned e = threadIdx.x; e < nbk; e += kThreads) s_hist[e] = 0;
+        for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < nwin; i += kThreads) {
+        for (int i = threadIdx.x; i < nwin; i += kTestThreads) {
           const double idx = ((double)wmean(i) - lo) / 0.01 + 0.5;   // wufunctions.cpp:396
           atomicAdd(&s_hist[(unsigned)(unsigned long long)idx], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-          const size_t n = (size_t)nwin, r1 = n / 4, r2 = n / 2, r3 = n * 3 / 4;
-          size_t seen = 0;
-          for (size_t b = 0; b < nbk; ++b) {
-            const size_t upto = seen + s_hist[b];
-            if (seen < r1 && upto >= r1) O.ref_q[0] = lo + b * 0.01;
-            if (seen < r2 && upto >= r2) O.ref_q[1] = lo + b * 0.01;
-            if (seen < r3 && upto >= r3) O.ref_q[2] = lo + b * 0.01;
-            seen = upto;
-          }
-        }
+        int qb[3];
+        hist_ranks(s_hist, (unsigned)nbk, (size_t)nwin, W.s_scan, s_q, qb);
+        if (qb[0] >= 0) O.ref_q[0] = lo + qb[0] * 0.01;
+        if (qb[1] >= 0) O.ref_q[1] = lo + qb[1] * 0.01;
+        if (qb[2] >= 0) O.ref_q[2] = lo + qb[2] * 0.01;
         __syncthreads();
       }
     }
@@ -352,17 +403,19 @@ void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long
   hipLaunchKernelGGL(k_range_sums, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums);
 }
 
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* scratch, hipStream_t stream) {
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* part_v, int32_t* part_i,
+                          uint32_t* done, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_sharpen_edges, dim3(njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, scratch);
+  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, part_v, part_i, done);
 }
+size_t sharpen_part_slots(int njobs) { return (size_t)njobs * 2 * kEdgeChunks; }
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;
   const size_t lds = (size_t)kCandHistBins * 4;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_candidate_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL(k_candidate_test, dim3(njobs), dim3(kThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch,
+  hipLaunchKernelGGL(k_candidate_test, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch,
                      lscratch, RDmedian, outs);
 }
 

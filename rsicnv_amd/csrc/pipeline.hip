@@ -313,19 +313,20 @@ class DeviceTester : public rsih::NeighbourTester {
   bool sharpen(std::vector<Candidate>& L) override {
     if (L.empty()) return true;
     std::vector<EdgeJob> jobs(L.size());
-    size_t words = 0;
-    for (size_t i = 0; i < L.size(); ++i) {
-      const int64_t len = (int64_t)L[i].end - L[i].start + 1;
-      const int64_t grown = len + 2 * std::max<int64_t>(250, len / 4);        // the second pass may see this length
-      const int64_t need = 3 * grown + 2 * std::max<int64_t>(250, grown / 4) + 8;
-      jobs[i] = {L[i].start, L[i].end, L[i].type, (int32_t)std::min<int64_t>(need, INT32_MAX), (int64_t)words};
-      words += (size_t)need;
-    }
-    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(words * 8))) return false; }
+    for (size_t i = 0; i < L.size(); ++i) jobs[i] = {L[i].start, L[i].end, L[i].type, 0};
+    const size_t slots = sharpen_part_slots((int)jobs.size());
+    const size_t off_i = slots * 8, off_done = off_i + slots * 4;
+    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(off_done + jobs.size() * 4))) return false; }
+    uint8_t* ws = ctx->cand_i64.as<uint8_t>();
     GateShared gs(ctx);
     Phase ph(ctx, "cand.sharpen");
     if (!ok(hipMemcpyAsync(ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob), hipMemcpyHostToDevice, ctx->stream))) return false;
-    { Timer t(ctx, "sharpen_edges"); launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), (int)jobs.size(), ctx->cand_i64.as<long long>(), ctx->stream); }
+    if (!ok(hipMemsetAsync(ws + off_done, 0, jobs.size() * 4, ctx->stream))) return false;
+    for (int pass = 0; pass < 2; ++pass) {   // rsi.cpp:1876-1877
+      Timer t(ctx, "sharpen_edges");
+      launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), (int)jobs.size(), reinterpret_cast<long long*>(ws),
+                           reinterpret_cast<int32_t*>(ws + off_i), reinterpret_cast<uint32_t*>(ws + off_done), ctx->stream);
+    }
     if (!ok(hipMemcpyAsync(jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob), hipMemcpyDeviceToHost, ctx->stream))) return false;
     if (!wait()) return false;
     gs.release();
