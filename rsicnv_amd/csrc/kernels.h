@@ -157,6 +157,7 @@ struct CandOut {
   int32_t nref, nbody, nwin, left_reach, right_reach, body_min, body_max;
   double body_q[3], body_s1, body_s2;   // lower quartile / median / upper quartile (partition_stat_tp), sum, sum of squares
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
+  int32_t dbg[6];
 };
 void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
 // one launch = one call of optimize_with_derivative for every job; part_v / part_i: sharpen_part_slots(njobs) entries, done: njobs

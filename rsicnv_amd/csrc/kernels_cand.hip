@@ -272,6 +272,8 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   const CandJob J = jobs[blockIdx.x];
   CandOut O;
   O.flags = 0;
+  long long tk[8]; int tn = 0;
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   int32_t* left = iscratch + J.iscratch_off;              // J.top + 1 slots
   int32_t* ref = left + (J.top + 1 > 0 ? J.top + 1 : 0);  // J.capacity slots
   int32_t* thin = ref + J.capacity;                       // min(capacity, budget) slots
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   if (J.top >= 0)
     lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
   __syncthreads();
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
   const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
   for (int j = threadIdx.x; j < used0; j += kTestThreads) ref[j] = left[J.top + 1 - used0 + j];
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   __syncthreads();
   // a chain the host cut short was consumed to its end: the walk may have missed a neighbour
   if (((J.cut & 1) && lused >= J.nleft) || ((J.cut & 2) && rused >= J.nright)) O.flags |= 8;
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   int nref = used0 + rcnt;
   int nbody = J.end - J.start + 1;
   // ---- thinning to about `budget` points (rsi.cpp:264-282) ----
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   O.nref = nref; O.nbody = nbody_eff; O.nwin = nwin; O.left_reach = lreach; O.right_reach = rreach;
   if (nwin <= 0 || width <= 0) { O.flags |= 1; if (threadIdx.x == 0) outs[blockIdx.x] = O; return; }
 
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   // ---- body statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
   {
     int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
@@ -348,8 +353,10 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       }
     }
   }
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   // ---- running mean of width `width` over the neighbourhood (rsi.cpp:113-124): exact prefix, float means ----
   block_prefix_i64(P, nref, [&](int e) { return (long long)R[e]; }, s_l);
+  tk[tn++] = (long long)__builtin_readcyclecounter();
   const double dw = (double)width;
   auto wmean = [&](int i) -> float { return (float)((double)(P[i + width] - P[i]) / dw); };
   {
@@ -382,6 +389,8 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       }
     }
   }
+  tk[tn++] = (long long)__builtin_readcyclecounter();
+  for (int k = 0; k < 6; ++k) O.dbg[k] = (int32_t)((tk[k + 1] - tk[k]) >> 4);
   if (threadIdx.x == 0) outs[blockIdx.x] = O;
 }
 

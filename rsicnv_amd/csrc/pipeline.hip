@@ -114,7 +114,7 @@ struct rsi_ctx {
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
   int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
-  bool gate_shared = true;    // bin-level kernels wait while a streaming phase runs (RSI_HOT_ISOLATE_STREAMING=0 disables)
+  bool gate_shared = false;   // RSI_HOT_ISOLATE_STREAMING=1: bin-level kernels wait while a per-base phase runs (clean kernel timings, ~20 % less throughput)
 };
 
 namespace {
@@ -386,6 +386,11 @@ class DeviceTester : public rsih::NeighbourTester {
       if (!wait()) return false;
       gs.release();
       ph.stop();
+      if (getenv("RSI_CAND_DBG")) {
+        long long tot[6] = {0, 0, 0, 0, 0, 0}; size_t big = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) { for (int q = 0; q < 6; ++q) tot[q] += outs[k].dbg[q]; if (jobs[k].capacity > jobs[big].capacity) big = k; }
+        fprintf(stderr, "[cand dbg] jobs %zu sum/16: left %lld right %lld thin %lld body %lld prefix %lld means %lld | biggest cap %d nref %d: %d %d %d %d %d %d\n", jobs.size(), tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], jobs[big].capacity, outs[big].nref, outs[big].dbg[0], outs[big].dbg[1], outs[big].dbg[2], outs[big].dbg[3], outs[big].dbg[4], outs[big].dbg[5]);
+      }
       for (size_t k = 0; k < jobs.size(); ++k) {
         const CandOut& O = outs[k];
         if (O.flags != 0) continue;
@@ -547,15 +552,33 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(hipMemcpyAsync(hT.data(), d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(hst.data(), d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(CTX_SYNC());
+  { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
   {
-    int lo = hst[0], hi = hst[0];
-    for (int64_t i = 0; i < nb; ++i) { lo = std::min(lo, hst[i]); hi = std::max(hi, hst[i]); }
+    Phase phs(ctx, "fs.sums");
+    // status values lie in [-Lmax, Lmax]; the unmarked level (almost every bin) is summed in a register.
+    // The level range the reference works on is [min status, max status]: taken from the counts afterwards.
+    std::vector<float> wsum((size_t)(2 * Lmax + 1), 0.0f);
+    std::vector<int> wcnt((size_t)(2 * Lmax + 1), 0);
+    {
+      float s0 = 0.0f;
+      int n0 = 0;
+      const int* st = hst.data();
+      const float* tv = hT.data();
+      for (int64_t i = 0; i < nb; ++i) {
+        const int s = st[i];
+        if (s == 0) { s0 += tv[i]; ++n0; }
+        else { wsum[s + Lmax] += tv[i]; ++wcnt[s + Lmax]; }
+      }
+      wsum[Lmax] = s0; wcnt[Lmax] = n0;
+    }
+    int lo = 0, hi = 0;
+    { int a = 0, b = 2 * Lmax; while (a < b && wcnt[a] == 0) ++a; while (b > a && wcnt[b] == 0) --b; lo = a - Lmax; hi = b - Lmax; }
     const int nl = hi - lo + 1;
-    std::vector<float> lsum((size_t)nl, 0.0f);
-    std::vector<int> lcnt((size_t)nl, 0);
-    for (int64_t i = 0; i < nb; ++i) { lsum[hst[i] - lo] += hT[i]; ++lcnt[hst[i] - lo]; }
+    std::vector<float> lsum(wsum.begin() + (lo + Lmax), wsum.begin() + (hi + Lmax + 1));
+    std::vector<int> lcnt(wcnt.begin() + (lo + Lmax), wcnt.begin() + (hi + Lmax + 1));
     for (int l = 0; l < nl; ++l) if (lcnt[l] != 0) lsum[l] /= (double)lcnt[l];
+    phs.stop();
+    Phase phr(ctx, "fs.runs");
     if (lo <= 0 && -lo < nl) {
       const float m0 = lsum[-lo];
       int leveldel = lo, leveladd = hi;
@@ -1176,7 +1199,7 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
     }
     c->gate = &pool->gate;
     const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
-    c->gate_shared = !(iso && iso[0] == '0');   // default on; RSI_HOT_ISOLATE_STREAMING=0 lets everything overlap
+    c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
     pool->workers.push_back(c);
   }
   if (status) *status = RSI_OK;

@@ -35,7 +35,7 @@ def main():
         name, _, spec = v.partition(":")
         kv = dict(x.split("=", 1) for x in spec.split(",") if x)
         w = int(kv.pop("workers", 12))
-        iso = kv.get("RSI_HOT_ISOLATE_STREAMING", "1")
+        iso = kv.get("RSI_HOT_ISOLATE_STREAMING", "0")
         key = (w, iso)
         if key not in pools:
             os.environ["RSI_HOT_ISOLATE_STREAMING"] = iso
