@@ -38,18 +38,21 @@ void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_e
 // worker's first chromosome no hipFree/hipMalloc -- a device-wide synchronisation that stalls every
 // other worker, and slow on recycled VRAM -- happens in steady state.
 thread_local double tl_grow = 1.0;
+thread_local double tl_grow_ms = 0.0;   // time this thread spent re-allocating during the current run
 
 struct DevBuf {   // grow-only device allocation
   void* p = nullptr;
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     const size_t scaled = (size_t)((double)bytes * tl_grow);
     const size_t want = scaled + scaled / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    tl_grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return e;
   }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -58,19 +61,27 @@ struct DevBuf {   // grow-only device allocation
 
 struct KernelTime { const char* name; hipEvent_t a, b; };
 
-// One GPU, several workers.  The HBM-bound per-base phase of a chromosome takes the gate
-// exclusively, so that each streaming launch has the whole chip and memory system (and its
-// HIP-event time is a clean roofline sample); bin-level kernels of other chromosomes share it.
-// Waiting streamers hold back new sharers, so the streaming phases are never starved.
+// One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
+// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
+// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
+// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
+// a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
+// sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
 struct GpuGate {
   std::mutex m;
   std::condition_variable cv;
-  int sharers = 0, streamers_waiting = 0;
-  bool streaming = false;
-  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !streaming && streamers_waiting == 0; }); ++sharers; }
+  int sharers = 0, streamers_waiting = 0, streaming = 0;
+  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
+  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
   void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
-  void lock() { std::unique_lock<std::mutex> lk(m); ++streamers_waiting; cv.wait(lk, [&] { return !streaming && sharers == 0; }); --streamers_waiting; streaming = true; }
-  void unlock() { { std::lock_guard<std::mutex> lk(m); streaming = false; } cv.notify_all(); }
+  void lock(bool exclude_sharers) {
+    std::unique_lock<std::mutex> lk(m);
+    ++streamers_waiting;
+    cv.wait(lk, [&] { return exclude_sharers ? (streaming == 0 && sharers == 0) : streaming < max_streamers; });
+    --streamers_waiting;
+    ++streaming;
+  }
+  void unlock() { { std::lock_guard<std::mutex> lk(m); --streaming; } cv.notify_all(); }
 };
 
 double now_ms() {
@@ -696,6 +707,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->event_next = 0;
   ctx->phases.clear();
   tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
+  tl_grow_ms = 0.0;
   // The per-base kernels are HBM-bound: workers of a pool take turns through this phase (GpuGate).
   struct StreamTurn {
     GpuGate* g = nullptr;
@@ -704,7 +716,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   } hbm_turn;
   if (ctx->gate) {
     Phase ph_wait(ctx, "wait.hbm_turn");
-    ctx->gate->lock();
+    ctx->gate->lock(ctx->gate_shared);
     hbm_turn.g = ctx->gate;
   }
   Phase ph_a1(ctx, "a1.classify+nruns");
@@ -1011,6 +1023,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     for (size_t i = 0; i < lists[w]->size(); ++i) to_call((*lists[w])[i], &res->lists[w][i]);
   }
   HIPCHK(CTX_SYNC());
+  ctx->phases.push_back({"mem.grow", tl_grow_ms});
   S.t_device_ms = now_ms() - t_begin;
   if (ctx->timing) {
     double tot = 0;
@@ -1198,6 +1211,7 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
       return nullptr;
     }
     c->gate = &pool->gate;
+    if (const char* ms = getenv("RSI_HOT_STREAMERS")) pool->gate.max_streamers = std::max(1, atoi(ms));
     const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
     c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
     pool->workers.push_back(c);
@@ -1228,7 +1242,7 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
     for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
-  std::atomic<int> next(0);
+  std::atomic<int> next(std::min<int>(nchrom, (int)pool->workers.size()));
   std::vector<int> rcs((size_t)nchrom, RSI_OK);
   std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
   std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
@@ -1238,8 +1252,13 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
   std::mutex trace_mu;
   auto work = [&](size_t w) {
     rsi_ctx* ctx = pool->workers[w];
+    bool first = true;
     for (;;) {
-      const int k = next.fetch_add(1);
+      // the W longest chromosomes always go to the same workers (rank k -> worker k): a context then
+      // meets its biggest workload in the first batch and never has to grow its workspace again
+      int k;
+      if (first && (int)w < nchrom) { k = (int)w; first = false; }
+      else { first = false; k = next.fetch_add(1); }
       if (k >= nchrom) break;
       const int i = order[(size_t)k];
       out[i] = nullptr;

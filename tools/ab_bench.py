@@ -35,10 +35,15 @@ def main():
         name, _, spec = v.partition(":")
         kv = dict(x.split("=", 1) for x in spec.split(",") if x)
         w = int(kv.pop("workers", 12))
-        iso = kv.get("RSI_HOT_ISOLATE_STREAMING", "0")
-        key = (w, iso)
+        iso = kv.pop("RSI_HOT_ISOLATE_STREAMING", "0")
+        ms = kv.pop("RSI_HOT_STREAMERS", "")
+        key = (w, iso, ms)
         if key not in pools:
             os.environ["RSI_HOT_ISOLATE_STREAMING"] = iso
+            if ms:
+                os.environ["RSI_HOT_STREAMERS"] = ms
+            else:
+                os.environ.pop("RSI_HOT_STREAMERS", None)
             pools[key] = api.RsiPool(0, w)
             pools[key].set_timing(True)
         variants.append((name, pools[key], kv))
@@ -47,15 +52,28 @@ def main():
     tables = {name: api.RsiBatchTimes() for name, _, _ in variants}
     calls = {}
 
+    def throttled():
+        try:
+            d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0))
+        except Exception:
+            return 0, 0, 0
+
+    notes = {name: [] for name, _, _ in variants}
+
     def run(name, pool, kv, timed):
         for k in keys:
             os.environ[k] = kv.get(k, "0")
         pool.times = tables[name]
         torch.cuda.synchronize()
+        th0 = throttled()
         t0 = time.perf_counter()
         res = pool.run(params, chrom_args, collect_times=timed)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
+        th1 = throttled()
+        if timed:
+            notes[name].append(f"{dt:.0f}ms:thr{th1[0]-th0[0]}/{(th1[1]-th0[1])/1e3:.0f}ms/cpu{(th1[2]-th0[2])/1e3/dt:.1f}")
         sig = tuple((len(r.calls("calls")), r.stats["RDmedian"]) for r in res)
         full = [[(c["start"], c["end"], c["type"]) for c in r.calls("calls")] for r in res]
         calls.setdefault("ref", full)
@@ -72,6 +90,8 @@ def main():
     for name, pool, kv in variants:
         t = times[name]
         print(f"{name:>16s}: mean {sum(t)/len(t):7.2f} ms  min {min(t):7.2f}  max {max(t):7.2f}   ({' '.join(f'{x:.0f}' for x in t)})", flush=True)
+    for name, _, _ in variants:
+        print(f"    {name} steps (wall : throttled periods / throttled thread-ms / mean busy CPUs): " + " ".join(notes[name]), flush=True)
     if args.phases:
         for name, pool, kv in variants:
             n = len(times[name])
