@@ -56,8 +56,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config (1-based as in SURVEY 8d): 2, 3, 4 or 5")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink chromosome lengths (debug only; invalidates the metric)")
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
@@ -150,20 +150,42 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events on the library's streams, timed region) ----
     per_kernel = pool.kernel_table()      # name -> (sum ms, launches, sum of chromosome lengths)
+
+    def kernel_roofline(table, name):
+        ms, cnt, bases = table[name]
+        byts = ALGO_BYTES_PER_BASE[name] * bases
+        achieved = byts / (ms * 1e-3) / 1e9
+        return ms, cnt, bases, byts, achieved
+
     roofline = None
     streaming = [k for k in per_kernel if k in ALGO_BYTES_PER_BASE]
     if streaming:
         dom = max(streaming, key=lambda k: per_kernel[k][0])
-        ms, cnt, bases = per_kernel[dom]
-        byts = ALGO_BYTES_PER_BASE[dom] * bases
-        achieved = byts / (ms * 1e-3) / 1e9
+        ms, cnt, bases, byts, achieved = kernel_roofline(per_kernel, dom)
         tpb = pmc_traffic_per_base(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": None if tpb is None else round(tpb * bases / cnt),
                     "avg_launch_ms": round(ms / cnt, 4), "launches": int(cnt),
                     "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[dom],
-                    "algorithmic_bytes_per_launch": round(byts / cnt)}
+                    "algorithmic_bytes_per_launch": round(byts / cnt),
+                    "measured": "in situ: the timed steps, with the bin-level kernels of up to "
+                                f"{args.workers - 1} other chromosomes and a second per-base phase sharing the GPU"}
+        # The same kernel with the per-base phases run alone on the chip (rsi_pool_set_schedule isolate=1):
+        # one extra, untimed genome pass; `value` above does not include it.
+        pool.set_schedule(isolate=True)
+        timed_tables = (pool.times, )
+        pool.reset_times()
+        fence()
+        step(timed=True)
+        fence()
+        iso = pool.kernel_table()
+        pool.set_schedule(isolate=False)
+        if dom in iso:
+            ims, icnt, ibases, ibyts, iach = kernel_roofline(iso, dom)
+            roofline["isolated"] = {"achieved": round(iach, 1), "frac": round(iach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ims / icnt, 4),
+                                    "launches": int(icnt), "note": "same launches with the chip to themselves (untimed extra pass)"}
+        pool.times = timed_tables[0]
     kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
     phase_ms = pool.phase_table()
 

@@ -152,6 +152,11 @@ void rsi_pool_destroy(rsi_pool* pool);
 int rsi_pool_workers(const rsi_pool* pool);
 rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w);
 void rsi_pool_set_timing(rsi_pool* pool, int on);
+/* Scheduling of the pool's workers on the GPU.  isolate != 0: a chromosome's per-base (HBM-bound) phase runs
+ * alone on the chip -- bin-level work of the other workers waits -- so that every streaming launch is a clean
+ * bandwidth sample (profiling); 0 (default): bin-level work overlaps it (about 20 % more throughput).
+ * streamers: per-base phases allowed in flight at once (default 2; ignored while isolating). */
+void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers);
 const char* rsi_pool_last_error(const rsi_pool* pool);
 /* d_depth[i], d_fasta[i], n[i]: chromosome i, resident in HBM.  out[i] receives its result (or NULL),
  * status[i] (optional) its rsi_status; returns the first failure or RSI_OK.  times may be NULL. */

@@ -1229,6 +1229,12 @@ void rsi_pool_destroy(rsi_pool* pool) {
 int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
 rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
 void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) c->timing = on != 0; }
+void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
+  if (!pool) return;
+  std::lock_guard<std::mutex> lk(pool->gate.m);
+  for (rsi_ctx* c : pool->workers) c->gate_shared = isolate != 0;
+  if (streamers >= 1) pool->gate.max_streamers = streamers;
+}
 const char* rsi_pool_last_error(const rsi_pool* pool) { return pool ? pool->err.c_str() : g_last_error.c_str(); }
 
 int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
