@@ -43,6 +43,11 @@ void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n
 // adjust=0 copies depth through unchanged (the -NOGC path only needs the histogram).
 // hist[kHistValues] counts output values < kHistValues; *big counts the rest, *vmax their maximum.
 struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int negatives; };
+// Median walk of partition_stat_tp (wufunctions.cpp:398-420, dy = 1) over hist[kHistValues] for `total` values, on the device:
+// inrange = sum of the counters, lo / hi = smallest / largest value present (lo > hi: none), med = the bucket where the
+// cumulated count first reaches total/2 (-1: never).
+struct ValueMedian { unsigned long long inrange; int32_t lo, hi, med, pad; };
+void launch_value_median(const uint32_t* hist, uint64_t total, ValueMedian* out, hipStream_t stream);
 size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream);
@@ -157,7 +162,6 @@ struct CandOut {
   int32_t nref, nbody, nwin, left_reach, right_reach, body_min, body_max;
   double body_q[3], body_s1, body_s2;   // lower quartile / median / upper quartile (partition_stat_tp), sum, sum of squares
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
-  int32_t dbg[6];
 };
 void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
 // one launch = one call of optimize_with_derivative for every job; part_v / part_i: sharpen_part_slots(njobs) entries, done: njobs

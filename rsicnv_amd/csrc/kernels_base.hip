@@ -823,6 +823,42 @@ void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t 
   hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, rdmean, adjust, out, hist, aux);
 }
 
+// one workgroup of 1024 threads, 64 consecutive counters each
+__global__ __launch_bounds__(1024) void k_value_median(const uint32_t* __restrict__ hist, unsigned long long total,
+                                                       ValueMedian* __restrict__ out) {
+  __shared__ unsigned long long s_w[16];
+  __shared__ int s_lo[16], s_hi[16], s_med;
+  constexpr int kPer = kHistValues / 1024;
+  const int v0 = threadIdx.x * kPer;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long local = 0;
+  int lo = 0x7fffffff, hi = -1;
+  for (int v = v0; v < v0 + kPer; ++v) { const uint32_t c = hist[v]; local += c; if (c) { lo = v < lo ? v : lo; hi = v; } }
+  unsigned long long incl = local;
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+  int wlo = lo, whi = hi;
+  for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(wlo, d), b = __shfl_xor(whi, d); wlo = a < wlo ? a : wlo; whi = b > whi ? b : whi; }
+  if (lane == 63) s_w[wave] = incl;
+  if (lane == 0) { s_lo[wave] = wlo; s_hi[wave] = whi; }
+  if (threadIdx.x == 0) s_med = -1;
+  __syncthreads();
+  unsigned long long base = 0, all = 0;
+  int glo = 0x7fffffff, ghi = -1;
+  for (int w = 0; w < 16; ++w) { if (w < wave) base += s_w[w]; all += s_w[w]; glo = s_lo[w] < glo ? s_lo[w] : glo; ghi = s_hi[w] > ghi ? s_hi[w] : ghi; }
+  const unsigned long long r2 = total / 2;
+  unsigned long long seen = base + incl - local;
+  for (int v = v0; v < v0 + kPer; ++v) {
+    const unsigned long long upto = seen + hist[v];
+    if (seen < r2 && upto >= r2) s_med = v;
+    seen = upto;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { out->inrange = all; out->lo = glo; out->hi = ghi; out->med = s_med; out->pad = 0; }
+}
+void launch_value_median(const uint32_t* hist, uint64_t total, ValueMedian* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_value_median, dim3(1), dim3(1024), 0, stream, hist, (unsigned long long)total, out);
+}
+
 static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {
   TB = 64;   // bins per tile: as many as fit ~48 KB of values, 4..64, power of two
   while (TB > 4 && (size_t)TB * m * 4 > 48 * 1024) TB >>= 1;

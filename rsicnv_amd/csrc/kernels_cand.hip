@@ -170,66 +170,108 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __res
 // Neighbourhood test.  See CandJob in kernels.h for what the host prepares.
 constexpr int kWalkBlock = 4 * kTestThreads;   // positions examined per trip of a walk
 
-struct WalkShared { int s_scan[kMaxWaves]; int s_red[kMaxWaves]; };
+// s_scan doubles as scratch of hist_ranks; the rest is the walk's per-trip exchange, double-buffered by trip parity
+struct WalkShared { int s_scan[kMaxWaves]; int cnt[2][kMaxWaves]; int trg[2][kMaxWaves]; int kept[2]; int lastt[2]; };
 
 // One side of the reference gather (rsi.cpp:206-257).  dir = -1: left of the candidate, values land
 // in dst[fill], dst[fill-1], ...; dir = +1: right, values land in dst[used], dst[used+1], ...
 // Returns the number of values stored; *reach = last position examined.
+// A trip examines kWalkBlock positions in walk order (four consecutive ones per thread): which are
+// taken (not extreme, not inside the neighbour the walk is about to meet), and where the walk first
+// steps into that neighbour (the trigger, rsi.cpp:222-228 / 246-252: everything after it is dropped
+// and the walk jumps).  One barrier per trip: the waves exchange their taken-counts and triggers; a
+// second one only when there is a trigger, a third when the slots run out.
 __device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int dir, int pos, int room /* slots left */,
                                   int32_t* __restrict__ dst, int first_slot, const int2* __restrict__ chain, int nchain,
                                   int kind, double too_high, double too_low, WalkShared& W, int* reach, int* chain_used) {
-  int stored = 0, ci = 0;
+  constexpr int kNone = 0x7fffffff;
+  int stored = 0, ci = 0, trip = 0;
   int last = pos;
+  const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // the values of a trip are loaded one trip ahead (the walk continues straight on unless it meets a
+  // neighbour, which is rare): addresses are clamped, positions beyond the trip are masked when used
+  auto load4 = [&](int from, int* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long p = (long long)from + (long long)dir * (1 + 4 * (int)threadIdx.x + j);
+      p = p < 0 ? 0 : (p > N - 1 ? N - 1 : p);
+      out[j] = A[p];
+    }
+  };
+  int vnext[4];
+  load4(pos, vnext);
   while (room > 0 && (dir < 0 ? pos > 2 : (int64_t)pos < N - 2)) {
+    const int par = trip & 1;
+    ++trip;
     // positions of this trip in walk order: p_t = pos + dir*(1+t)
     const int avail = dir < 0 ? pos - 2 : (int)(N - 2 - pos);     // how many positions the walk may still visit
     const int cnt = avail < kWalkBlock ? avail : kWalkBlock;
     const int2 cur = ci < nchain ? chain[ci] : make_int2(1, 0);   // empty interval when the chain is used up
-    int v[4]; bool acc[4]; int nacc = 0; int trig = 0x7fffffff;
+    int v[4]; bool acc[4]; int nacc = 0; int trig = kNone;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = vnext[j];
+    load4(pos + dir * cnt, vnext);                                 // next trip, if the walk goes straight on
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = 4 * threadIdx.x + j;
-      acc[j] = false; v[j] = 0;
+      acc[j] = false;
       if (t < cnt) {
         const int p = pos + dir * (1 + t);
-        v[j] = A[p];
         const bool ext = kind == 0 ? ((double)v[j] > too_high) : (kind == 1 ? ((double)v[j] < too_low) : false);
         const bool inside = p >= cur.x && p <= cur.y;
         if (!ext && inside && t < trig) trig = t;
         acc[j] = !ext && !inside;
+        nacc += acc[j];
       }
     }
-    const int tstar = block_reduce(trig, [](int a, int b) { return a < b ? a : b; }, W.s_red);
+    int incl = nacc, wtrig = trig;
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(wtrig, d); wtrig = o < wtrig ? o : wtrig; }
+    if (lane == 63) W.cnt[par][wave] = incl;
+    if (lane == 0) W.trg[par][wave] = wtrig;
+    __syncthreads();
+    int base = 0, all = 0, tstar = kNone;
+    for (int w = 0; w < nwaves; ++w) { const int c = W.cnt[par][w]; if (w < wave) base += c; all += c; const int g = W.trg[par][w]; tstar = g < tstar ? g : tstar; }
+    int rank = base + incl - nacc;             // rank of this thread's first taken value if nothing were dropped
+    int total = all;
+    if (tstar != kNone) {                       // values taken before the trigger = the trigger position's rank
+      if ((int)threadIdx.x == (tstar >> 2)) {
+        int k = rank;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { if (4 * (int)threadIdx.x + j >= tstar) acc[j] = false; nacc += acc[j]; }
-    int total;
-    int rank = block_exscan(nacc, W.s_scan, &total);
-    int my_last_t = -1;
+        for (int j = 0; j < 4; ++j) if (acc[j] && 4 * (int)threadIdx.x + j < tstar) ++k;
+        W.kept[par] = k;
+      }
+      __syncthreads();
+      total = W.kept[par];
+    }
+    const bool fills = total >= room;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (acc[j]) {
-        if (rank < room) { dst[first_slot + dir * (stored + rank)] = v[j]; my_last_t = 4 * threadIdx.x + j; }
+      const int t = 4 * (int)threadIdx.x + j;
+      if (acc[j] && t < tstar) {
+        if (rank < room) dst[first_slot + dir * (stored + rank)] = v[j];
+        if (fills && rank == room - 1) W.lastt[par] = t;      // the value that fills the last slot
         ++rank;
       }
     }
-    const int take = total < room ? total : room;
-    if (total >= room) {
-      // the walk stops right after the value that filled the last slot
-      const int tl = block_reduce(my_last_t, [](int a, int b) { return a > b ? a : b; }, W.s_red);
-      last = pos + dir * (1 + tl);
-      stored += take; room = 0;
+    if (fills) {   // the walk stops right after the value that filled the last slot
+      __syncthreads();
+      last = pos + dir * (1 + W.lastt[par]);
+      stored += room; room = 0;
       break;
     }
-    stored += take; room -= take;
-    if (tstar != 0x7fffffff) {      // jump over the neighbour (rsi.cpp:222-228 / 246-252)
+    stored += total; room -= total;
+    if (tstar != kNone) {      // jump over the neighbour
       last = pos + dir * (1 + tstar);
       pos = dir < 0 ? cur.x - 1 : cur.y + 1;
       ++ci;
+      load4(pos, vnext);       // the prefetch was for the straight continuation
     } else {
       pos += dir * cnt;
       last = pos;
     }
   }
+  __syncthreads();   // the next user of W (or of dst) starts from a quiet block
   *reach = last;
   *chain_used = ci;
   return stored;
@@ -272,11 +314,10 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   const CandJob J = jobs[blockIdx.x];
   CandOut O;
   O.flags = 0;
-  long long tk[8]; int tn = 0;
-  tk[tn++] = (long long)__builtin_readcyclecounter();
-  int32_t* left = iscratch + J.iscratch_off;              // J.top + 1 slots
-  int32_t* ref = left + (J.top + 1 > 0 ? J.top + 1 : 0);  // J.capacity slots
-  int32_t* thin = ref + J.capacity;                       // min(capacity, budget) slots
+  // every piece starts on a 16-byte boundary (the host sizes the scratch the same way, cand_scratch_ints)
+  int32_t* left = iscratch + J.iscratch_off;                          // J.top + 1 slots
+  int32_t* ref = left + (((J.top + 1 > 0 ? J.top + 1 : 0) + 3) & ~3);  // J.capacity slots
+  int32_t* thin = ref + ((J.capacity + 3) & ~3);                      // min(capacity, budget) slots
   long long* P = lscratch + J.lscratch_off;               // capacity + 1
   const double too_high = RDmedian * 3.0, too_low = RDmedian * 0.15;
 
@@ -286,7 +327,6 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   if (J.top >= 0)
     lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
   __syncthreads();
-  tk[tn++] = (long long)__builtin_readcyclecounter();
   // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
   const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
   for (int j = threadIdx.x; j < used0; j += kTestThreads) ref[j] = left[J.top + 1 - used0 + j];
@@ -301,7 +341,6 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   __syncthreads();
   // a chain the host cut short was consumed to its end: the walk may have missed a neighbour
   if (((J.cut & 1) && lused >= J.nleft) || ((J.cut & 2) && rused >= J.nright)) O.flags |= 8;
-  tk[tn++] = (long long)__builtin_readcyclecounter();
   int nref = used0 + rcnt;
   int nbody = J.end - J.start + 1;
   // ---- thinning to about `budget` points (rsi.cpp:264-282) ----
@@ -325,7 +364,6 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   O.nref = nref; O.nbody = nbody_eff; O.nwin = nwin; O.left_reach = lreach; O.right_reach = rreach;
   if (nwin <= 0 || width <= 0) { O.flags |= 1; if (threadIdx.x == 0) outs[blockIdx.x] = O; return; }
 
-  tk[tn++] = (long long)__builtin_readcyclecounter();
   // ---- body statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
   {
     int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
@@ -353,15 +391,45 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       }
     }
   }
-  tk[tn++] = (long long)__builtin_readcyclecounter();
   // ---- running mean of width `width` over the neighbourhood (rsi.cpp:113-124): exact prefix, float means ----
-  block_prefix_i64(P, nref, [&](int e) { return (long long)R[e]; }, s_l);
-  tk[tn++] = (long long)__builtin_readcyclecounter();
+  {   // tiles of four consecutive values per thread: one 16-byte load, one block scan per 4096 values
+    long long carry = 0;
+    if (threadIdx.x == 0) P[0] = 0;
+    for (int t0 = 0; t0 < nref; t0 += 4 * kTestThreads) {
+      const int e = t0 + 4 * (int)threadIdx.x;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (e + 3 < nref) v = *reinterpret_cast<const int4*>(R + e);
+      else { if (e < nref) v.x = R[e]; if (e + 1 < nref) v.y = R[e + 1]; if (e + 2 < nref) v.z = R[e + 2]; }
+      const long long a1 = v.x, a2 = a1 + v.y, a3 = a2 + v.z, a4 = a3 + v.w;
+      long long total;
+      const long long b = carry + block_exscan_i64(a4, s_l, &total);
+      if (e < nref) P[e + 1] = b + a1;
+      if (e + 1 < nref) P[e + 2] = b + a2;
+      if (e + 2 < nref) P[e + 3] = b + a3;
+      if (e + 3 < nref) P[e + 4] = b + a4;
+      carry += total;
+    }
+    __syncthreads();
+  }
   const double dw = (double)width;
-  auto wmean = [&](int i) -> float { return (float)((double)(P[i + width] - P[i]) / dw); };
+  // the means are kept (as floats, over the neighbourhood values, which are not needed any more) for the histogram pass
+  float* Wm = reinterpret_cast<float*>(ref);
   {
     float flo = 3.0e38f, fhi = -3.0e38f; double m1 = 0, m2 = 0;
-    for (int i = threadIdx.x; i < nwin; i += kTestThreads) { const float w = wmean(i); flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w; }
+    for (int i = threadIdx.x; i < nwin; i += 4 * kTestThreads) {
+      long long hi4[4], lo4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int q = i + k * kTestThreads; const int qq = q < nwin ? q : i; hi4[k] = P[qq + width]; lo4[k] = P[qq]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = i + k * kTestThreads;
+        if (q < nwin) {
+          const float w = (float)((double)(hi4[k] - lo4[k]) / dw);
+          Wm[q] = w;
+          flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w;
+        }
+      }
+    }
     flo = block_reduce(flo, [](float a, float b) { return a < b ? a : b; }, s_f);
     fhi = block_reduce(fhi, [](float a, float b) { return a > b ? a : b; }, s_f);
     m1 = block_reduce(m1, [](double a, double b) { return a + b; }, s_d);
@@ -375,9 +443,28 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       else {
         for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < nwin; i += kTestThreads) {
-          const double idx = ((double)wmean(i) - lo) / 0.01 + 0.5;   // wufunctions.cpp:396
-          atomicAdd(&s_hist[(unsigned)(unsigned long long)idx], 1u);
+        // neighbouring windows differ by one value in `width`, so their means mostly share a bucket:
+        // every thread takes eight consecutive means and merges equal buckets before touching LDS
+        for (int i0 = 8 * (int)threadIdx.x; i0 < nwin; i0 += 8 * kTestThreads) {
+          float w8[8];
+          if (i0 + 7 < nwin) {
+            const float4 a = *reinterpret_cast<const float4*>(Wm + i0), b = *reinterpret_cast<const float4*>(Wm + i0 + 4);
+            w8[0] = a.x; w8[1] = a.y; w8[2] = a.z; w8[3] = a.w; w8[4] = b.x; w8[5] = b.y; w8[6] = b.z; w8[7] = b.w;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w8[k] = Wm[i0 + k < nwin ? i0 + k : i0];
+          }
+          unsigned pend_b = 0xffffffffu, pend_c = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (i0 + k < nwin) {
+              const double idx = ((double)w8[k] - lo) / 0.01 + 0.5;   // wufunctions.cpp:396
+              const unsigned bkt = (unsigned)(unsigned long long)idx;
+              if (bkt != pend_b) { if (pend_c) atomicAdd(&s_hist[pend_b], pend_c); pend_b = bkt; pend_c = 0; }
+              ++pend_c;
+            }
+          }
+          if (pend_c) atomicAdd(&s_hist[pend_b], pend_c);
         }
         __syncthreads();
         int qb[3];
@@ -389,8 +476,6 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       }
     }
   }
-  tk[tn++] = (long long)__builtin_readcyclecounter();
-  for (int k = 0; k < 6; ++k) O.dbg[k] = (int32_t)((tk[k + 1] - tk[k]) >> 4);
   if (threadIdx.x == 0) outs[blockIdx.x] = O;
 }
 

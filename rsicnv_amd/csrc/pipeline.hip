@@ -119,6 +119,7 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
+  double h_gc_table[256];     // GC table of the running chromosome (kGcLevels entries)
   std::vector<float> h_T;     // host copies of the bin arrays for filterstatus, grow-only
   std::vector<int> h_status;
   int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
@@ -168,6 +169,7 @@ constexpr size_t kOffBinAcc = 4352;                               // BinAccum
 constexpr size_t kOffMinMax = 4608;                               // MinMaxF
 constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
 constexpr size_t kOffRawMin = 5120;                               // uint32
+constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
 constexpr size_t kOffTable = 5376;                                // double[202]
 constexpr size_t kOffLevelHist = 8192;                            // uint32[4096]
 constexpr size_t kOffBreaks = 8192 + 16384;                       // int64 cbreak[4096], cum[4097]
@@ -270,15 +272,21 @@ void scan_thresholds(double tmedian, double tlamda, int Lmax, std::vector<double
 // Collect (pos << 1 | is_end) boundary entries from the device into sorted [start, end] pairs.
 int fetch_pairs(rsi_ctx* ctx, const uint64_t* d_list, const uint32_t* d_count, uint32_t cap, std::vector<Region>& out,
                 bool end_exclusive) {
+  // the count and the first entries travel together (one round trip for all but the longest lists)
+  constexpr uint32_t kEager = 1024;
   uint32_t cnt = 0;
+  std::vector<uint64_t> raw(kEager);
   HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(raw.data(), d_list, (size_t)std::min(cap, kEager) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(CTX_SYNC());
   out.clear();
   if (cnt == 0) return RSI_OK;
   if (cnt > cap) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
-  std::vector<uint64_t> raw(cnt);
-  HIPCHK(hipMemcpyAsync(raw.data(), d_list, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(CTX_SYNC());
+  raw.resize(cnt);
+  if (cnt > kEager) {
+    HIPCHK(hipMemcpyAsync(raw.data() + kEager, d_list + kEager, (size_t)(cnt - kEager) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(CTX_SYNC());
+  }
   std::vector<int64_t> s, e;
   for (uint64_t v : raw) ((v & 1) ? e : s).push_back((int64_t)(v >> 1));
   if (s.size() != e.size()) return fail(ctx, RSI_ERR_INTERNAL, "unbalanced run boundaries");
@@ -359,8 +367,9 @@ class DeviceTester : public rsih::NeighbourTester {
       for (; last < n; ++last) {
         const rsih::TestPlan& T = plans[last];
         if (T.capacity <= 0 || T.end < T.start || T.start < 0 || T.end >= N) break;   // left to the host path (ok stays 0)
-        const size_t iw = (size_t)std::max(T.top + 1, 0) + (size_t)T.capacity + (size_t)std::min(T.capacity, T.budget);
-        const size_t lw = (size_t)T.capacity + 1;
+        auto up4 = [](size_t x) { return (x + 3) & ~(size_t)3; };   // the kernel wants every piece on a 16-byte boundary
+        const size_t iw = up4((size_t)std::max(T.top + 1, 0)) + up4((size_t)T.capacity) + up4((size_t)std::min(T.capacity, T.budget));
+        const size_t lw = up4((size_t)T.capacity + 1);
         if (!jobs.empty() && (iwords + iw) * 4 + (lwords + lw) * 8 > kCandScratchBytes) break;
         CandJob J{};
         J.start = T.start; J.end = T.end; J.kind = T.kind; J.margin = T.margin; J.capacity = T.capacity; J.top = T.top;
@@ -397,11 +406,6 @@ class DeviceTester : public rsih::NeighbourTester {
       if (!wait()) return false;
       gs.release();
       ph.stop();
-      if (getenv("RSI_CAND_DBG")) {
-        long long tot[6] = {0, 0, 0, 0, 0, 0}; size_t big = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) { for (int q = 0; q < 6; ++q) tot[q] += outs[k].dbg[q]; if (jobs[k].capacity > jobs[big].capacity) big = k; }
-        fprintf(stderr, "[cand dbg] jobs %zu sum/16: left %lld right %lld thin %lld body %lld prefix %lld means %lld | biggest cap %d nref %d: %d %d %d %d %d %d\n", jobs.size(), tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], jobs[big].capacity, outs[big].nref, outs[big].dbg[0], outs[big].dbg[1], outs[big].dbg[2], outs[big].dbg[3], outs[big].dbg[4], outs[big].dbg[5]);
-      }
       for (size_t k = 0; k < jobs.size(); ++k) {
         const CandOut& O = outs[k];
         if (O.flags != 0) continue;
@@ -788,20 +792,19 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     if (acc.negatives & 1u) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112
     if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
-    double table[kGcLevels];
+    double* table = ctx->h_gc_table;   // context-owned: the upload below may still be reading it when this scope ends
     for (int g = 0; g < kGcLevels; ++g) {                     // gccontent.cpp:141-145
       table[g] = acc.cnt[g] > 0 ? (double)acc.sum[g] / double(acc.cnt[g]) : rdmean;
       if (table[g] < 1) table[g] = rdmean;
     }
     S.gc_rdmean = rdmean;
     double* d_table = reinterpret_cast<double*>(small + kOffTable);
-    HIPCHK(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_table, table, sizeof(double) * kGcLevels, hipMemcpyHostToDevice, st));
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
     { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
     { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
     { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
-    HIPCHK(CTX_SYNC());   // table[] leaves scope
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   } else if (want_cap) {
@@ -816,19 +819,20 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   // ---- A4: cap from the median of the uncompacted array (loaddata.cpp:229-240, Q15) ----
   int32_t capval = 0x7fffffff;
   if (want_cap) {
-    std::vector<uint32_t> h32(kHistValues);
+    // the median walk runs on the device (one small workgroup): 24 bytes come back instead of the 256 KB histogram
     ValueHistAux aux;
-    HIPCHK(hipMemcpyAsync(h32.data(), ctx->hist_val.p, (size_t)kHistValues * 4, hipMemcpyDeviceToHost, st));
+    ValueMedian vm;
+    ValueMedian* d_vm = reinterpret_cast<ValueMedian*>(small + kOffValMedian);
+    { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
+    HIPCHK(hipMemcpyAsync(&vm, d_vm, sizeof(vm), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&aux, d_aux, sizeof(aux), hipMemcpyDeviceToHost, st));
     HIPCHK(CTX_SYNC());
     if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
-    std::vector<uint64_t> h(h32.begin(), h32.end());
-    uint64_t inrange = 0;
-    for (uint64_t c : h) inrange += c;
-    if (inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
-    if ((uint64_t)n / 2 > inrange) return fail(ctx, RSI_ERR_UNSUPPORTED, "median depth above 65535");
-    rsih::Quantiles q;
-    int_quantiles(h, (uint64_t)n, q);
+    if (vm.inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
+    if ((uint64_t)n / 2 > vm.inrange) return fail(ctx, RSI_ERR_UNSUPPORTED, "median depth above 65535");
+    rsih::Quantiles q;   // hist_quantiles_int's result for the median (hostmath.h), from the device's walk
+    q.med = (double)vm.lo;
+    if (vm.lo <= vm.hi && (double)vm.hi - (double)vm.lo >= 1.0 && vm.med >= 0) q.med = (double)vm.med;
     S.cap_median = q.med;
     capval = (int32_t)(q.med * P.cap);   // RD[i] = RDmedian*cap, truncated (loaddata.cpp:238)
   }
