@@ -122,6 +122,11 @@ struct rsi_ctx {
   double h_gc_table[256];     // GC table of the running chromosome (kGcLevels entries)
   std::vector<float> h_T;     // host copies of the bin arrays for filterstatus, grow-only
   std::vector<int> h_status;
+  // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
+  char* mailbox = nullptr;
+  size_t mb_cap = 0, mb_used = 0;
+  struct Pending { void* dst; const void* src; size_t bytes; };
+  std::vector<Pending> pending;   // mailbox -> destination copies to finish at the next synchronisation
   int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
@@ -154,7 +159,48 @@ hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
   }
   return hipEventSynchronize(ev);
 }
-#define CTX_SYNC() stream_wait(ctx->stream, ctx->sync_ev)
+
+// Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
+// runtime and blocks the calling thread; with a dozen workers issuing some fifty small copies per
+// chromosome that serialises them.  From / to pinned memory the copy is a plain asynchronous DMA:
+//  * host -> device: the bytes are parked in the mailbox first, so the caller's buffer is free at once;
+//  * device -> host: the bytes land in the mailbox and are moved to their destination by the next
+//    ctx_sync() -- exactly when the caller may look at them anyway.
+// Slots live until the end of the run (bump allocation); large transfers take the direct path.
+constexpr size_t kMailboxBytes = size_t(8) << 20, kMailboxMaxCopy = size_t(512) << 10;
+void* mb_alloc(rsi_ctx* ctx, size_t bytes) {
+  if (!ctx->mailbox) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), kMailboxBytes, hipHostMallocDefault) != hipSuccess) { ctx->mailbox = nullptr; return nullptr; }
+    ctx->mb_cap = kMailboxBytes;
+  }
+  const size_t need = (bytes + 63) & ~size_t(63);
+  if (ctx->mb_used + need > ctx->mb_cap) return nullptr;
+  void* p = ctx->mailbox + ctx->mb_used;
+  ctx->mb_used += need;
+  return p;
+}
+hipError_t copy_d2h(rsi_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
+  if (!slot) return hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  ctx->pending.push_back({dst, slot, bytes});
+  return hipMemcpyAsync(slot, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
+  if (!slot) return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  memcpy(slot, src, bytes);
+  return hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+hipError_t ctx_sync(rsi_ctx* ctx) {
+  const hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
+  if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
+  ctx->pending.clear();
+  return e;
+}
+void mailbox_reset(rsi_ctx* ctx) { ctx->mb_used = 0; ctx->pending.clear(); }
+#define CTX_SYNC() ctx_sync(ctx)
 
 int fail(rsi_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -228,10 +274,10 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
                 double* med, uint64_t* count) {
   uint8_t* small = ctx->small.as<uint8_t>();
   MinMaxF init{0xffffffffu, 0u, 0u, 0u};
-  HIPCHK(hipMemcpyAsync(small + kOffMinMax, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(copy_h2d(ctx, small + kOffMinMax, &init, sizeof(init)));
   { Timer t(ctx, "minmax_f32"); launch_minmax_f32(d_x, d_mask, nb, use_abs, center, reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->stream); }
   MinMaxF mm;
-  HIPCHK(hipMemcpyAsync(&mm, small + kOffMinMax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, &mm, small + kOffMinMax, sizeof(mm)));
   HIPCHK(CTX_SYNC());
   if (mm.min_bits == 0xffffffffu) { *count = 0; *med = 0; return RSI_OK; }
   if (mm.nonfinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
@@ -245,7 +291,7 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   HIPCHK(hipMemsetAsync(ctx->hist_f.p, 0, np * 4, ctx->stream));
   { Timer t(ctx, "hist_f32"); launch_hist_f32(d_x, d_mask, nb, use_abs, center, ymin, ctx->hist_f.as<uint32_t>(), (uint32_t)np, ctx->stream); }
   std::vector<uint32_t> h(np);
-  HIPCHK(hipMemcpyAsync(h.data(), ctx->hist_f.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, h.data(), ctx->hist_f.p, np * 4));
   HIPCHK(CTX_SYNC());
   uint64_t total = 0;
   for (uint32_t c : h) total += c;
@@ -276,15 +322,15 @@ int fetch_pairs(rsi_ctx* ctx, const uint64_t* d_list, const uint32_t* d_count, u
   constexpr uint32_t kEager = 1024;
   uint32_t cnt = 0;
   std::vector<uint64_t> raw(kEager);
-  HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(raw.data(), d_list, (size_t)std::min(cap, kEager) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, &cnt, d_count, 4));
+  HIPCHK(copy_d2h(ctx, raw.data(), d_list, (size_t)std::min(cap, kEager) * 8));
   HIPCHK(CTX_SYNC());
   out.clear();
   if (cnt == 0) return RSI_OK;
   if (cnt > cap) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
   raw.resize(cnt);
   if (cnt > kEager) {
-    HIPCHK(hipMemcpyAsync(raw.data() + kEager, d_list + kEager, (size_t)(cnt - kEager) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(copy_d2h(ctx, raw.data() + kEager, d_list + kEager, (size_t)(cnt - kEager) * 8));
     HIPCHK(CTX_SYNC());
   }
   std::vector<int64_t> s, e;
@@ -313,7 +359,7 @@ int upload_runs(rsi_ctx* ctx, const std::vector<Region>& runs, int32_t** d_start
   HIPCHK(ctx->run_se.ensure(k * 8 + 64));
   std::vector<int32_t> se(2 * k);
   for (size_t i = 0; i < k; ++i) { se[i] = runs[i].start; se[k + i] = runs[i].end; }
-  HIPCHK(hipMemcpyAsync(ctx->run_se.p, se.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(copy_h2d(ctx, ctx->run_se.p, se.data(), k * 8));
   HIPCHK(CTX_SYNC());   // se goes out of scope
   *d_start = ctx->run_se.as<int32_t>();
   *d_end = ctx->run_se.as<int32_t>() + k;
@@ -339,14 +385,14 @@ class DeviceTester : public rsih::NeighbourTester {
     uint8_t* ws = ctx->cand_i64.as<uint8_t>();
     GateShared gs(ctx);
     Phase ph(ctx, "cand.sharpen");
-    if (!ok(hipMemcpyAsync(ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob), hipMemcpyHostToDevice, ctx->stream))) return false;
+    if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob)))) return false;
     if (!ok(hipMemsetAsync(ws + off_done, 0, jobs.size() * 4, ctx->stream))) return false;
     for (int pass = 0; pass < 2; ++pass) {   // rsi.cpp:1876-1877
       Timer t(ctx, "sharpen_edges");
       launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), (int)jobs.size(), reinterpret_cast<long long*>(ws),
                            reinterpret_cast<int32_t*>(ws + off_i), reinterpret_cast<uint32_t*>(ws + off_done), ctx->stream);
     }
-    if (!ok(hipMemcpyAsync(jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob), hipMemcpyDeviceToHost, ctx->stream))) return false;
+    if (!ok(copy_d2h(ctx, jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob)))) return false;
     if (!wait()) return false;
     gs.release();
     for (size_t i = 0; i < L.size(); ++i) { L[i].start = jobs[i].start; L[i].end = jobs[i].end; }
@@ -395,14 +441,14 @@ class DeviceTester : public rsih::NeighbourTester {
       }
       GateShared gs(ctx);
       Phase ph(ctx, "cand.test");
-      if (!ok(hipMemcpyAsync(ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(CandJob), hipMemcpyHostToDevice, ctx->stream))) return false;
-      if (!ok(hipMemcpyAsync(ctx->cand_chains.p, chains.data(), chains.size() * 4, hipMemcpyHostToDevice, ctx->stream))) return false;
+      if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(CandJob)))) return false;
+      if (!ok(copy_h2d(ctx, ctx->cand_chains.p, chains.data(), chains.size() * 4))) return false;
       {
         Timer t(ctx, "candidate_test");
         launch_candidate_test(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
                               ctx->cand_i64.as<long long>(), median, ctx->cand_outs.as<CandOut>(), ctx->stream);
       }
-      if (!ok(hipMemcpyAsync(outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut), hipMemcpyDeviceToHost, ctx->stream))) return false;
+      if (!ok(copy_d2h(ctx, outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut)))) return false;
       if (!wait()) return false;
       gs.release();
       ph.stop();
@@ -432,11 +478,11 @@ class DeviceTester : public rsih::NeighbourTester {
       flat.push_back(r.first); flat.push_back(r.second);
     }
     if (!ok(ctx->cand_chains.ensure(flat.size() * 4)) || !ok(ctx->cand_outs.ensure(ranges.size() * 8))) return false;
-    if (!ok(hipMemcpyAsync(ctx->cand_chains.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream))) return false;
+    if (!ok(copy_h2d(ctx, ctx->cand_chains.p, flat.data(), flat.size() * 4))) return false;
     GateShared gs(ctx);
     { Timer t(ctx, "range_sums"); launch_range_sums(d_rdc, ctx->cand_chains.p, (int)ranges.size(), ctx->cand_outs.as<long long>(), ctx->stream); }
     static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-    if (!ok(hipMemcpyAsync(sums.data(), ctx->cand_outs.p, ranges.size() * 8, hipMemcpyDeviceToHost, ctx->stream))) return false;
+    if (!ok(copy_d2h(ctx, sums.data(), ctx->cand_outs.p, ranges.size() * 8))) return false;
     return wait();
   }
 
@@ -454,7 +500,7 @@ class DeviceTester : public rsih::NeighbourTester {
   }
   bool wait() {
     const double t0 = now_ms();
-    const bool r = ok(stream_wait(ctx->stream, ctx->sync_ev));
+    const bool r = ok(ctx_sync(ctx));
     kernel_wait_ms += now_ms() - t0;
     ++launches;
     return r;
@@ -473,8 +519,8 @@ int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t n
   HIPCHK(ctx->thr.ensure(nthr * 16));
   double* d_del = ctx->thr.as<double>();
   double* d_dup = d_del + nthr;
-  HIPCHK(hipMemcpyAsync(d_del, del.data(), nthr * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_dup, dup.data(), nthr * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(copy_h2d(ctx, d_del, del.data(), nthr * 8));
+  HIPCHK(copy_h2d(ctx, d_dup, dup.data(), nthr * 8));
   uint32_t* d_counters = reinterpret_cast<uint32_t*>(small + kOffCounters);
   HIPCHK(hipMemsetAsync(d_counters, 0, 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->first_del.p, 0xff, (size_t)nb * 4, ctx->stream));
@@ -497,14 +543,14 @@ int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t n
   uint32_t ldel = 0, ldup = 0;
   HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
   { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_del.as<uint32_t>(), nullptr, 0, nb, Lmax, d_lh, ctx->stream); }
-  HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, lh.data(), d_lh, (size_t)(Lmax + 1) * 4));
   HIPCHK(CTX_SYNC());
   stop_level(ldel);
   HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
   { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_dup.as<uint32_t>(), ctx->first_del.as<uint32_t>(), ldel, nb, Lmax, d_lh, ctx->stream); }
-  HIPCHK(hipMemcpyAsync(lh.data(), d_lh, (size_t)(Lmax + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, lh.data(), d_lh, (size_t)(Lmax + 1) * 4));
   uint32_t cnts[2];
-  HIPCHK(hipMemcpyAsync(cnts, d_counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, cnts, d_counters, 8));
   HIPCHK(CTX_SYNC());
   stop_level(ldup);
   *escapes += cnts[0];
@@ -564,8 +610,8 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   std::vector<float>& hT = ctx->h_T;       // context-owned: no 20 MB of fresh pages per chromosome
   std::vector<int>& hst = ctx->h_status;
   if (hT.size() < (size_t)nb) { hT.resize((size_t)((double)nb * tl_grow) + 16); hst.resize(hT.size()); }
-  HIPCHK(hipMemcpyAsync(hT.data(), d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hst.data(), d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, hT.data(), d_T, (size_t)nb * 4));
+  HIPCHK(copy_d2h(ctx, hst.data(), d_st1, (size_t)nb * 4));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
   {
@@ -635,7 +681,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
   out.status2.resize((size_t)nb);
-  HIPCHK(hipMemcpyAsync(out.status2.data(), d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, out.status2.data(), d_st2, (size_t)nb * 4));
   std::vector<Region> runs;
   if ((rc = marked_runs_device(ctx, d_st2, nb, runs)) != RSI_OK) return rc;   // synchronises
   out.segs.clear();
@@ -661,12 +707,12 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int64_t* d_poff = reinterpret_cast<int64_t*>(d_scratch + poff.back());
   HIPCHK(ctx->items.ensure(items.size() * sizeof(SegItem)));
   HIPCHK(ctx->best.ensure(items.size() * sizeof(BestSeg)));
-  HIPCHK(hipMemcpyAsync(d_poff, poff.data(), poff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->items.p, items.data(), items.size() * sizeof(SegItem), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(copy_h2d(ctx, d_poff, poff.data(), poff.size() * 8));
+  HIPCHK(copy_h2d(ctx, ctx->items.p, items.data(), items.size() * sizeof(SegItem)));
   { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, d_rs, d_re, (int)runs.size(), d_poff, d_scratch, ctx->stream); }
   { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
   std::vector<BestSeg> best(items.size());
-  HIPCHK(hipMemcpyAsync(best.data(), ctx->best.p, items.size() * sizeof(BestSeg), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(copy_d2h(ctx, best.data(), ctx->best.p, items.size() * sizeof(BestSeg)));
   HIPCHK(CTX_SYNC());
   std::vector<BestSeg> per_run(runs.size(), BestSeg{-1.0, 0, 0});
   for (size_t i = 0; i < items.size(); ++i) {   // items of a run are in increasing L: strict > keeps the earliest
@@ -712,6 +758,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->phases.clear();
   tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
   tl_grow_ms = 0.0;
+  mailbox_reset(ctx);
   // The per-base kernels are HBM-bound: workers of a pool take turns through this phase (GpuGate).
   struct StreamTurn {
     GpuGate* g = nullptr;
@@ -780,13 +827,13 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, ctx->slabs.p, st); }
     { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
     GcAccum acc;
-    HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
     HIPCHK(CTX_SYNC());
     if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
       HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
       { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, ctx->slabs.p, st); }
       { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
-      HIPCHK(hipMemcpyAsync(&acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+      HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
       HIPCHK(CTX_SYNC());
     }
     if (acc.negatives & 1u) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
@@ -799,7 +846,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     }
     S.gc_rdmean = rdmean;
     double* d_table = reinterpret_cast<double*>(small + kOffTable);
-    HIPCHK(hipMemcpyAsync(d_table, table, sizeof(double) * kGcLevels, hipMemcpyHostToDevice, st));
+    HIPCHK(copy_h2d(ctx, d_table, table, sizeof(double) * kGcLevels));
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
     { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
@@ -824,8 +871,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     ValueMedian vm;
     ValueMedian* d_vm = reinterpret_cast<ValueMedian*>(small + kOffValMedian);
     { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
-    HIPCHK(hipMemcpyAsync(&vm, d_vm, sizeof(vm), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&aux, d_aux, sizeof(aux), hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_d2h(ctx, &vm, d_vm, sizeof(vm)));
+    HIPCHK(copy_d2h(ctx, &aux, d_aux, sizeof(aux)));
     HIPCHK(CTX_SYNC());
     if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     if (vm.inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
@@ -852,8 +899,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   if (ncompact <= 0 || nb < 8) return fail(ctx, RSI_ERR_TOO_SMALL, "nothing left after removing N regions");
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  if (!noncode.empty()) HIPCHK(hipMemcpyAsync(d_cbreak, cbreak.data(), cbreak.size() * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, st));
+  if (!noncode.empty()) HIPCHK(copy_h2d(ctx, d_cbreak, cbreak.data(), cbreak.size() * 8));
+  HIPCHK(copy_h2d(ctx, d_cum, cum.data(), cum.size() * 8));
   HIPCHK(ctx->rdc.ensure((size_t)(ncompact + 4) * 4));
   HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
   HIPCHK(ctx->binsum.ensure((size_t)nb * 8));
@@ -866,8 +913,8 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, ctx->hist_res.as<uint32_t>(), ctx->slabs.p, st); }
   BinAccum bacc;
   std::vector<uint32_t> hres(res_vals * kResClasses);
-  HIPCHK(hipMemcpyAsync(&bacc, d_bacc, sizeof(bacc), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(hres.data(), ctx->hist_res.p, hres.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(copy_d2h(ctx, &bacc, d_bacc, sizeof(bacc)));
+  HIPCHK(copy_d2h(ctx, hres.data(), ctx->hist_res.p, hres.size() * 4));
   HIPCHK(CTX_SYNC());   // also covers cbreak/cum going out of use
   if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");
   // chromosome median / SD (rsi.cpp:2202-2203)
@@ -926,7 +973,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     HIPCHK(hipMemsetAsync(d_rawmin, 0xff, 4, st));
     { Timer t(ctx, "nb_raw"); launch_nb_raw(ctx->binsum.as<int64_t>(), nb, P.m, ncompact, r, ctx->tnb.as<float>(), d_rawmin, st); }
     uint32_t minkey;
-    HIPCHK(hipMemcpyAsync(&minkey, d_rawmin, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_d2h(ctx, &minkey, d_rawmin, 4));
     HIPCHK(CTX_SYNC());
     float tminf;
     { uint32_t b = (minkey & 0x80000000u) ? (minkey & 0x7fffffffu) : ~minkey; memcpy(&tminf, &b, 4); }
@@ -951,7 +998,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     rsih::CallerInput in;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     std::vector<int> medint((size_t)nb);
-    HIPCHK(hipMemcpyAsync(medint.data(), ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_d2h(ctx, medint.data(), ctx->binmed.p, (size_t)nb * 4));
     HIPCHK(CTX_SYNC());
     in.binmedint = &medint;
 
@@ -1073,6 +1120,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1097,8 +1145,8 @@ int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const u
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
   HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
-  HIPCHK(hipMemcpyAsync(ctx->in_depth.p, depth, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(copy_h2d(ctx, ctx->in_depth.p, depth, (size_t)n * 4));
+  HIPCHK(copy_h2d(ctx, ctx->in_fasta.p, fasta, (size_t)n));
   HIPCHK(CTX_SYNC());
   return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
 }
@@ -1129,7 +1177,8 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(cnt, cap);
-    HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    mailbox_reset(ctx);
+    HIPCHK(copy_d2h(ctx, out, src, (size_t)k * 4));
     HIPCHK(CTX_SYNC());
   }
   return cnt;
@@ -1143,7 +1192,8 @@ int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t ca
   if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(cnt, cap);
-    HIPCHK(hipMemcpyAsync(out, src, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    mailbox_reset(ctx);
+    HIPCHK(copy_d2h(ctx, out, src, (size_t)k * 4));
     HIPCHK(CTX_SYNC());
   }
   return cnt;
@@ -1154,7 +1204,8 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
   if (s != "binsum" || ctx->nb == 0) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(ctx->nb, cap);
-    HIPCHK(hipMemcpyAsync(out, ctx->binsum.p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    mailbox_reset(ctx);
+    HIPCHK(copy_d2h(ctx, out, ctx->binsum.p, (size_t)k * 8));
     HIPCHK(CTX_SYNC());
   }
   return ctx->nb;
