@@ -1,7 +1,9 @@
-// host_calls.h -- host-sized stages of the path: candidate tests,
-// boundary refinement, merge, final filters.  Candidates are few (10^2..10^4) and the walks are
-// sequential and data-dependent, so these stay on the host; the per-base depth they read stays in
-// HBM and is paged in on demand (DepthPager).
+// host_calls.h -- the candidate stages of the path: candidate tests,
+// boundary refinement, merge, final filters.  Candidates are few (10^2..10^4) and the list logic
+// around them is sequential and data-dependent: that part lives here, on the host.  Everything
+// that touches the per-base depth runs on the device through NeighbourTester (kernels_cand.hip,
+// implemented next to the pipeline); the host walks below remain as the path a test takes when
+// the device declines it, reading the depth through DepthPager (pages fetched from HBM on demand).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

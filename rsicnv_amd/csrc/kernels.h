@@ -154,8 +154,8 @@ struct CandJob {            // one isitcnvwrap test, prepared on the host from t
   int32_t budget;           // maxchkbp*10: thinning threshold
   int32_t cut;              // bit 0 / 1: the left / right chain was cut short by the host (the kernel reports when it runs out)
   double right_cap;         // 2*chklen*d (the right side appends while used < right_cap)
-  int64_t iscratch_off;     // int32 scratch: (top+1) + capacity + min(capacity, budget)
-  int64_t lscratch_off;     // int64 scratch: capacity + 1
+  int64_t iscratch_off;     // int32 scratch: (top+1) + capacity + min(capacity, budget), each rounded up to a multiple of 4; offset a multiple of 4
+  int64_t lscratch_off;     // int64 scratch: capacity + 1 rounded up to a multiple of 4; offset even
 };
 struct CandOut {
   int32_t flags;            // 1: empty neighbourhood, 2: body value range beyond the LDS histogram, 4: same for the window means, 8: cut chain used up

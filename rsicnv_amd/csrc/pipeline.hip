@@ -2,8 +2,8 @@
 // sequencing with the global-reduction barriers of the path (GC table -> cap median -> chromosome
 // median/MAD -> NB minimum -> scan thresholds), the small host decisions between kernels, and the
 // C ABI.  There is no CPU fallback anywhere in this file: every array-sized computation is a
-// kernel from kernels_base.hip / kernels_bin.hip; the host only walks device-built histograms and
-// runs the candidate stages (host_calls.cpp).
+// kernel from kernels_base.hip / kernels_bin.hip / kernels_cand.hip; the host only walks
+// device-built histograms and runs the candidate list logic (host_calls.cpp).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
