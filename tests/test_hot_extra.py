@@ -183,3 +183,24 @@ def test_parity_20mb_vs_oracle(hot, hotlib, oracle_cls):
         assert ok, f"{which}: {why}"
     assert len(res.calls("calls")) >= 15
 
+
+
+def test_host_candidate_path_still_agrees(hot, hotlib, oracle_cls, monkeypatch):
+    """RSI_HOT_HOST_CANDIDATES=1 routes the per-base candidate steps through the host walks (the path a
+    test takes when the device declines it): same calls as the oracle, and as the device path."""
+    import oracle
+    from rsicnv_amd import api
+    plan_kw = dict(n=1_200_011, seed=0xCA4D, model=1, n_events=8, gaps=2, max_len=40000, end_n=6000, gap_len=20000)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta, snapshots=False)
+    dev = hot.run(api.make_params(), depth, fasta)
+    monkeypatch.setenv("RSI_HOT_HOST_CANDIDATES", "1")
+    host = hot.run(api.make_params(), depth, fasta)
+    monkeypatch.delenv("RSI_HOT_HOST_CANDIDATES")
+    for which in ("blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(host.calls(which), O.calls(which))
+        assert ok, f"host path {which}: {why}"
+        ok, why = calls_equal(dev.calls(which), host.calls(which), rtol=1e-9)
+        assert ok, f"device vs host path {which}: {why}"
+    assert len(dev.calls("calls_raw")) >= 4
