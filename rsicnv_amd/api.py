@@ -141,29 +141,56 @@ class RsiError(RuntimeError):
 
 
 class Result:
-    """Owned copy of one chromosome's results (the C object is freed on construction)."""
+    """One chromosome's results.  The C object is kept and read on demand (list by list), so that a caller
+    that only wants the final calls does not pay for converting thousands of intermediate segments."""
 
     def __init__(self, lib, handle):
-        self.lists = {}
-        for name, w in WHICH.items():
-            k = lib.rsi_result_ncalls(handle, w)
-            arr = lib.rsi_result_calls(handle, w)
-            self.lists[name] = [{f: getattr(arr[i], f) for f in CALL_FIELDS} for i in range(k)]
+        self._lib = lib
+        self._h = handle
+        self._lists = {}
+        self._rows = None
+        self._noncode = None
         st = lib.rsi_result_stats(handle).contents
         self.stats = {f[0]: getattr(st, f[0]) for f in RsiChromStats._fields_}
-        k = lib.rsi_result_noncode(handle, None, 0)
-        pairs = (C.c_int32 * max(2 * k, 2))()
-        lib.rsi_result_noncode(handle, pairs, k)
-        self.noncode = np.array(pairs[:2 * k], dtype=np.int32)
-        self.rows = []
-        buf = C.create_string_buffer(1024)
-        for i in range(len(self.lists["calls"])):
-            lib.rsi_result_format_row(handle, i, b"%CHROM%", buf, 1024)
-            self.rows.append(buf.value.decode())
-        lib.rsi_result_free(handle)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.rsi_result_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def calls(self, which="calls"):
-        return self.lists[which]
+        if which not in self._lists:
+            w = WHICH[which]
+            k = self._lib.rsi_result_ncalls(self._h, w)
+            arr = self._lib.rsi_result_calls(self._h, w)
+            self._lists[which] = [{f: getattr(arr[i], f) for f in CALL_FIELDS} for i in range(k)]
+        return self._lists[which]
+
+    @property
+    def lists(self):
+        return {name: self.calls(name) for name in WHICH}
+
+    @property
+    def noncode(self):
+        if self._noncode is None:
+            k = self._lib.rsi_result_noncode(self._h, None, 0)
+            pairs = (C.c_int32 * max(2 * k, 2))()
+            self._lib.rsi_result_noncode(self._h, pairs, k)
+            self._noncode = np.array(pairs[:2 * k], dtype=np.int32)
+        return self._noncode
+
+    @property
+    def rows(self):
+        if self._rows is None:
+            buf = C.create_string_buffer(1024)
+            self._rows = []
+            for i in range(self._lib.rsi_result_ncalls(self._h, WHICH["calls"])):
+                self._lib.rsi_result_format_row(self._h, i, b"%CHROM%", buf, 1024)
+                self._rows.append(buf.value.decode())
+        return self._rows
 
     def format_rows(self, chrom):
         return [r.replace("%CHROM%", chrom) for r in self.rows]

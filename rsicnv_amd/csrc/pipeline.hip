@@ -1068,14 +1068,17 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     ctx->phases.push_back({"calls.merge(incl tests)", prof.merge});
     ctx->phases.push_back({"calls.ntests", (double)prof.tests});
   }
+  Phase ph_fin(ctx, "z.finish");
   const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
   for (int w = 0; w < 4; ++w) {
     res->lists[w].resize(lists[w]->size());
     for (size_t i = 0; i < lists[w]->size(); ++i) to_call((*lists[w])[i], &res->lists[w][i]);
   }
   HIPCHK(CTX_SYNC());
+  ph_fin.stop();
   ctx->phases.push_back({"mem.grow", tl_grow_ms});
   S.t_device_ms = now_ms() - t_begin;
+  ctx->phases.push_back({"z.total", S.t_device_ms});
   if (ctx->timing) {
     double tot = 0;
     for (const KernelTime& k : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, k.a, k.b); tot += ms; }
@@ -1340,7 +1343,9 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
   std::vector<std::thread> th;
   for (size_t w = 1; w < pool->workers.size(); ++w) th.emplace_back(work, w);
   work(0);
+  const double t_work = now_ms() - t_run0;
   for (auto& t : th) t.join();
+  if (trace) fprintf(stderr, "[trace] pool_run: own work done at %.2f ms, all workers joined at %.2f ms\n", t_work, now_ms() - t_run0);
   int worst = RSI_OK;
   for (int i = 0; i < nchrom; ++i) {
     if (status) status[i] = rcs[(size_t)i];
