@@ -94,6 +94,23 @@ const char* rsi_hot_last_error(const rsi_ctx* ctx);   /* ctx may be NULL: last g
 /* One chromosome, inputs in host memory: depth[n] raw per-base depth, fasta[n] sequence bytes. */
 int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const uint8_t* fasta, int64_t n,
                 rsi_result** out);
+
+/* ---- Depth text ingestion on the device --------------------------------------------
+ * Replaces the parse loop of load_data_from_text (loaddata.cpp:496-517): "pos depth" lines; empty lines
+ * and '#' lines skipped; pos < 1 skipped; reading stops at the first pos >= n (the last base is never
+ * set); RD[pos-1] = depth; positions that never appear stay 0.  The file is streamed to HBM in pinned
+ * chunks and parsed by a kernel; files whose positions are not strictly increasing (where the order-
+ * dependent rules matter) are parsed by the sequential host loop instead (stats->fallback = 1). */
+typedef struct rsi_text_stats {
+  int64_t bytes, lines, stored, beyond;   /* file size; lines with pos >= 1; lines stored; lines with pos >= n */
+  int32_t fallback, pad;                  /* 1: parsed on the host (unsorted positions) */
+  double t_total_ms, t_parse_kernel_ms;   /* wall time of the load; summed kernel time when timing is on */
+} rsi_text_stats;
+/* Parses `path` into the context's device depth buffer (int32[n]); rsi_hot_fetch_i32("depth_in") reads it back. */
+int rsi_hot_load_depth_text(rsi_ctx* ctx, const char* path, int64_t n, rsi_text_stats* stats);
+/* rsi_hot_load_depth_text + rsi_hot_run on the loaded depth: fasta[n] in host memory.  stats may be NULL. */
+int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, const uint8_t* fasta, int64_t n,
+                     rsi_result** out, rsi_text_stats* stats);
 /* Same, inputs already resident in device memory (HBM); they are not modified. */
 int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n,
                        rsi_result** out);

@@ -24,7 +24,7 @@ STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3:
 
 # every symbol include/rsi_hot.h and include/rsi_synth.h declare
 EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
-           "rsi_hot_run_device", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
+           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
            "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_synth_generate_host", "rsi_synth_generate_device"]
@@ -54,6 +54,11 @@ class RsiChromStats(C.Structure):
 
 
 RSI_MAX_TIMED = 64
+
+
+class RsiTextStats(C.Structure):
+    _fields_ = [("bytes", C.c_int64), ("lines", C.c_int64), ("stored", C.c_int64), ("beyond", C.c_int64),
+                ("fallback", C.c_int32), ("pad", C.c_int32), ("t_total_ms", C.c_double), ("t_parse_kernel_ms", C.c_double)]
 
 
 class RsiBatchTimes(C.Structure):
@@ -94,6 +99,8 @@ def load_library():
     L.rsi_hot_last_error.restype = C.c_char_p
     L.rsi_hot_run.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.rsi_hot_run_device.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.rsi_hot_load_depth_text.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(RsiTextStats)]
+    L.rsi_hot_run_text.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(RsiTextStats)]
     L.rsi_result_ncalls.argtypes = [C.c_void_p, C.c_int]
     L.rsi_result_calls.argtypes = [C.c_void_p, C.c_int]
     L.rsi_result_calls.restype = C.POINTER(RsiCall)
@@ -233,6 +240,23 @@ class RsiHot:
         out = C.c_void_p()
         self._check(self.lib.rsi_hot_run(self.ctx, C.byref(params), d.ctypes.data, f.ctypes.data, d.size, C.byref(out)))
         return Result(self.lib, out)
+
+    def load_depth_text(self, path, n):
+        """Parse a "pos depth" text file into the context's device depth buffer (rsi_hot_load_depth_text).
+        Returns the statistics as a dict; fetch("depth_in") reads the result back."""
+        st = RsiTextStats()
+        self._check(self.lib.rsi_hot_load_depth_text(self.ctx, os.fsencode(path), int(n), C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in RsiTextStats._fields_ if f[0] != "pad"}
+
+    def run_text(self, params, path, fasta):
+        """Depth from a text file (parsed on the device), fasta: uint8[n] host array."""
+        f = np.ascontiguousarray(fasta, dtype=np.uint8)
+        out = C.c_void_p()
+        st = RsiTextStats()
+        self._check(self.lib.rsi_hot_run_text(self.ctx, C.byref(params), os.fsencode(path), f.ctypes.data, f.size, C.byref(out), C.byref(st)))
+        res = Result(self.lib, out)
+        res.text_stats = {f_[0]: getattr(st, f_[0]) for f_ in RsiTextStats._fields_ if f_[0] != "pad"}
+        return res
 
     def run_device(self, params, d_depth_ptr, d_fasta_ptr, n):
         """Inputs already in HBM (raw device pointers, 16-byte aligned)."""

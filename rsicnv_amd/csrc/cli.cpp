@@ -127,50 +127,6 @@ bool read_fasta(const std::string& fasta, const std::string& chr, std::string& r
   return true;
 }
 
-// The parse loop of load_data_from_text (loaddata.cpp:496-517): "pos depth" lines, '#' and empty
-// lines skipped, pos < 1 skipped, reading stops at the first pos >= size (App. A Q7).
-bool load_depth_text(const std::string& path, std::vector<int32_t>& rd) {
-  const int fd = open(path.c_str(), O_RDONLY);
-  if (fd < 0) { std::cerr << "Cannot open file " << path << std::endl; return false; }
-  struct stat sb;
-  fstat(fd, &sb);
-  const size_t sz = (size_t)sb.st_size;
-  const char* p = sz ? (const char*)mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-  if (sz && p == MAP_FAILED) { close(fd); std::cerr << "Cannot map file " << path << std::endl; return false; }
-  const char* end = p + sz;
-  const long size = (long)rd.size();
-  auto parse_int = [&](const char*& q, const char* e, long& v) {
-    while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
-    bool neg = false;
-    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
-    if (q >= e || *q < '0' || *q > '9') return false;
-    long x = 0;
-    while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; }
-    v = neg ? -x : x;
-    return true;
-  };
-  const char* q = p;
-  while (q < end) {
-    const char* eol = (const char*)memchr(q, '\n', (size_t)(end - q));
-    if (!eol) eol = end;
-    if (eol > q && *q != '#') {
-      const char* c = q;
-      long pos = 0, d = 0;
-      if (parse_int(c, eol, pos)) {
-        parse_int(c, eol, d);
-        if (pos >= 1) {
-          if (pos >= size) break;
-          rd[(size_t)pos - 1] = (int32_t)d;
-        }
-      }
-    }
-    q = eol + 1;
-  }
-  if (sz) munmap((void*)p, sz);
-  close(fd);
-  return true;
-}
-
 const char* kHeader =
     "#CHROM\tSTART\tEND\tTYPE\tSCORE\tLENGTH\tCNV_MED(CNV_SD);NEIGHBOR_MED(NEIGHBOR_RUNMEANSD);CHR_MED(CHR_SD)\t"
     "RP=#support_read_pairs;Q0=#fraction_of_Q0_reads\tMETHOD";
@@ -203,15 +159,15 @@ int main(int argc, char** argv) {
   const double t0 = now_s();
   std::string fasta;
   if (!read_fasta(o.reffile, o.chr, fasta)) return 0;
-  std::vector<int32_t> rd(fasta.size(), 0);
-  if (!load_depth_text(o.rdfile, rd)) return 0;
   const double t1 = now_s();
 
   int st = 0;
   rsi_ctx* ctx = rsi_hot_create(o.device, &st);
   if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
   rsi_result* res = nullptr;
-  const int rc = rsi_hot_run(ctx, &o.P, rd.data(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res);
+  rsi_text_stats ts;
+  // the depth file is parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517)
+  const int rc = rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
   if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
     std::cerr << rsi_hot_last_error(ctx) << std::endl; log << rsi_hot_last_error(ctx) << std::endl;
     rsi_hot_destroy(ctx);
@@ -234,7 +190,9 @@ int main(int argc, char** argv) {
        << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
        << "Selected " << rsi_result_ncalls(res, 3) << " segments for testing\n"
        << "Found " << rsi_result_ncalls(res, 1) << " CNVs before sd_filters, " << rsi_result_ncalls(res, 0) << " written\n"
-       << "timing: load " << (t1 - t0) << " s, device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
+       << "timing: fasta " << (t1 - t0) << " s, depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
+       << (ts.fallback ? ", host parser: positions not increasing" : "") << "), whole device path " << (t2 - t1) << " s (" << S->t_device_ms
+       << " ms on resident inputs)\n";
   std::cerr << info.str(); log << info.str();
 
   // write_cnv_to_file, rsi.cpp:1592-1616

@@ -172,4 +172,13 @@ size_t sharpen_part_slots(int njobs);
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
 
+// ---- depth text ingestion (kernels_io.hip; load_data_from_text's parse loop, loaddata.cpp:496-517) ----
+struct TextParseStats { unsigned long long lines, stored, beyond; unsigned int unsorted, pad; };
+// One chunk of text that starts on a line start and ends on a line end (or the end of the file).  depth[size] must be
+// zeroed before the first chunk.  wg_first / wg_max: text_parse_workgroups(nbytes) entries each (first counted position
+// and running maximum per workgroup; -1 = none) for the caller's cross-workgroup order check; stats accumulates.
+int text_parse_workgroups(long long nbytes);
+void launch_parse_depth_text(const void* text, long long nbytes, long long size, int32_t* depth, long long* wg_first,
+                             long long* wg_max, TextParseStats* stats, hipStream_t stream);
+
 }  // namespace rsik

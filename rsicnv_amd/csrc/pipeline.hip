@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -108,6 +111,10 @@ struct rsi_ctx {
   size_t event_next = 0;
   // workspace
   DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
+  DevBuf text_dev[2], text_wg;               // depth text ingestion: two chunks of file bytes in HBM, per-workgroup order records
+  char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
+  size_t text_pin_cap = 0;
+  int64_t n_in = 0;                          // length of the depth currently in in_depth
   DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del, first_dup;
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
@@ -1124,6 +1131,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->mirror) (void)hipHostFree(ctx->mirror);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  for (int b = 0; b < 2; ++b) if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1142,12 +1150,181 @@ int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, c
   return RSI_OK;
 }
 
+
+namespace {
+
+// The sequential parse loop (the reference's rules in the reference's order), used when the device
+// cannot prove that positions are strictly increasing.
+void parse_depth_text_host(const char* p, size_t sz, int64_t size, std::vector<int32_t>& rd, rsi_text_stats* st) {
+  const char* end = p + sz;
+  auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+  auto parse_int = [&](const char*& q, const char* e, long long& v) {
+    while (q < e && blank(*q)) ++q;
+    bool neg = false;
+    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    if (q >= e || *q < '0' || *q > '9') { v = 0; return false; }
+    long long x = 0;
+    while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; }
+    v = neg ? -x : x;
+    return true;
+  };
+  const char* q = p;
+  while (q < end) {
+    const char* eol = (const char*)memchr(q, '\n', (size_t)(end - q));
+    if (!eol) eol = end;
+    if (eol > q && *q != '#') {
+      const char* c = q;
+      long long pos = 0, d = 0;
+      if (parse_int(c, eol, pos)) {
+        parse_int(c, eol, d);
+        if (pos >= 1) {
+          ++st->lines;
+          if (pos >= size) { ++st->beyond; break; }       // loaddata.cpp:514
+          rd[(size_t)pos - 1] = (int32_t)d;
+          ++st->stored;
+        }
+      }
+    }
+    q = eol + 1;
+  }
+}
+
+constexpr size_t kTextChunk = size_t(64) << 20;   // bytes of text per transfer + kernel
+
+}  // namespace
+
+int rsi_hot_load_depth_text(rsi_ctx* ctx, const char* path, int64_t n, rsi_text_stats* stats) {
+  rsi_text_stats local;
+  rsi_text_stats* st = stats ? stats : &local;
+  memset(st, 0, sizeof(*st));
+  if (!ctx || !path) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
+  const double t0 = now_ms();
+  HIPCHK(hipSetDevice(ctx->device));
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("Cannot open file ") + path);
+  struct FdGuard { int fd; ~FdGuard() { close(fd); } } guard{fd};
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("Cannot stat file ") + path);
+  st->bytes = (int64_t)sb.st_size;
+  mailbox_reset(ctx);
+  HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
+  HIPCHK(hipMemsetAsync(ctx->in_depth.p, 0, (size_t)n * 4, ctx->stream));
+  ctx->n_in = n;
+  if (ctx->text_pin_cap < kTextChunk) {
+    for (int b = 0; b < 2; ++b) {
+      if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
+      ctx->text_pin[b] = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->text_pin[b]), kTextChunk, hipHostMallocDefault) != hipSuccess)
+        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the text staging");
+    }
+    ctx->text_pin_cap = kTextChunk;
+  }
+  const int max_wg = text_parse_workgroups((long long)kTextChunk);
+  HIPCHK(ctx->text_dev[0].ensure(kTextChunk));
+  HIPCHK(ctx->text_dev[1].ensure(kTextChunk));
+  HIPCHK(ctx->text_wg.ensure((size_t)max_wg * 16 * 2 + 256));   // (first, max) per workgroup, two chunks in flight, + stats
+  uint8_t* wgbase = ctx->text_wg.as<uint8_t>();
+  TextParseStats* d_stats = reinterpret_cast<TextParseStats*>(wgbase + (size_t)max_wg * 32);
+  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(TextParseStats), ctx->stream));
+  std::vector<long long> wg_host[2];
+  wg_host[0].resize((size_t)max_wg * 2); wg_host[1].resize((size_t)max_wg * 2);
+
+  // Double buffering: while the device parses chunk k the host reads chunk k+1 from the file.  A chunk ends on
+  // a line end; the partial last line is carried to the front of the next chunk.
+  size_t carry = 0;            // bytes of an unfinished line already at the front of the buffer being filled
+  bool eof = false, unsorted = false;
+  long long run_max = -1;      // largest position seen in the chunks checked so far
+  int inflight_wgs[2] = {0, 0};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; ++b) if (hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) return fail(ctx, RSI_ERR_HIP, "hipEventCreate failed");
+  struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } evguard{done};
+  auto check_chunk = [&](int b) {   // cross-workgroup order of a finished chunk
+    const long long* f = wg_host[b].data();
+    const long long* m = f + inflight_wgs[b];
+    for (int w = 0; w < inflight_wgs[b]; ++w) {
+      if (f[w] < 0) continue;
+      if (run_max >= 0 && f[w] <= run_max) unsorted = true;
+      run_max = m[w] > run_max ? m[w] : run_max;
+    }
+    inflight_wgs[b] = 0;
+  };
+  int cur = 0;
+  bool used[2] = {false, false};
+  while (!eof) {
+    char* buf = ctx->text_pin[cur];   // free: its previous chunk was waited for before `carry` was parked in it
+    size_t have = carry;
+    while (have < kTextChunk) {
+      const ssize_t got = read(fd, buf + have, kTextChunk - have);
+      if (got < 0) return fail(ctx, RSI_ERR_INTERNAL, std::string("read error on ") + path);
+      if (got == 0) { eof = true; break; }
+      have += (size_t)got;
+    }
+    size_t len = have;
+    if (!eof) {   // cut at the last line end
+      while (len > 0 && buf[len - 1] != '\n') --len;
+      if (len == 0) return fail(ctx, RSI_ERR_UNSUPPORTED, "a line of the depth file is longer than 64 MB");
+    }
+    if (len > 0) {
+      const int nwg = text_parse_workgroups((long long)len);
+      long long* d_first = reinterpret_cast<long long*>(wgbase + (size_t)cur * max_wg * 16);
+      long long* d_max = d_first + nwg;
+      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf, len, hipMemcpyHostToDevice, ctx->stream));
+      { Timer t(ctx, "parse_depth_text"); launch_parse_depth_text(ctx->text_dev[cur].p, (long long)len, (long long)n, ctx->in_depth.as<int32_t>(), d_first, d_max, d_stats, ctx->stream); }
+      HIPCHK(hipMemcpyAsync(wg_host[cur].data(), d_first, (size_t)nwg * 16, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipEventRecord(done[cur], ctx->stream));
+      inflight_wgs[cur] = nwg;
+      used[cur] = true;
+    }
+    // the other buffer's chunk (the older one) has to be through before the unfinished line is parked in it
+    // and the next read fills it; the chunk just launched keeps the device busy meanwhile
+    const int other = cur ^ 1;
+    if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); check_chunk(other); used[other] = false; }
+    carry = have - len;
+    if (carry) memcpy(ctx->text_pin[other], buf + len, carry);
+    cur = other;
+  }
+  for (int b = 0; b < 2; ++b) if (used[b] && inflight_wgs[b]) { HIPCHK(hipEventSynchronize(done[b])); check_chunk(b); }
+  TextParseStats hs;
+  HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  st->lines = (int64_t)hs.lines; st->stored = (int64_t)hs.stored; st->beyond = (int64_t)hs.beyond;
+  if (hs.unsorted || unsorted) {
+    // order-dependent rules in play: redo the file with the sequential loop
+    st->fallback = 1; st->lines = st->stored = st->beyond = 0;
+    std::vector<int32_t> rd((size_t)n, 0);
+    std::vector<char> all((size_t)st->bytes);
+    if (lseek(fd, 0, SEEK_SET) != 0) return fail(ctx, RSI_ERR_INTERNAL, "seek error");
+    size_t have = 0;
+    while (have < all.size()) { const ssize_t got = read(fd, all.data() + have, all.size() - have); if (got <= 0) break; have += (size_t)got; }
+    parse_depth_text_host(all.data(), have, n, rd, st);
+    HIPCHK(hipMemcpyAsync(ctx->in_depth.p, rd.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  st->t_total_ms = now_ms() - t0;
+  if (ctx->timing) { double tot = 0; for (const KernelTime& k : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, k.a, k.b); tot += ms; } st->t_parse_kernel_ms = tot; }
+  return RSI_OK;
+}
+
+int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, const uint8_t* fasta, int64_t n, rsi_result** out,
+                     rsi_text_stats* stats) {
+  if (!ctx || !p || !depth_path || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  ctx->ktimes.clear(); ctx->event_next = 0;
+  int rc = rsi_hot_load_depth_text(ctx, depth_path, n, stats);
+  if (rc != RSI_OK) return rc;
+  HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
+  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
+}
+
 int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const uint8_t* fasta, int64_t n, rsi_result** out) {
   if (!ctx || !p || !depth || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
   if (n <= 0) return fail(ctx, RSI_ERR_BAD_ARG, "empty chromosome");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
   HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
+  ctx->n_in = n;
   HIPCHK(copy_h2d(ctx, ctx->in_depth.p, depth, (size_t)n * 4));
   HIPCHK(copy_h2d(ctx, ctx->in_fasta.p, fasta, (size_t)n));
   HIPCHK(CTX_SYNC());
@@ -1173,6 +1350,7 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   const void* src = nullptr; int64_t cnt = 0;
   if (s == "rd_gc" && ctx->have_gc) { src = ctx->rd_gc.p; cnt = ctx->n; }
   else if (s == "rd_concat") { src = ctx->rdc.p; cnt = ctx->ncompact; }
+  else if (s == "depth_in" && ctx->in_depth.p) { src = ctx->in_depth.p; cnt = ctx->n_in; }
   else if (s == "binmedint") { src = ctx->binmed.p; cnt = ctx->nb; }
   else if (s == "status1") { src = ctx->status1.p; cnt = ctx->nb; }
   else if (s == "status1f") { src = ctx->status1f.p; cnt = ctx->nb; }

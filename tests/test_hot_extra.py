@@ -204,3 +204,76 @@ def test_host_candidate_path_still_agrees(hot, hotlib, oracle_cls, monkeypatch):
         ok, why = calls_equal(dev.calls(which), host.calls(which), rtol=1e-9)
         assert ok, f"device vs host path {which}: {why}"
     assert len(dev.calls("calls_raw")) >= 4
+
+
+def _reference_text_semantics(lines, n):
+    """load_data_from_text's loop (loaddata.cpp:496-517) in Python, for small inputs."""
+    rd = np.zeros(n, dtype=np.int32)
+    for ln in lines:
+        if len(ln) < 1 or ln[0] == "#":
+            continue
+        toks = ln.split()
+        def as_int(t):
+            import re
+            m = re.match(r"[+-]?\d+", t)
+            return int(m.group(0)) if m else None
+        pos = as_int(toks[0]) if toks else None
+        if pos is None:
+            continue                      # failed extraction leaves 0: skipped by pos < 1
+        d = as_int(toks[1]) if len(toks) > 1 else None
+        d = 0 if d is None else d
+        if pos < 1:
+            continue
+        if pos >= n:
+            break
+        rd[pos - 1] = d
+    return rd
+
+
+def test_depth_text_parsed_on_device(hot, tmp_path):
+    """Device text ingestion: comments, blank lines, CRLF, junk, missing positions, pos < 1,
+    the stop at pos >= n -- against the reference loop's semantics; unsorted input takes the host loop."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    depth = rng.poisson(30, n).astype(np.int32)
+    lines = ["# header", ""]
+    for pos in range(1, n + 40):                  # runs past the end: the loop must stop at pos >= n
+        if pos % 997 == 0:
+            continue                              # missing position stays 0
+        d = int(depth[pos - 1]) if pos <= n else 77
+        sep = "\t" if pos % 3 else "  "
+        lines.append(f"{pos}{sep}{d}" + ("\r" if pos % 5 == 0 else ""))
+        if pos == 1000:
+            lines += ["#comment in the middle", "", "chrS\t5\t9", "0\t55", "-3 4"]   # all skipped
+        if pos == 2000:
+            lines.append(f"{pos + 1}")            # position without a depth: stored as 0 ... then overwritten? no: next line is pos+1 again
+    text = "\n".join(lines)                       # no trailing newline
+    # the duplicate of position 2001 makes this file unsorted -> host loop; build a sorted variant as well
+    p_uns = tmp_path / "unsorted.txt"; p_uns.write_text(text)
+    sorted_lines = [ln for i, ln in enumerate(lines) if not (ln == "2001")]
+    p_srt = tmp_path / "sorted.txt"; p_srt.write_text("\n".join(sorted_lines) + "\n")
+    for path, src, want_fallback in ((p_srt, sorted_lines, 0), (p_uns, lines, 1)):
+        st = hot.load_depth_text(str(path), n)
+        got = hot.fetch("depth_in")
+        exp = _reference_text_semantics(src, n)
+        assert st["fallback"] == want_fallback, st
+        assert np.array_equal(got, exp), (path.name, int(np.sum(got != exp)))
+        assert st["bytes"] == path.stat().st_size and st["stored"] > 0.99 * n * (1 - 1 / 997) - 10
+
+
+def test_depth_text_big_file_matches_arrays(hot, hotlib, tmp_path):
+    """A 3 Mb chromosome through text (several 64 MB chunks would need > 5 Mb; this one checks the run
+    end to end): same calls as from the arrays."""
+    from rsicnv_amd import api
+    plan_kw = dict(n=3_000_017, seed=0x7E47, model=1, n_events=10, gaps=2, max_len=60000, end_n=8000, gap_len=30000)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    path = tmp_path / "depth.txt"
+    n = depth.size
+    pos = np.arange(1, n + 1)
+    with open(path, "w") as f:
+        np.savetxt(f, np.column_stack([pos, depth]), fmt="%d", delimiter="\t")
+    r_arr = hot.run(api.make_params(), np.concatenate([depth[:-1], [0]]).astype(np.int32), fasta)   # the last base is never set (Q7)
+    r_txt = hot.run_text(api.make_params(), str(path), fasta)
+    assert r_txt.text_stats["fallback"] == 0 and r_txt.text_stats["lines"] == n
+    ok, why = calls_equal(r_txt.calls("calls_raw"), r_arr.calls("calls_raw"), rtol=0)
+    assert ok, why
