@@ -111,6 +111,28 @@ int rsi_hot_load_depth_text(rsi_ctx* ctx, const char* path, int64_t n, rsi_text_
 /* rsi_hot_load_depth_text + rsi_hot_run on the loaded depth: fasta[n] in host memory.  stats may be NULL. */
 int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, const uint8_t* fasta, int64_t n,
                      rsi_result** out, rsi_text_stats* stats);
+
+/* ---- BAM pileup -> per-base depth, GPU-assisted -------------------------------------
+ * Replaces the read loop of load_data_from_bam (loaddata.cpp:277-333): reads of chromosome `chrom`
+ * (all of them, as bam_iter_query(ref, 0, 0x7fffffff) yields) that pass pos != 0, mapq >= minq, not
+ * secondary, not duplicate; every base of an M or '=' CIGAR operation with base quality >= min_baseq
+ * adds one to the depth at its reference position as resolve_cigar_pos computes it (samfunctions.cpp:
+ * 38-100, including that '=' / 'X' do not advance the position).  The host inflates the BGZF blocks
+ * (threads) and finds record boundaries; filters, CIGAR and qualities are evaluated on the device, one
+ * thread per read, into a difference array that a scan turns into the depth.  A `BAM.bai` next to the
+ * file is used to start at the chromosome's first read; without it the file is scanned from the top.
+ * Reference defaults: minq 0 (-q), min_baseq 13 (-Q), rsi.cpp:57-58. */
+typedef struct rsi_bam_stats {
+  int64_t n;                         /* length of the chromosome (header) */
+  int64_t bytes_compressed, bytes_inflated, records, used, runs;   /* work done; used = reads that passed the filters */
+  int32_t tid, indexed;              /* reference id of `chrom`; 1 if the .bai was used */
+  double t_total_ms, t_inflate_ms;   /* wall time of the load; of which the inflate threads (summed over chunks) */
+} rsi_bam_stats;
+/* Depth of `chrom` into the context's device depth buffer (int32[stats->n]); rsi_hot_fetch_i32("depth_in") reads it back. */
+int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats);
+/* rsi_hot_load_depth_bam + rsi_hot_run on the loaded depth; fasta[n] in host memory, n must equal the header's length. */
+int rsi_hot_run_bam(rsi_ctx* ctx, const rsi_params* p, const char* bam_path, const char* chrom, int minq, int min_baseq,
+                    const uint8_t* fasta, int64_t n, rsi_result** out, rsi_bam_stats* stats);
 /* Same, inputs already resident in device memory (HBM); they are not modified. */
 int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n,
                        rsi_result** out);

@@ -24,7 +24,7 @@ STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3:
 
 # every symbol include/rsi_hot.h and include/rsi_synth.h declare
 EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
-           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
+           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
            "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_synth_generate_host", "rsi_synth_generate_device"]
@@ -59,6 +59,12 @@ RSI_MAX_TIMED = 64
 class RsiTextStats(C.Structure):
     _fields_ = [("bytes", C.c_int64), ("lines", C.c_int64), ("stored", C.c_int64), ("beyond", C.c_int64),
                 ("fallback", C.c_int32), ("pad", C.c_int32), ("t_total_ms", C.c_double), ("t_parse_kernel_ms", C.c_double)]
+
+
+class RsiBamStats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("bytes_compressed", C.c_int64), ("bytes_inflated", C.c_int64), ("records", C.c_int64),
+                ("used", C.c_int64), ("runs", C.c_int64), ("tid", C.c_int32), ("indexed", C.c_int32),
+                ("t_total_ms", C.c_double), ("t_inflate_ms", C.c_double)]
 
 
 class RsiBatchTimes(C.Structure):
@@ -101,6 +107,9 @@ def load_library():
     L.rsi_hot_run_device.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.rsi_hot_load_depth_text.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(RsiTextStats)]
     L.rsi_hot_run_text.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(RsiTextStats)]
+    L.rsi_hot_load_depth_bam.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(RsiBamStats)]
+    L.rsi_hot_run_bam.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                  C.POINTER(C.c_void_p), C.POINTER(RsiBamStats)]
     L.rsi_result_ncalls.argtypes = [C.c_void_p, C.c_int]
     L.rsi_result_calls.argtypes = [C.c_void_p, C.c_int]
     L.rsi_result_calls.restype = C.POINTER(RsiCall)
@@ -256,6 +265,22 @@ class RsiHot:
         self._check(self.lib.rsi_hot_run_text(self.ctx, C.byref(params), os.fsencode(path), f.ctypes.data, f.size, C.byref(out), C.byref(st)))
         res = Result(self.lib, out)
         res.text_stats = {f_[0]: getattr(st, f_[0]) for f_ in RsiTextStats._fields_ if f_[0] != "pad"}
+        return res
+
+    def load_depth_bam(self, bam, chrom, minq=0, min_baseq=13):
+        """Per-base depth of `chrom` from a BAM file into the context's device depth buffer (rsi_hot_load_depth_bam)."""
+        st = RsiBamStats()
+        self._check(self.lib.rsi_hot_load_depth_bam(self.ctx, os.fsencode(bam), chrom.encode(), int(minq), int(min_baseq), C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in RsiBamStats._fields_}
+
+    def run_bam(self, params, bam, chrom, fasta, minq=0, min_baseq=13):
+        f = np.ascontiguousarray(fasta, dtype=np.uint8)
+        out = C.c_void_p()
+        st = RsiBamStats()
+        self._check(self.lib.rsi_hot_run_bam(self.ctx, C.byref(params), os.fsencode(bam), chrom.encode(), int(minq), int(min_baseq),
+                                             f.ctypes.data, f.size, C.byref(out), C.byref(st)))
+        res = Result(self.lib, out)
+        res.bam_stats = {f_[0]: getattr(st, f_[0]) for f_ in RsiBamStats._fields_}
         return res
 
     def run_device(self, params, d_depth_ptr, d_fasta_ptr, n):

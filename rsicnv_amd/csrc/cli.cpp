@@ -142,9 +142,9 @@ int main(int argc, char** argv) {
     std::cerr << "rsicnv " << o.function << ": not part of the accelerated read-depth path in this build" << std::endl;
     return 0;
   }
-  if (!o.bamfile.empty()) {
-    std::cerr << "BAM input (-b) is not wired up in this build yet: produce a depth file with\n"
-              << "  samtools mpileup BAM | cut -f2,4   and pass it with -d RDFILE -c RNAME" << std::endl;
+  const bool from_bam = !o.bamfile.empty();
+  if (from_bam && (o.chr.empty() || o.chr == "1-22XY")) {
+    std::cerr << "BAM input (-b): name the chromosome with -c RNAME (one chromosome per run in this build)" << std::endl;
     return 0;
   }
   std::ofstream log((o.outfile + ".log").c_str());
@@ -166,14 +166,27 @@ int main(int argc, char** argv) {
   if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
   rsi_result* res = nullptr;
   rsi_text_stats ts;
-  // the depth file is parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517)
-  const int rc = rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
+  rsi_bam_stats bs;
+  memset(&ts, 0, sizeof(ts)); memset(&bs, 0, sizeof(bs));
+  // the depth comes from a text file parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517) or from
+  // the BAM file's reads, inflated on the host and piled up on the device (load_data_from_bam, loaddata.cpp:277-333)
+  const int rc = from_bam
+      ? rsi_hot_run_bam(ctx, &o.P, o.bamfile.c_str(), o.chr.c_str(), o.minq, o.min_baseQ, reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &bs)
+      : rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
   if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
     std::cerr << rsi_hot_last_error(ctx) << std::endl; log << rsi_hot_last_error(ctx) << std::endl;
     rsi_hot_destroy(ctx);
     return 0;
   }
   const double t2 = now_s();
+  if (from_bam && o.saverd) {   // -s: write_rd_to_file, loaddata.cpp:340-344, 464-470
+    const std::string dump = o.outfile + "." + o.chr + "_rd";
+    std::vector<int32_t> rd((size_t)bs.n);
+    rsi_hot_fetch_i32(ctx, "depth_in", rd.data(), bs.n);
+    FILE* f = fopen(dump.c_str(), "w");
+    if (f) { for (int64_t i = 0; i < bs.n; ++i) fprintf(f, "%lld\t%d\n", (long long)i + 1, rd[(size_t)i]); fclose(f); }
+    std::cerr << "RD of " << o.chr << " is saved to " << dump << std::endl; log << "RD of " << o.chr << " is saved to " << dump << std::endl;
+  }
   const rsi_chrom_stats* S = rsi_result_stats(res);
   std::ostringstream info;
   info << "#Noseq regions excluded\n";
@@ -190,14 +203,21 @@ int main(int argc, char** argv) {
        << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
        << "Selected " << rsi_result_ncalls(res, 3) << " segments for testing\n"
        << "Found " << rsi_result_ncalls(res, 1) << " CNVs before sd_filters, " << rsi_result_ncalls(res, 0) << " written\n"
-       << "timing: fasta " << (t1 - t0) << " s, depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
-       << (ts.fallback ? ", host parser: positions not increasing" : "") << "), whole device path " << (t2 - t1) << " s (" << S->t_device_ms
-       << " ms on resident inputs)\n";
+       << "timing: fasta " << (t1 - t0) << " s, ";
+  if (from_bam)
+    info << "BAM pileup " << bs.t_total_ms * 1e-3 << " s (" << bs.bytes_compressed << " bytes compressed, " << bs.records << " reads read, " << bs.used
+         << " counted, inflate " << bs.t_inflate_ms * 1e-3 << " s" << (bs.indexed ? ", index used" : ", no index: scanned from the top") << ")";
+  else
+    info << "depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
+         << (ts.fallback ? ", host parser: positions not increasing" : "") << ")";
+  info << ", whole device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
+  if (from_bam) info << "note: RP / Q0 annotation of the calls (cnv_stat) is not part of this build: those columns stay empty\n";
   std::cerr << info.str(); log << info.str();
 
   // write_cnv_to_file, rsi.cpp:1592-1616
   std::ofstream out(o.outfile.c_str());
   if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << o.chr << std::endl;
+  if (from_bam) out << "#input " << o.bamfile << std::endl;
   if (o.P.gcadjust) out << "#GC adjusted\n";
   out << kHeader << std::endl;
   char row[1024];

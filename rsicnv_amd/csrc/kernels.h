@@ -181,4 +181,13 @@ int text_parse_workgroups(long long nbytes);
 void launch_parse_depth_text(const void* text, long long nbytes, long long size, int32_t* depth, long long* wg_first,
                              long long* wg_max, TextParseStats* stats, hipStream_t stream);
 
+// ---- BAM pileup -> depth (kernels_io.hip; load_data_from_bam, loaddata.cpp:277-333 + resolve_cigar_pos, samfunctions.cpp:38-100) ----
+struct BamDepthStats { unsigned long long used, runs; };
+// One thread per record: data = inflated BAM bytes, rec_off[i] = offset of record i's block_size field.  diff: int32[n + 1], zeroed
+// before the first chunk; launch_inclusive_scan_i32 over n turns it into the depth (tile_scratch: scan_tiles(n) ints).
+void launch_bam_depth(const void* data, const uint32_t* rec_off, int nrec, int tid, int minq, int min_baseq, long long n, int32_t* diff,
+                      BamDepthStats* stats, hipStream_t stream);
+int scan_tiles(long long n);
+void launch_inclusive_scan_i32(int32_t* x, long long n, int32_t* tile_scratch, hipStream_t stream);
+
 }  // namespace rsik

@@ -107,3 +107,142 @@ void launch_parse_depth_text(const void* text, long long nbytes, long long size,
 }
 
 }  // namespace rsik
+
+// ------------------------------------------------------------------------------------------
+// BAM pileup -> per-base depth.  The host inflates the BGZF blocks and finds the
+// record boundaries; everything the reference does per read -- the filters of load_data_from_bam
+// (loaddata.cpp:313-320), the CIGAR positions of resolve_cigar_pos (samfunctions.cpp:38-100) and the
+// per-base quality test (loaddata.cpp:328-331) -- runs here, one thread per record, on the inflated
+// bytes in HBM.  A run of counted bases becomes +1 / -1 in a difference array; an inclusive scan turns
+// that into the depth.
+namespace rsik {
+
+namespace {
+
+__device__ inline uint32_t ld_u32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ inline uint32_t ld_u16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+enum { kCigM = 0, kCigI = 1, kCigD = 2, kCigN = 3, kCigS = 4, kCigEq = 7, kCigX = 8 };
+
+__global__ __launch_bounds__(256) void k_bam_depth(const unsigned char* __restrict__ data, const uint32_t* __restrict__ rec_off,
+                                                   int nrec, int tid, int minq, int min_baseq, long long n,
+                                                   int32_t* __restrict__ diff, BamDepthStats* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned used = 0, runs = 0;
+  if (i < nrec) {
+    const unsigned char* b = data + rec_off[i] + 4;       // past block_size
+    const int rtid = (int)ld_u32(b), pos0 = (int)ld_u32(b + 4);
+    const int l_name = b[8], mapq = b[9];
+    const int n_cig = (int)ld_u16(b + 12), flag = (int)ld_u16(b + 14);
+    const int l_seq = (int)ld_u32(b + 16);
+    // loaddata.cpp:315-319: pos == 0, tid < 0, mapq, secondary, duplicate (the iterator only yields this tid)
+    const bool keep = rtid == tid && pos0 != 0 && mapq >= minq && !(flag & 0x100) && !(flag & 0x400);
+    if (keep) {
+      const unsigned char* cig = b + 32 + l_name;
+      const unsigned char* qual = cig + 4 * n_cig + (l_seq + 1) / 2;
+      // anchor: the first M / D / = / X (samfunctions.cpp:75-78); without one the read contributes nothing
+      int anchor = -1;
+      for (int k = 0; k < n_cig && anchor < 0; ++k) { const int op = cig[4 * k] & 0xf; if (op == kCigM || op == kCigD || op == kCigEq || op == kCigX) anchor = k; }
+      if (anchor >= 0) {
+        used = 1;
+        long long ref_end = (long long)pos0 + 1;     // 1-based position of op `anchor` (samfunctions.cpp:85-92)
+        int q = 0;
+        for (int k = 0; k < n_cig; ++k) {
+          const uint32_t c = ld_u32(cig + 4 * k);
+          const int op = (int)(c & 0xf), len = (int)(c >> 4);
+          if (k >= anchor && (op == kCigM || op == kCigEq)) {
+            const long long p1 = ref_end - 1;        // 0-based reference position of the op's first base
+            // bases with quality >= min_baseq, in runs (loaddata.cpp:328-331)
+            long long run_start = -1;
+            for (int t = 0; t < len; ++t) {
+              const long long p = p1 + t;
+              if (p >= n) break;
+              const bool ok = qual[q + t] >= min_baseq;
+              if (ok && run_start < 0) run_start = p;
+              if (!ok && run_start >= 0) { atomicAdd(&diff[run_start], 1); atomicAdd(&diff[p], -1); run_start = -1; ++runs; }
+            }
+            if (run_start >= 0) {
+              long long e = p1 + len; if (e > n) e = n;
+              atomicAdd(&diff[run_start], 1); atomicAdd(&diff[e], -1); ++runs;
+            }
+          }
+          // ops before the anchor never match (they are I / S / H / N / P); their positions are not needed
+          if (k >= anchor && (op == kCigM || op == kCigD || op == kCigN || op == kCigS)) ref_end += len;   // '=' and 'X' do not advance: reference quirk
+          if (op == kCigM || op == kCigI || op == kCigS || op == kCigEq || op == kCigX) q += len;          // samfunctions.cpp:67-71
+        }
+      }
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) { used += __shfl_xor(used, d); runs += __shfl_xor(runs, d); }
+  if ((threadIdx.x & 63) == 0) { if (used) atomicAdd(&stats->used, (unsigned long long)used); if (runs) atomicAdd(&stats->runs, (unsigned long long)runs); }
+}
+
+// ---- inclusive scan of int32 in place: tile sums, scan of the tile sums, tile scan + offset ----
+constexpr int kScanThreads = 256, kScanPer = 16, kScanTileElems = kScanThreads * kScanPer;
+
+__device__ inline int wg_exscan_i32(int v, int* s_w /* 4 */, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kScanThreads / 64; ++w) { if (w < wave) base += s_w[w]; tot += s_w[w]; }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const int32_t* __restrict__ x, long long n, int32_t* __restrict__ tile_sum) {
+  __shared__ int s_w[kScanThreads / 64];
+  const long long e0 = (long long)blockIdx.x * kScanTileElems + (long long)threadIdx.x * kScanPer;
+  int s = 0;
+  for (int k = 0; k < kScanPer; ++k) if (e0 + k < n) s += x[e0 + k];
+  int total;
+  (void)wg_exscan_i32(s, s_w, &total);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_offsets(int32_t* __restrict__ tile_sum, int ntiles) {   // exclusive, in place, one workgroup
+  __shared__ int s_w[kScanThreads / 64];
+  int carry = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += kScanThreads) {
+    const int t = t0 + (int)threadIdx.x;
+    const int v = t < ntiles ? tile_sum[t] : 0;
+    int total;
+    const int ex = wg_exscan_i32(v, s_w, &total);
+    if (t < ntiles) tile_sum[t] = carry + ex;
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t* __restrict__ x, long long n, const int32_t* __restrict__ tile_off) {
+  __shared__ int s_w[kScanThreads / 64];
+  const long long e0 = (long long)blockIdx.x * kScanTileElems + (long long)threadIdx.x * kScanPer;
+  int v[kScanPer];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) { v[k] = e0 + k < n ? x[e0 + k] : 0; s += v[k]; v[k] = s; }
+  int total;
+  const int base = tile_off[blockIdx.x] + wg_exscan_i32(s, s_w, &total);
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) if (e0 + k < n) x[e0 + k] = base + v[k];
+}
+
+}  // namespace
+
+void launch_bam_depth(const void* data, const uint32_t* rec_off, int nrec, int tid, int minq, int min_baseq, long long n, int32_t* diff,
+                      BamDepthStats* stats, hipStream_t stream) {
+  if (nrec <= 0) return;
+  hipLaunchKernelGGL(k_bam_depth, dim3((nrec + 255) / 256), dim3(256), 0, stream, static_cast<const unsigned char*>(data), rec_off, nrec, tid,
+                     minq, min_baseq, n, diff, stats);
+}
+int scan_tiles(long long n) { return (int)((n + kScanTileElems - 1) / kScanTileElems); }
+void launch_inclusive_scan_i32(int32_t* x, long long n, int32_t* tile_scratch, hipStream_t stream) {
+  const int ntiles = scan_tiles(n);
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, stream, tile_scratch, ntiles);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
+}
+
+}  // namespace rsik

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/rsi_hot.h"
+#include "bam_host.h"
 #include "host_calls.h"
 #include "hostmath.h"
 #include "kernels.h"
@@ -1312,6 +1313,159 @@ int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, 
   ctx->ktimes.clear(); ctx->event_next = 0;
   int rc = rsi_hot_load_depth_text(ctx, depth_path, n, stats);
   if (rc != RSI_OK) return rc;
+  HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
+  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
+}
+
+
+int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats) {
+  rsi_bam_stats local;
+  rsi_bam_stats* st = stats ? stats : &local;
+  memset(st, 0, sizeof(*st));
+  if (!ctx || !bam_path || !chrom) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  const double t0 = now_ms();
+  HIPCHK(hipSetDevice(ctx->device));
+  std::string err;
+  rsih::BamFile bam;
+  if (!bam.open(bam_path, err)) return fail(ctx, RSI_ERR_BAD_ARG, err);
+  std::vector<std::pair<std::string, int64_t>> refs;
+  uint64_t voff = 0;
+  if (!bam.read_header(refs, voff, err)) return fail(ctx, RSI_ERR_BAD_ARG, err);
+  int tid = -1;
+  for (size_t r = 0; r < refs.size(); ++r) if (refs[r].first == chrom) tid = (int)r;
+  if (tid < 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("chromosome not in the BAM header: ") + chrom);
+  const int64_t n = refs[(size_t)tid].second;
+  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
+  st->tid = tid; st->n = n;
+  uint64_t idx_off = 0;
+  if (rsih::bai_first_offset(std::string(bam_path) + ".bai", tid, idx_off)) { voff = idx_off; st->indexed = 1; }
+
+  mailbox_reset(ctx);
+  HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
+  int32_t* d_diff = ctx->in_depth.as<int32_t>();     // difference array first, scanned in place into the depth
+  HIPCHK(hipMemsetAsync(d_diff, 0, (size_t)(n + 1) * 4, ctx->stream));
+  ctx->n_in = n;
+  if (ctx->text_pin_cap < kTextChunk) {
+    for (int b = 0; b < 2; ++b) {
+      if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
+      ctx->text_pin[b] = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->text_pin[b]), kTextChunk, hipHostMallocDefault) != hipSuccess)
+        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the BAM staging");
+    }
+    ctx->text_pin_cap = kTextChunk;
+  }
+  HIPCHK(ctx->text_dev[0].ensure(kTextChunk));
+  HIPCHK(ctx->text_dev[1].ensure(kTextChunk));
+  constexpr size_t kMaxRec = kTextChunk / 36 + 16;   // a record is at least 36 bytes
+  const size_t stats_off = 2 * kMaxRec * 4, scan_off = stats_off + 256;
+  HIPCHK(ctx->text_wg.ensure(scan_off + (size_t)scan_tiles(n) * 4 + 64));
+  uint8_t* wsb = ctx->text_wg.as<uint8_t>();
+  BamDepthStats* d_stats = reinterpret_cast<BamDepthStats*>(wsb + stats_off);
+  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(BamDepthStats), ctx->stream));
+
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; ++b) if (hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) return fail(ctx, RSI_ERR_HIP, "hipEventCreate failed");
+  struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } evguard{done};
+  bool used[2] = {false, false};
+  std::vector<uint32_t> rec_off[2];
+  const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+
+  uint64_t coff = voff >> 16;            // next block to inflate
+  size_t skip = (size_t)(voff & 0xffff); // bytes of the first block that precede the first record
+  size_t carry = 0;                      // bytes of an unfinished record parked at the front of the buffer being filled
+  bool finished = false;
+  int cur = 0;
+  while (!finished) {
+    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[cur]);
+    // ---- the next run of blocks that fits ----
+    std::vector<rsih::BgzfBlock> blocks;
+    std::vector<size_t> at;              // where each block lands in buf
+    size_t have = carry;
+    bool eof = false;
+    for (;;) {
+      rsih::BgzfBlock b;
+      err.clear();
+      if (!bam.block_at(coff, b, err)) { if (!err.empty()) return fail(ctx, RSI_ERR_BAD_ARG, err); eof = true; break; }
+      if (have + b.isize > kTextChunk) break;
+      blocks.push_back(b); at.push_back(have);
+      have += b.isize; coff += b.csize;
+      st->bytes_compressed += b.csize;
+    }
+    if (blocks.empty() && !eof) return fail(ctx, RSI_ERR_UNSUPPORTED, "a BAM record is longer than 64 MB");
+    {   // inflate in parallel
+      const double ti = now_ms();
+      std::atomic<size_t> next(0);
+      std::atomic<bool> bad(false);
+      std::string terr;
+      std::mutex emu;
+      auto work = [&]() {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= blocks.size()) break;
+          std::string e2;
+          if (!bam.inflate(blocks[k], buf + at[k], e2)) { bad = true; std::lock_guard<std::mutex> lk(emu); terr = e2; }
+        }
+      };
+      std::vector<std::thread> th;
+      const unsigned nt = (unsigned)std::min<size_t>(nthreads, blocks.size());
+      for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+      work();
+      for (auto& t : th) t.join();
+      if (bad) return fail(ctx, RSI_ERR_BAD_ARG, terr);
+      st->t_inflate_ms += now_ms() - ti;
+      st->bytes_inflated += (int64_t)(have - carry);
+    }
+    // ---- record boundaries; the BAM is coordinate sorted, so reading ends with the first read beyond `tid` ----
+    std::vector<uint32_t>& offs = rec_off[cur];
+    offs.clear();
+    size_t p = skip;                     // `skip` only applies to the very first chunk (carry == 0 there)
+    skip = 0;
+    while (p + 4 <= have) {
+      const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
+      if (bs < 32) return fail(ctx, RSI_ERR_BAD_ARG, "malformed BAM record");
+      if (p + 4 + bs > have) break;
+      const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
+      ++st->records;
+      if (rtid == tid) offs.push_back((uint32_t)p);
+      else if (rtid > tid || rtid < 0) { finished = true; break; }
+      p += 4 + (size_t)bs;
+    }
+    if (eof) finished = true;
+    const size_t len = p;                // bytes of whole records examined
+    if (!offs.empty()) {
+      uint32_t* d_off = reinterpret_cast<uint32_t*>(wsb + (size_t)cur * kMaxRec * 4);
+      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf, len, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d_off, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      { Timer t(ctx, "bam_depth"); launch_bam_depth(ctx->text_dev[cur].p, d_off, (int)offs.size(), tid, minq, min_baseq, (long long)n, d_diff, d_stats, ctx->stream); }
+      HIPCHK(hipEventRecord(done[cur], ctx->stream));
+      used[cur] = true;
+    }
+    const int other = cur ^ 1;
+    if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); used[other] = false; }
+    carry = finished ? 0 : have - len;
+    if (carry) memcpy(ctx->text_pin[other], buf + len, carry);
+    cur = other;
+  }
+  { Timer t(ctx, "depth_scan"); launch_inclusive_scan_i32(d_diff, (long long)n, reinterpret_cast<int32_t*>(wsb + scan_off), ctx->stream); }
+  BamDepthStats hs;
+  HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs;
+  st->t_total_ms = now_ms() - t0;
+  return RSI_OK;
+}
+
+int rsi_hot_run_bam(rsi_ctx* ctx, const rsi_params* p, const char* bam_path, const char* chrom, int minq, int min_baseq,
+                    const uint8_t* fasta, int64_t n, rsi_result** out, rsi_bam_stats* stats) {
+  if (!ctx || !p || !bam_path || !chrom || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
+  rsi_bam_stats local;
+  rsi_bam_stats* st = stats ? stats : &local;
+  ctx->ktimes.clear(); ctx->event_next = 0;
+  int rc = rsi_hot_load_depth_bam(ctx, bam_path, chrom, minq, min_baseq, st);
+  if (rc != RSI_OK) return rc;
+  if (st->n != n) return fail(ctx, RSI_ERR_BAD_ARG, "reference and target not same size (loaddata.cpp:284-287)");
   HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
   HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

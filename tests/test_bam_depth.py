@@ -1,0 +1,96 @@
+"""BAM pileup -> depth.  CPU: the Python restatement of the reference's rules against the golden
+depth the real reference produced (tests/golden/bam_small.npz, tools/make_golden_bam.py).  GPU: the library
+(host inflate + device pileup) against the same golden file, against the restatement, and -- where the compiled
+reference is present -- against a fresh `-s` dump of the reference binary, plus the command line."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bam_util as bu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bam_small.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_rules_match_reference_golden(tmp_path):
+    g = np.load(GOLDEN)
+    _, refs, recs = bu.build_golden_bam(str(tmp_path))
+    for t, (chrom, n) in enumerate(refs):
+        for q, Q in bu.golden_spec()["settings"]:
+            assert np.array_equal(bu.depth_rules(recs, t, n, minq=q, min_baseq=Q), g[f"{chrom}_q{q}_Q{Q}"]), (chrom, q, Q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indexed", [False, True])
+def test_library_depth_matches_reference_golden(hotlib, tmp_path, indexed):
+    from rsicnv_amd import api
+    import oracle
+    g = np.load(GOLDEN)
+    bam, refs, recs = bu.build_golden_bam(str(tmp_path))
+    libref = os.path.join(os.path.dirname(oracle.REF_BIN), "libref.so")
+    if indexed:
+        if not os.path.exists(libref):
+            pytest.skip("no compiled reference to build the .bai with")
+        import ctypes
+        L = ctypes.CDLL(libref)
+        L.bam_index_build.argtypes = [ctypes.c_char_p]
+        assert L.bam_index_build(os.fsencode(bam)) == 0
+    h = api.RsiHot(0)
+    for t, (chrom, n) in enumerate(refs):
+        for q, Q in bu.golden_spec()["settings"]:
+            st = h.load_depth_bam(bam, chrom, minq=q, min_baseq=Q)
+            assert st["n"] == n and st["tid"] == t and st["indexed"] == int(indexed)
+            got = h.fetch("depth_in")
+            assert np.array_equal(got, g[f"{chrom}_q{q}_Q{Q}"]), (chrom, q, Q, int(np.sum(got != g[f"{chrom}_q{q}_Q{Q}"])))
+    h.close()
+
+
+@pytest.mark.gpu
+def test_bam_end_to_end_against_reference_binary(hotlib, tmp_path):
+    """A 2 Mb chromosome at 25x through a BAM of many BGZF blocks: depth equal to the reference's -s dump, calls equal
+    to the calls from the same depth as arrays; the command line's -s dump equal too, and its rows equal to the reference
+    binary's up to the RP / Q0 column when the reference gets that far (its annotation pass is not part of this build)."""
+    import oracle
+    from conftest import make_case, calls_equal
+    from test_hot_extra import _write_case
+    from rsicnv_amd import api
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref/rsicnv_ref not built")
+    n = 2_000_003
+    _, fasta, depth = make_case(hotlib, dict(n=n, seed=0xBA5, model=0, n_events=8, gaps=2, max_len=50000, end_n=8000, gap_len=20000))
+    fa, _ = _write_case(str(tmp_path), fasta, depth)
+    # properly paired reads whose local coverage follows the synthetic depth (so that there is something to call, and
+    # so that the reference's read-pair annotation pass, which runs in -b mode, finds the pairs it samples)
+    recs = bu.paired_reads_following_depth(depth, n)
+    bam = str(tmp_path / "big.bam")
+    bu.write_bam(bam, [("chrS", n)], recs)
+    libref = os.path.join(os.path.dirname(oracle.REF_BIN), "libref.so")
+    ref_rd, ref_out = bu.reference_depth_dump(oracle.REF_BIN, libref, bam, fa, "chrS", str(tmp_path))
+    h = api.RsiHot(0)
+    res = h.run_bam(api.make_params(), bam, "chrS", fasta)
+    assert res.bam_stats["indexed"] == 1 and res.bam_stats["records"] == len(recs)
+    assert np.array_equal(h.fetch("depth_in"), ref_rd)
+    res_arr = h.run(api.make_params(), ref_rd, fasta)
+    ok, why = calls_equal(res.calls("calls"), res_arr.calls("calls"), rtol=0)
+    assert ok, why
+    assert len(res.calls("calls")) >= 3
+    h.close()
+    # command line
+    exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+    ours = str(tmp_path / "ours.txt")
+    subprocess.run([exe, "rsi", "-b", bam, "-f", fa, "-c", "chrS", "-o", ours, "-np", "-s"], check=True, capture_output=True, timeout=300)
+    dump = np.loadtxt(ours + ".chrS_rd", dtype=np.int64)
+    assert np.array_equal(dump[:, 1].astype(np.int32), ref_rd)
+    def rows(path):
+        out = []
+        for ln in open(path).read().splitlines():
+            cols = ln.split("\t")
+            out.append("\t".join(c for i, c in enumerate(cols) if not (len(cols) > 8 and i == 7)))   # drop the RP/Q0 column of data rows
+        return out
+    if ref_out is not None:   # the reference survives its annotation pass only on chromosomes beyond 10 Mb (see bam_util)
+        a, b = rows(ours), rows(ref_out)
+        assert a == b, "\n".join(a[:8]) + "\n---\n" + "\n".join(b[:8])
+    else:
+        assert len(rows(ours)) == 3 + len(res.calls("calls"))
