@@ -1,7 +1,8 @@
 // cli.cpp -- `rsicnv rsi ...`: the reference's command line (rsi.cpp:1949-2068, 2069-2217) in
 // front of librsi_hot.so.  Same flags and defaults, same output file (header lines, columns,
-// number formatting).  This round serves the depth-file input (-d RDFILE -c RNAME); BAM pileup
-// (-b), plot, stat and pin are outside the accelerated path and say so.
+// number formatting).  Inputs: a depth file (-d RDFILE -c RNAME, parsed on the device) or a BAM
+// file (-b BAMFILE -c RNAME, piled up on the device); the RP / Q0 annotation of the -b mode, plot,
+// stat and pin are outside the accelerated path and say so.
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,7 +45,8 @@ int usage() {
             << "   -gpu INT  HIP device to run on, default=0\n"
             << "\nNote:\n"
             << "   This build runs the read-depth hot path on an MI355X; input is a read depth file\n"
-            << "   (samtools mpileup BAM | cut -f2,4) with -c RNAME, plus the indexed reference.\n"
+            << "   (samtools mpileup BAM | cut -f2,4) or a coordinate-sorted BAM file, with -c RNAME (one\n"
+            << "   chromosome per run), plus the indexed reference.  -s saves the BAM's depth to OUT.RNAME_rd.\n"
             << std::endl;
   return 0;
 }
