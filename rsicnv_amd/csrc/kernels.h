@@ -49,12 +49,14 @@ struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int ne
 struct ValueMedian { unsigned long long inrange; int32_t lo, hi, med, pad; };
 void launch_value_median(const uint32_t* hist, uint64_t total, ValueMedian* out, hipStream_t stream);
 size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
-void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+// table: kGcLevels level means followed by the mean of the positive depths (launch_gc_table builds it on the device)
+void launch_gc_table(const GcAccum* acc, double* table, hipStream_t stream);
+void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream);
 void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream);   // must follow launch_gc_rescale
 // Must follow launch_gc_rescale: tail quirks of the 20-slice write-back fixed
 // in out[] and hist[], plus the last n % 4 bases, which the streaming kernel leaves out.
-void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                           int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----

@@ -412,8 +412,8 @@ __device__ __attribute__((noinline)) void value_hist_add(unsigned int* s_hist, u
 template <bool ADJUST>
 __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restrict__ depth,
                                                          const uint64_t* __restrict__ gcbits, int64_t n,
-                                                         int64_t nwords, const double* __restrict__ table,
-                                                         double rdmean, int32_t* __restrict__ out,
+                                                         int64_t nwords, const double* __restrict__ table /* [kGcLevels] + rdmean */,
+                                                         int32_t* __restrict__ out,
                                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
                                                          unsigned int* __restrict__ hist_slabs) {
   __shared__ GcTile gt;
@@ -422,6 +422,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   __shared__ unsigned int s_hist[kValLds * 32];
   for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
   if (ADJUST) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
+  const double rdmean = ADJUST ? table[kGcLevels] : 0.0;
   const int phase = threadIdx.x & 31;
   const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
   auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
@@ -506,9 +507,10 @@ __global__ void k_gc_hist_tail(const int32_t* __restrict__ depth, const uint64_t
 // that the streaming kernel leaves out.  One thread.  adjust = 0: only the ragged quad's values are
 // added to the histogram (the -NOGC path has no slices).
 __global__ void k_gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
-                                const double* __restrict__ table, double rdmean, int adjust, int32_t* __restrict__ out,
+                                const double* __restrict__ table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
                                 uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave; lane k handles tail cell k (r <= 19)
+  const double rdmean = adjust ? table[kGcLevels] : 0.0;
   const int lane = threadIdx.x;
   const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
   auto hist_add = [&](int to) {
@@ -804,23 +806,39 @@ void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n
   if (n & 3) hipLaunchKernelGGL(k_gc_hist_tail, dim3(1), dim3(64), 0, stream, depth, gcbits, n, acc);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
-void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+// GC table on the device (gccontent.cpp:109-112, 141-145): level means, the mean of the positive depths where a
+// level is empty or below 1; table[kGcLevels] = that mean.  Saves the host round trip between K2 and K3.
+__global__ void k_gc_table(const GcAccum* __restrict__ acc, double* __restrict__ table) {
+  double rdmean = (double)acc->possum;
+  if (acc->poscnt > 0) rdmean /= (double)acc->poscnt;
+  for (int g = threadIdx.x; g < kGcLevels; g += blockDim.x) {
+    double t = acc->cnt[g] > 0 ? (double)acc->sum[g] / (double)acc->cnt[g] : rdmean;
+    if (t < 1) t = rdmean;
+    table[g] = t;
+  }
+  if (threadIdx.x == 0) table[kGcLevels] = rdmean;
+}
+void launch_gc_table(const GcAccum* acc, double* table, hipStream_t stream) {
+  hipLaunchKernelGGL(k_gc_table, dim3(1), dim3(256), 0, stream, acc, table);
+}
+
+void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   const dim3 g(grid), b(kThreads);
   unsigned int* sl = static_cast<unsigned int*>(slabs);
-  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
-  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, rdmean, out, hist, aux, sl);
+  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl);
+  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl);
 }
 void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   hipLaunchKernelGGL(k_hist_slab_reduce, dim3((kValLds + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
                      static_cast<const unsigned int*>(slabs), grid, kValLds, hist);
 }
-void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, double rdmean,
+void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                           int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
   if (!adjust && (n & 3) == 0) return;
-  hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, rdmean, adjust, out, hist, aux);
+  hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, adjust, out, hist, aux);
 }
 
 // one workgroup of 1024 threads, 64 consecutive counters each

@@ -127,7 +127,6 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
-  double h_gc_table[256];     // GC table of the running chromosome (kGcLevels entries)
   std::vector<float> h_T;     // host copies of the bin arrays for filterstatus, grow-only
   std::vector<int> h_status;
   // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
@@ -795,20 +794,90 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   HIPCHK(ctx->hist_val.ensure((size_t)kHistValues * 4));
   uint8_t* small = ctx->small.as<uint8_t>();
   ph_a1a.stop();
-  Phase ph_a1b(ctx, "a1b.memset+launch");
+  Phase ph_a1b(ctx, "a1b.launch K1-K3");
   HIPCHK(hipMemsetAsync(small, 0, kOffTable, st));
 
-  // ---- A1: GC mask, N runs (K1, K1b) ----
+  // ---- A1-A4 are issued back to back: GC mask and N runs (K1, K1b), GC table and rescale (K2, K3), the cap
+  // median walk.  The GC table is built on the device, so nothing in this chain needs the host; the N-run list,
+  // the GC accumulators (for the checks and the log) and the median come back in ONE round trip. ----
   uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
   { Timer t(ctx, "fasta_classify"); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
   { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, st); }
-  ph_a1b.stop();
-  Phase ph_a1c(ctx, "a1c.fetch");
-  std::vector<Region> nruns;
-  int rc = fetch_pairs(ctx, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, nruns, true);
-  ph_a1c.stop();
+  constexpr uint32_t kEagerRuns = 1024;
+  uint32_t n_trans = 0;
+  std::vector<uint64_t> trans_raw(kEagerRuns);
+  HIPCHK(copy_d2h(ctx, &n_trans, d_ncount, 4));
+  HIPCHK(copy_d2h(ctx, trans_raw.data(), ctx->ntrans.p, (size_t)kEagerRuns * 8));
+
+  const int32_t* d_src = d_depth;
+  const bool want_cap = P.cap > 1;
+  if (P.gcadjust || want_cap) HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
+  ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
+  GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
+  double* d_table = reinterpret_cast<double*>(small + kOffTable);
+  ValueMedian* d_vm = reinterpret_cast<ValueMedian*>(small + kOffValMedian);
+  GcAccum acc;
+  ValueHistAux aux;
+  ValueMedian vm;
+  memset(&acc, 0, sizeof(acc)); memset(&aux, 0, sizeof(aux)); memset(&vm, 0, sizeof(vm));
+  // packed = 1 first; depths of 2^21 and more make the packed accumulators overflow (flag bit 1): everything from K2 on is
+  // then issued once more with the two-atomic form
+  auto issue_gc_chain = [&](int packed) -> int {
+    if (P.gcadjust) {
+      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, packed, ctx->slabs.p, st); }
+      { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
+      HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
+      { Timer t(ctx, "gc_table"); launch_gc_table(d_acc, d_table, st); }
+      HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
+      { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+      { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
+      { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+    } else if (want_cap) {
+      HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
+      { Timer t(ctx, "value_hist"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+      launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st);
+      launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
+    }
+    if (want_cap) {
+      // the median walk runs on the device (one small workgroup): 24 bytes come back instead of the 256 KB histogram
+      { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
+      HIPCHK(copy_d2h(ctx, &vm, d_vm, sizeof(vm)));
+      HIPCHK(copy_d2h(ctx, &aux, d_aux, sizeof(aux)));
+    }
+    return RSI_OK;
+  };
+  // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
+  if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), gc_rescale_slab_bytes(n))));
+  int rc = issue_gc_chain(1);
   if (rc != RSI_OK) return rc;
-  std::vector<Region> noncode;   // get_noseq_regions, loaddata.cpp:243-273: pad, clamp, re-merge
+  ph_a1b.stop();
+  { Phase ph_a1c(ctx, "a1c.wait K1-K3"); HIPCHK(CTX_SYNC()); }
+  if (P.gcadjust && (acc.negatives & 2u)) {
+    Phase ph_w(ctx, "a2-3.gc wide redo");
+    HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
+    HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
+    HIPCHK(hipMemsetAsync(d_aux, 0, sizeof(ValueHistAux), st));
+    if ((rc = issue_gc_chain(0)) != RSI_OK) return rc;
+    HIPCHK(CTX_SYNC());
+  }
+
+  // ---- N runs -> padded, merged regions (get_noseq_regions, loaddata.cpp:243-273) ----
+  std::vector<Region> nruns;
+  {
+    if (n_trans > kMaxTransitions) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
+    trans_raw.resize(n_trans > kEagerRuns ? n_trans : std::max<uint32_t>(n_trans, 0));
+    if (n_trans > kEagerRuns) {
+      HIPCHK(copy_d2h(ctx, trans_raw.data() + kEagerRuns, ctx->ntrans.as<uint64_t>() + kEagerRuns, (size_t)(n_trans - kEagerRuns) * 8));
+      HIPCHK(CTX_SYNC());
+    }
+    std::vector<int64_t> rs, re;
+    for (uint32_t i = 0; i < n_trans; ++i) { const uint64_t v = trans_raw[i]; ((v & 1) ? re : rs).push_back((int64_t)(v >> 1)); }
+    if (rs.size() != re.size()) return fail(ctx, RSI_ERR_INTERNAL, "unbalanced run boundaries");
+    std::sort(rs.begin(), rs.end());
+    std::sort(re.begin(), re.end());
+    for (size_t i = 0; i < rs.size(); ++i) nruns.push_back({(int)rs[i], (int)(re[i] - 1)});
+  }
+  std::vector<Region> noncode;
   {
     const int dx = std::max(50, P.m / 4);
     for (const Region& r : nruns) {
@@ -821,67 +890,20 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   S.n_noncode = (int)noncode.size();
   res->noncode.clear();
   for (const Region& r : noncode) { res->noncode.push_back(r.start); res->noncode.push_back(r.end); }
-
   ph_a1.stop();
-  Phase ph_gc(ctx, "a2-3.gc");
-  // ---- A2/A3: GC table and rescale (K2, K3) ----
-  const int32_t* d_src = d_depth;
-  const bool want_cap = P.cap > 1;
-  if (P.gcadjust || want_cap) HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
-  ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
+
+  Phase ph_cap(ctx, "a4.checks+cap");
   if (P.gcadjust) {
-    GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
-    HIPCHK(ctx->slabs.ensure(gc_hist_slab_bytes(n)));
-    { Timer t(ctx, "gc_hist"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 1, ctx->slabs.p, st); }
-    { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
-    GcAccum acc;
-    HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
-    HIPCHK(CTX_SYNC());
-    if (acc.negatives & 2u) {   // depths of 2^21 and more: the packed accumulators may have overflowed
-      HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
-      { Timer t(ctx, "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, 0, ctx->slabs.p, st); }
-      { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
-      HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
-      HIPCHK(CTX_SYNC());
-    }
     if (acc.negatives & 1u) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
-    double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112
+    double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112 (the device's k_gc_table computes the same)
     if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
-    double* table = ctx->h_gc_table;   // context-owned: the upload below may still be reading it when this scope ends
-    for (int g = 0; g < kGcLevels; ++g) {                     // gccontent.cpp:141-145
-      table[g] = acc.cnt[g] > 0 ? (double)acc.sum[g] / double(acc.cnt[g]) : rdmean;
-      if (table[g] < 1) table[g] = rdmean;
-    }
     S.gc_rdmean = rdmean;
-    double* d_table = reinterpret_cast<double*>(small + kOffTable);
-    HIPCHK(copy_h2d(ctx, d_table, table, sizeof(double) * kGcLevels));
-    HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-    HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-    { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
-    { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
-    { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, rdmean, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
-  } else if (want_cap) {
-    HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-    { Timer t(ctx, "value_hist"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
-    launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st);
-    launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0.0, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
   }
-
-  ph_gc.stop();
-  Phase ph_cap(ctx, "a4.cap_median");
   // ---- A4: cap from the median of the uncompacted array (loaddata.cpp:229-240, Q15) ----
   int32_t capval = 0x7fffffff;
   if (want_cap) {
-    // the median walk runs on the device (one small workgroup): 24 bytes come back instead of the 256 KB histogram
-    ValueHistAux aux;
-    ValueMedian vm;
-    ValueMedian* d_vm = reinterpret_cast<ValueMedian*>(small + kOffValMedian);
-    { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
-    HIPCHK(copy_d2h(ctx, &vm, d_vm, sizeof(vm)));
-    HIPCHK(copy_d2h(ctx, &aux, d_aux, sizeof(aux)));
-    HIPCHK(CTX_SYNC());
     if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     if (vm.inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
     if ((uint64_t)n / 2 > vm.inrange) return fail(ctx, RSI_ERR_UNSUPPORTED, "median depth above 65535");
