@@ -63,6 +63,25 @@ struct DevBuf {   // grow-only device allocation
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+struct PinBuf {   // grow-only pinned host allocation: destination of the large device -> host copies.  From pageable memory
+                  // the runtime stages such a copy synchronously under its own lock, which stalls every other worker's
+                  // HIP calls for milliseconds per copy.
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t scaled = (size_t)((double)bytes * tl_grow);
+    const size_t want = scaled + scaled / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
 struct KernelTime { const char* name; hipEvent_t a, b; };
 
 // One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
@@ -127,8 +146,7 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
-  std::vector<float> h_T;     // host copies of the bin arrays for filterstatus, grow-only
-  std::vector<int> h_status;
+  PinBuf h_T, h_status, h_status2, h_medint;   // pinned host copies of the bin arrays (filterstatus, block tests)
   // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
   char* mailbox = nullptr;
   size_t mb_cap = 0, mb_used = 0;
@@ -614,11 +632,12 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
   // definition (App. A Q13) -> host; the edge trimming runs on the device, one thread per run ----
-  std::vector<float>& hT = ctx->h_T;       // context-owned: no 20 MB of fresh pages per chromosome
-  std::vector<int>& hst = ctx->h_status;
-  if (hT.size() < (size_t)nb) { hT.resize((size_t)((double)nb * tl_grow) + 16); hst.resize(hT.size()); }
-  HIPCHK(copy_d2h(ctx, hT.data(), d_T, (size_t)nb * 4));
-  HIPCHK(copy_d2h(ctx, hst.data(), d_st1, (size_t)nb * 4));
+  HIPCHK(ctx->h_T.ensure((size_t)nb * 4));
+  HIPCHK(ctx->h_status.ensure((size_t)nb * 4));
+  const float* hT = ctx->h_T.as<float>();
+  const int* hst = ctx->h_status.as<int>();
+  HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
   {
@@ -630,8 +649,8 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     {
       float s0 = 0.0f;
       int n0 = 0;
-      const int* st = hst.data();
-      const float* tv = hT.data();
+      const int* st = hst;
+      const float* tv = hT;
       for (int64_t i = 0; i < nb; ++i) {
         const int s = st[i];
         if (s == 0) { s0 += tv[i]; ++n0; }
@@ -687,10 +706,11 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   GateShared gs_seg(ctx);
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
-  out.status2.resize((size_t)nb);
-  HIPCHK(copy_d2h(ctx, out.status2.data(), d_st2, (size_t)nb * 4));
+  HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
+  HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));   // into out.status2 after the next sync
   std::vector<Region> runs;
   if ((rc = marked_runs_device(ctx, d_st2, nb, runs)) != RSI_OK) return rc;   // synchronises
+  out.status2.assign(ctx->h_status2.as<int>(), ctx->h_status2.as<int>() + nb);
   out.segs.clear();
   if (runs.empty()) return RSI_OK;
   int32_t *d_rs, *d_re;
@@ -1027,9 +1047,10 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     gs_nb.release();
     rsih::CallerInput in;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
-    std::vector<int> medint((size_t)nb);
-    HIPCHK(copy_d2h(ctx, medint.data(), ctx->binmed.p, (size_t)nb * 4));
+    HIPCHK(ctx->h_medint.ensure((size_t)nb * 4));
+    HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(CTX_SYNC());
+    std::vector<int> medint(ctx->h_medint.as<int>(), ctx->h_medint.as<int>() + nb);
     in.binmedint = &medint;
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
