@@ -124,12 +124,15 @@ int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, 
  * Reference defaults: minq 0 (-q), min_baseq 13 (-Q), rsi.cpp:57-58. */
 typedef struct rsi_bam_stats {
   int64_t n;                         /* length of the chromosome (header) */
-  int64_t bytes_compressed, bytes_inflated, records, used, runs;   /* work done; used = reads that passed the filters */
+  int64_t bytes_compressed, bytes_inflated, records, on_chrom, used, runs;   /* records walked, reads of `chrom`, reads that passed the filters, runs of counted bases */
   int32_t tid, indexed;              /* reference id of `chrom`; 1 if the .bai was used */
   double t_total_ms, t_inflate_ms;   /* wall time of the load; of which the inflate threads (summed over chunks) */
 } rsi_bam_stats;
 /* Depth of `chrom` into the context's device depth buffer (int32[stats->n]); rsi_hot_fetch_i32("depth_in") reads it back. */
 int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats);
+/* Reference sequences of the BAM header: names as one '\n'-separated string into names[names_cap], lengths into
+ * lengths[max_refs]; returns their number (also when the buffers are too small or NULL), < 0 on error. */
+int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs);
 /* rsi_hot_load_depth_bam + rsi_hot_run on the loaded depth; fasta[n] in host memory, n must equal the header's length. */
 int rsi_hot_run_bam(rsi_ctx* ctx, const rsi_params* p, const char* bam_path, const char* chrom, int minq, int min_baseq,
                     const uint8_t* fasta, int64_t n, rsi_result** out, rsi_bam_stats* stats);

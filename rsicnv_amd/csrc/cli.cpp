@@ -45,8 +45,9 @@ int usage() {
             << "   -gpu INT  HIP device to run on, default=0\n"
             << "\nNote:\n"
             << "   This build runs the read-depth hot path on an MI355X; input is a read depth file\n"
-            << "   (samtools mpileup BAM | cut -f2,4) or a coordinate-sorted BAM file, with -c RNAME (one\n"
-            << "   chromosome per run), plus the indexed reference.  -s saves the BAM's depth to OUT.RNAME_rd.\n"
+            << "   (samtools mpileup BAM | cut -f2,4) with -c RNAME, or a coordinate-sorted BAM file (all\n"
+            << "   chromosomes with reads, or the one named with -c), plus the indexed reference.\n"
+            << "   -s saves the BAM's depth to OUT.RNAME_rd.\n"
             << std::endl;
   return 0;
 }
@@ -145,10 +146,6 @@ int main(int argc, char** argv) {
     return 0;
   }
   const bool from_bam = !o.bamfile.empty();
-  if (from_bam && (o.chr.empty() || o.chr == "1-22XY")) {
-    std::cerr << "BAM input (-b): name the chromosome with -c RNAME (one chromosome per run in this build)" << std::endl;
-    return 0;
-  }
   std::ofstream log((o.outfile + ".log").c_str());
   std::ostringstream hdr;
   hdr << "#command:   "; for (int i = 0; i < argc; ++i) hdr << argv[i] << " ";
@@ -156,16 +153,37 @@ int main(int argc, char** argv) {
       << "\n#min_mapq:  " << o.minq << "\n#min_baseQ: " << o.min_baseQ << "\n#binsize:   " << o.P.m << "\n#adjustGC:  " << o.P.gcadjust
       << "\n#output:    " << o.outfile << "\n";
   std::cerr << hdr.str(); log << hdr.str();
-  std::cerr << "#processing " << o.chr << std::endl; log << "#processing " << o.chr << std::endl;
 
-  const double t0 = now_s();
-  std::string fasta;
-  if (!read_fasta(o.reffile, o.chr, fasta)) return 0;
-  const double t1 = now_s();
+  // chromosomes to process: -c RNAME, or (BAM input, rsi.cpp:2114-2131) every reference of the header that is not
+  // a mitochondrial / decoy name and has reads
+  std::vector<std::string> todo;
+  if (from_bam && (o.chr.empty() || o.chr == "1-22XY")) {
+    std::vector<char> names(1 << 20);
+    const int nref = rsi_bam_references(o.bamfile.c_str(), names.data(), (int)names.size(), nullptr, 0);
+    if (nref < 0) { std::cerr << rsi_hot_last_error(nullptr) << std::endl; return 0; }
+    std::istringstream iss(names.data());
+    std::string nm;
+    std::cerr << "#Check bam header for 1-22XY \n"; log << "#Check bam header for 1-22XY \n";
+    while (std::getline(iss, nm)) {
+      if (nm.find("MT") != std::string::npos || nm.find(".") != std::string::npos) continue;
+      todo.push_back(nm);
+    }
+  } else {
+    todo.push_back(o.chr);
+  }
 
   int st = 0;
   rsi_ctx* ctx = rsi_hot_create(o.device, &st);
   if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
+  bool wrote_header = false;
+  for (const std::string& chr : todo) {
+  std::cerr << "#processing " << chr << std::endl; log << "#processing " << chr << std::endl;
+
+  const double t0 = now_s();
+  std::string fasta;
+  if (!read_fasta(o.reffile, chr, fasta)) { if (todo.size() > 1) continue; rsi_hot_destroy(ctx); return 0; }
+  const double t1 = now_s();
+
   rsi_result* res = nullptr;
   rsi_text_stats ts;
   rsi_bam_stats bs;
@@ -173,21 +191,27 @@ int main(int argc, char** argv) {
   // the depth comes from a text file parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517) or from
   // the BAM file's reads, inflated on the host and piled up on the device (load_data_from_bam, loaddata.cpp:277-333)
   const int rc = from_bam
-      ? rsi_hot_run_bam(ctx, &o.P, o.bamfile.c_str(), o.chr.c_str(), o.minq, o.min_baseQ, reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &bs)
+      ? rsi_hot_run_bam(ctx, &o.P, o.bamfile.c_str(), chr.c_str(), o.minq, o.min_baseQ, reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &bs)
       : rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
   if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
     std::cerr << rsi_hot_last_error(ctx) << std::endl; log << rsi_hot_last_error(ctx) << std::endl;
+    if (todo.size() > 1 && from_bam && bs.on_chrom == 0) continue;   // a reference without reads is simply not "populated" (rsi.cpp:2125)
     rsi_hot_destroy(ctx);
     return 0;
   }
   const double t2 = now_s();
+  if (from_bam && todo.size() > 1 && bs.on_chrom == 0) {   // not "populated": the reference does not process it (rsi.cpp:2125)
+    std::cerr << "no reads on " << chr << std::endl; log << "no reads on " << chr << std::endl;
+    rsi_result_free(res);
+    continue;
+  }
   if (from_bam && o.saverd) {   // -s: write_rd_to_file, loaddata.cpp:340-344, 464-470
-    const std::string dump = o.outfile + "." + o.chr + "_rd";
+    const std::string dump = o.outfile + "." + chr + "_rd";
     std::vector<int32_t> rd((size_t)bs.n);
     rsi_hot_fetch_i32(ctx, "depth_in", rd.data(), bs.n);
     FILE* f = fopen(dump.c_str(), "w");
     if (f) { for (int64_t i = 0; i < bs.n; ++i) fprintf(f, "%lld\t%d\n", (long long)i + 1, rd[(size_t)i]); fclose(f); }
-    std::cerr << "RD of " << o.chr << " is saved to " << dump << std::endl; log << "RD of " << o.chr << " is saved to " << dump << std::endl;
+    std::cerr << "RD of " << chr << " is saved to " << dump << std::endl; log << "RD of " << chr << " is saved to " << dump << std::endl;
   }
   const rsi_chrom_stats* S = rsi_result_stats(res);
   std::ostringstream info;
@@ -195,11 +219,11 @@ int main(int argc, char** argv) {
   {
     std::vector<int32_t> pairs((size_t)S->n_noncode * 2 + 2);
     const int k = rsi_result_noncode(res, pairs.data(), S->n_noncode);
-    for (int i = 0; i < k; ++i) info << o.chr << "\t" << pairs[2 * i] << "\t" << pairs[2 * i + 1] << "\n";
+    for (int i = 0; i < k; ++i) info << chr << "\t" << pairs[2 * i] << "\t" << pairs[2 * i + 1] << "\n";
   }
   if (o.P.gcadjust) info << "RD mean before GC adjust = " << S->gc_rdmean << "\n";
   if (o.P.cap > 1) info << "applying cap " << o.P.cap << " times of mean " << S->cap_median << "\ncap = " << o.P.cap * S->cap_median << "\n";
-  info << "region  : " << o.chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
+  info << "region  : " << chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
   info << "RD median absolute deviation : " << S->nb_mad << "\n"
        << "first pass\n\tmedian of transformations : " << S->tmedian1 << "\n\tsigma : " << S->tsigma1 << "\n\tlamda : " << S->tlamda1 << "\n"
        << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
@@ -216,20 +240,24 @@ int main(int argc, char** argv) {
   if (from_bam) info << "note: RP / Q0 annotation of the calls (cnv_stat) is not part of this build: those columns stay empty\n";
   std::cerr << info.str(); log << info.str();
 
-  // write_cnv_to_file, rsi.cpp:1592-1616
-  std::ofstream out(o.outfile.c_str());
-  if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << o.chr << std::endl;
-  if (from_bam) out << "#input " << o.bamfile << std::endl;
-  if (o.P.gcadjust) out << "#GC adjusted\n";
-  out << kHeader << std::endl;
+  // write_cnv_to_file, rsi.cpp:1592-1616: the first chromosome opens the file and writes the header, the others append
+  std::ofstream out(o.outfile.c_str(), wrote_header ? std::ios::app : std::ios::trunc);
+  if (!wrote_header) {
+    if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << chr << std::endl;
+    if (from_bam) out << "#input " << o.bamfile << std::endl;
+    if (o.P.gcadjust) out << "#GC adjusted\n";
+    out << kHeader << std::endl;
+    wrote_header = true;
+  }
   char row[1024];
   for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
-    rsi_result_format_row(res, i, o.chr.c_str(), row, (int)sizeof(row));
+    rsi_result_format_row(res, i, chr.c_str(), row, (int)sizeof(row));
     out << row << std::endl;
   }
   out.close();
   std::cerr << "output written to " << o.outfile << std::endl; log << "output written to " << o.outfile << std::endl;
   rsi_result_free(res);
+  }   // chromosomes
   rsi_hot_destroy(ctx);
   return 0;
 }

@@ -1471,7 +1471,7 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
       if (p + 4 + bs > have) break;
       const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
       ++st->records;
-      if (rtid == tid) offs.push_back((uint32_t)p);
+      if (rtid == tid) { offs.push_back((uint32_t)p); ++st->on_chrom; }
       else if (rtid > tid || rtid < 0) { finished = true; break; }
       p += 4 + (size_t)bs;
     }
@@ -1498,6 +1498,23 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
   st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs;
   st->t_total_ms = now_ms() - t0;
   return RSI_OK;
+}
+
+int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs) {
+  if (!bam_path) return RSI_ERR_BAD_ARG;
+  std::string err;
+  rsih::BamFile bam;
+  std::vector<std::pair<std::string, int64_t>> refs;
+  uint64_t voff = 0;
+  if (!bam.open(bam_path, err) || !bam.read_header(refs, voff, err)) { set_global_error(err); return RSI_ERR_BAD_ARG; }
+  std::string all;
+  for (size_t r = 0; r < refs.size(); ++r) {
+    if (r) all += '\n';
+    all += refs[r].first;
+    if (lengths && (int)r < max_refs) lengths[r] = refs[r].second;
+  }
+  if (names && names_cap > 0) { strncpy(names, all.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
+  return (int)refs.size();
 }
 
 int rsi_hot_run_bam(rsi_ctx* ctx, const rsi_params* p, const char* bam_path, const char* chrom, int minq, int min_baseq,

@@ -94,3 +94,35 @@ def test_bam_end_to_end_against_reference_binary(hotlib, tmp_path):
         assert a == b, "\n".join(a[:8]) + "\n---\n" + "\n".join(b[:8])
     else:
         assert len(rows(ours)) == 3 + len(res.calls("calls"))
+
+
+@pytest.mark.gpu
+def test_cli_walks_all_chromosomes_of_a_bam(hotlib, tmp_path):
+    """-b without -c: every reference of the header with reads is processed (rsi.cpp:2114-2131), depth dumps equal to
+    the reference's golden depth, one header in the output file."""
+    from conftest import make_case
+    g = np.load(GOLDEN)
+    bam, refs, _ = bu.build_golden_bam(str(tmp_path))
+    fa = str(tmp_path / "ref.fa")
+    off = 0
+    with open(fa, "wb") as f, open(fa + ".fai", "w") as fai:
+        for chrom, n in refs + [("chrEmpty", 50_000)]:
+            _, fasta, _ = make_case(hotlib, dict(n=n, seed=0xFA + n, model=0, n_events=1, gaps=0, max_len=3000, end_n=1000))
+            head = f">{chrom}\n".encode()
+            f.write(head)
+            seq = fasta.tobytes()
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + b"\n")
+            fai.write(f"{chrom}\t{n}\t{off + len(head)}\t60\t61\n")
+            off += len(head) + n + (n + 59) // 60
+    exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+    out = str(tmp_path / "all.txt")
+    r = subprocess.run([exe, "rsi", "-b", bam, "-f", fa, "-o", out, "-np", "-s"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    log = open(out + ".log").read()
+    for chrom, n in refs:
+        assert f"#processing {chrom}" in log
+        dump = np.loadtxt(out + f".{chrom}_rd", dtype=np.int64)
+        assert np.array_equal(dump[:, 1].astype(np.int32), g[f"{chrom}_q0_Q13"]), chrom
+    text = open(out).read()
+    assert text.count("#CHROM") == 1 and text.startswith(f"#input {bam}\n")
