@@ -126,3 +126,38 @@ def test_cli_walks_all_chromosomes_of_a_bam(hotlib, tmp_path):
         assert np.array_equal(dump[:, 1].astype(np.int32), g[f"{chrom}_q0_Q13"]), chrom
     text = open(out).read()
     assert text.count("#CHROM") == 1 and text.startswith(f"#input {bam}\n")
+
+
+@pytest.mark.gpu
+def test_bam_12mb_rows_against_reference_binary(hotlib, tmp_path):
+    """a 12 Mb chromosome, where the reference's pair-sampling window (which starts at 10 Mb,
+    pairrd.cpp:636) finds reads and the reference binary therefore gets through its annotation pass: the command line's
+    rows equal the reference binary's in every column but RP / Q0, and the depth equals its -s dump."""
+    import oracle
+    from conftest import make_case
+    from test_hot_extra import _write_case
+    if not os.path.exists(oracle.REF_BIN):
+        pytest.skip("oracle/_ref/rsicnv_ref not built")
+    n = 12_000_017
+    _, fasta, depth = make_case(hotlib, dict(n=n, seed=0x5EED0001, model=0, mean=14.0, n_events=5, gaps=1, max_len=20000, end_n=10000, gap_len=30000))
+    fa, _ = _write_case(str(tmp_path), fasta, np.zeros(8, dtype=np.int32))
+    recs = bu.paired_reads_following_depth(depth, n, seed=11)
+    bam = str(tmp_path / "c1.bam")
+    bu.write_bam(bam, [("chrS", n)], recs)
+    libref = os.path.join(os.path.dirname(oracle.REF_BIN), "libref.so")
+    ref_rd, ref_out = bu.reference_depth_dump(oracle.REF_BIN, libref, bam, fa, "chrS", str(tmp_path))
+    assert ref_out is not None, "the reference binary should survive on a 12 Mb chromosome"
+    exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+    ours = str(tmp_path / "ours.txt")
+    subprocess.run([exe, "rsi", "-b", bam, "-f", fa, "-c", "chrS", "-o", ours, "-np", "-s"], check=True, capture_output=True, timeout=600)
+    dump = np.loadtxt(ours + ".chrS_rd", dtype=np.int64)
+    assert np.array_equal(dump[:, 1].astype(np.int32), ref_rd)
+    def rows(path):
+        out = []
+        for ln in open(path).read().splitlines():
+            cols = ln.split("\t")
+            out.append("\t".join(c for i, c in enumerate(cols) if not (len(cols) > 8 and i == 7)))
+        return out
+    a, b = rows(ours), rows(ref_out)
+    assert a == b, "\n".join(a[:8]) + "\n---\n" + "\n".join(b[:8])
+    assert len(a) >= 3 + 2
