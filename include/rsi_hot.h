@@ -130,6 +130,14 @@ typedef struct rsi_bam_stats {
 } rsi_bam_stats;
 /* Depth of `chrom` into the context's device depth buffer (int32[stats->n]); rsi_hot_fetch_i32("depth_in") reads it back. */
 int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats);
+/* RP / Q0 annotation of the final calls (cnv_stat, pairrd.cpp:622-748; host only): the insert-size statistics are
+ * sampled from the window the reference uses (1 Mb of reads from position 10 Mb of the chromosome on, pairrd.cpp:636),
+ * then, per call, the read pairs within max(1000, length) <= 5000 bases are classified.  Needs BAM.bai.  The result's
+ * rows (rsi_result_format_row) print the values afterwards; rsi_result_pairs reads them (-1 / -1.0 before annotation,
+ * rsi.h:49-50).  On chromosomes shorter than 10 Mb the reference crashes in this step; here the statistics keep their
+ * defaults (-1) there. */
+int rsi_result_annotate_bam(rsi_result* r, const char* bam_path, const char* chrom);
+int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0);
 /* Reference sequences of the BAM header: names as one '\n'-separated string into names[names_cap], lengths into
  * lengths[max_refs]; returns their number (also when the buffers are too small or NULL), < 0 on error. */
 int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs);

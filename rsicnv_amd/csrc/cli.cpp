@@ -1,8 +1,8 @@
 // cli.cpp -- `rsicnv rsi ...`: the reference's command line (rsi.cpp:1949-2068, 2069-2217) in
 // front of librsi_hot.so.  Same flags and defaults, same output file (header lines, columns,
 // number formatting).  Inputs: a depth file (-d RDFILE -c RNAME, parsed on the device) or a BAM
-// file (-b BAMFILE -c RNAME, piled up on the device); the RP / Q0 annotation of the -b mode, plot,
-// stat and pin are outside the accelerated path and say so.
+// file (-b BAMFILE [-c RNAME], piled up on the device, calls annotated with RP / Q0 from its read
+// pairs); plot, stat and pin are outside the accelerated path and say so.
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -237,7 +237,9 @@ int main(int argc, char** argv) {
     info << "depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
          << (ts.fallback ? ", host parser: positions not increasing" : "") << ")";
   info << ", whole device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
-  if (from_bam) info << "note: RP / Q0 annotation of the calls (cnv_stat) is not part of this build: those columns stay empty\n";
+  if (from_bam) {   // if ( fp_in ) cnv_stat(fp_in, bamidx, cnvlist), rsi.cpp:2210
+    if (rsi_result_annotate_bam(res, o.bamfile.c_str(), chr.c_str()) != RSI_OK) info << "RP / Q0 annotation failed: " << rsi_hot_last_error(nullptr) << "\n";
+  }
   std::cerr << info.str(); log << info.str();
 
   // write_cnv_to_file, rsi.cpp:1592-1616: the first chromosome opens the file and writes the header, the others append

@@ -116,6 +116,8 @@ double now_ms() {
 struct rsi_result {
   std::vector<rsi_call> lists[4];
   std::vector<int32_t> noncode;   // pairs
+  std::vector<int32_t> rp;        // per final call, after rsi_result_annotate_bam
+  std::vector<double> q0;
   rsi_chrom_stats stats;
   rsi_params params;
 };
@@ -1631,8 +1633,37 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
   static const char* kType[3] = {"DEL", "DUP", "UNKNOWN"};
   const int k = snprintf(buf, (size_t)cap, "%s\t%d\t%d\t%s\t%d\t%d\t%g(%g);%g(%g);%g(%g)\tRP=%d;Q0=%g\trsi", chrom, c.start, c.end,
                          kType[c.type < 0 || c.type > 2 ? 2 : c.type], c.qscore, c.end - c.start + 1, c.cnvmed,
-                         c.cnviqr / 1.349, c.refmed, c.refiqr / 1.349, r->stats.RDmedian, r->stats.RDsd, -1, -1.0);
+                         c.cnviqr / 1.349, c.refmed, c.refiqr / 1.349, r->stats.RDmedian, r->stats.RDsd,
+                         (size_t)i < r->rp.size() ? r->rp[(size_t)i] : -1, (size_t)i < r->q0.size() ? r->q0[(size_t)i] : -1.0);
   return k;
+}
+
+int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0) {
+  if (!r || i < 0 || i >= (int)r->lists[0].size()) return RSI_ERR_BAD_ARG;
+  if (rp) *rp = (size_t)i < r->rp.size() ? r->rp[(size_t)i] : -1;
+  if (q0) *q0 = (size_t)i < r->q0.size() ? r->q0[(size_t)i] : -1.0;
+  return RSI_OK;
+}
+
+int rsi_result_annotate_bam(rsi_result* r, const char* bam_path, const char* chrom) {
+  if (!r || !bam_path || !chrom) return RSI_ERR_BAD_ARG;
+  std::string err;
+  rsih::BamFile bam;
+  std::vector<std::pair<std::string, int64_t>> refs;
+  uint64_t voff = 0;
+  if (!bam.open(bam_path, err) || !bam.read_header(refs, voff, err)) { set_global_error(err); return RSI_ERR_BAD_ARG; }
+  int tid = -1;
+  for (size_t k = 0; k < refs.size(); ++k) if (refs[k].first == chrom) tid = (int)k;
+  if (tid < 0) { set_global_error(std::string("chromosome not in the BAM header: ") + chrom); return RSI_ERR_BAD_ARG; }
+  const std::string bai = std::string(bam_path) + ".bai";
+  rsih::PairSample ps;
+  if (!rsih::bam_pair_sample(bam, bai, tid, refs[(size_t)tid].second, 10000000, 349250621, ps, err)) { set_global_error(err); return RSI_ERR_BAD_ARG; }
+  std::vector<rsih::CallSpan> spans;
+  for (const rsi_call& c : r->lists[0]) spans.push_back({c.start, c.end, c.type, -1, -1.0});
+  if (!rsih::bam_annotate_calls(bam, bai, tid, ps, spans, err)) { set_global_error(err); return RSI_ERR_BAD_ARG; }
+  r->rp.clear(); r->q0.clear();
+  for (const rsih::CallSpan& c : spans) { r->rp.push_back(c.rp); r->q0.push_back(c.q0); }
+  return RSI_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -166,7 +166,7 @@ def build_golden_bam(workdir):
     return path, spec["refs"], recs
 
 
-def paired_reads_following_depth(depth, n, read_len=100, isize_mean=300, isize_sd=25, seed=3, tid=0):
+def paired_reads_following_depth(depth, n, read_len=100, isize_mean=300, isize_sd=25, seed=3, tid=0, events=(), clipped=0.0, q0=0.0):
     """Properly paired FR reads (both mates present, coordinate sorted) whose local coverage follows `depth`:
     what the reference's read-pair annotation pass expects to find in a BAM."""
     rng = np.random.default_rng(seed)
@@ -180,11 +180,28 @@ def paired_reads_following_depth(depth, n, read_len=100, isize_mean=300, isize_s
             p2 = p + isz - L
             if p < 1 or p2 + L >= n:
                 continue
-            mq = int(rng.integers(20, 61))
+            mq = 0 if rng.random() < q0 else int(rng.integers(20, 61))
             q1 = rng.integers(14, 41, L).astype(np.uint8).tobytes()
             q2 = rng.integers(14, 41, L).astype(np.uint8).tobytes()
             nm = f"f{fid}".encode(); fid += 1
-            items.append((p, encode_read(tid, p, mq, 0x1 | 0x2 | 0x20 | 0x40, [("M", L)], L, q1, name=nm, mtid=tid, mpos=p2, tlen=isz)))
-            items.append((p2, encode_read(tid, p2, mq, 0x1 | 0x2 | 0x10 | 0x80, [("M", L)], L, q2, name=nm, mtid=tid, mpos=p, tlen=-isz)))
+            # a share of the reads carries a soft clip: the reference's annotation pass only looks at reads with
+            # more than one CIGAR operation (pairrd.cpp:669)
+            c1 = [("S", 3), ("M", L - 3)] if rng.random() < clipped else [("M", L)]
+            c2 = [("M", L - 3), ("S", 3)] if rng.random() < clipped else [("M", L)]
+            items.append((p, encode_read(tid, p, mq, 0x1 | 0x2 | 0x20 | 0x40, c1, L, q1, name=nm, mtid=tid, mpos=p2, tlen=isz)))
+            items.append((p2, encode_read(tid, p2, mq, 0x1 | 0x2 | 0x10 | 0x80, c2, L, q2, name=nm, mtid=tid, mpos=p, tlen=-isz)))
+    # discordant pairs around the implanted events: spanning pairs for losses, everted pairs for gains
+    for (e0, e1, level) in events:
+        for k in range(14):
+            nm = f"d{fid}".encode(); fid += 1
+            qa = rng.integers(14, 41, L).astype(np.uint8).tobytes()
+            if level <= 2:     # deletion: forward read ends before the event, its mate starts after it
+                pa = int(e0 - L - rng.integers(20, 200)); pb = int(e1 + rng.integers(20, 200))
+            else:              # duplication: forward read near the end of the event, its mate near the start (everted)
+                pa = int(e1 - L - rng.integers(20, 200)); pb = int(e0 + rng.integers(20, 200))
+            if pa < 1 or pb < 1 or max(pa, pb) + L >= n:
+                continue
+            items.append((pa, encode_read(tid, pa, 40, 0x1 | 0x20 | 0x40, [("M", L - 5), ("S", 5)], L, qa, name=nm, mtid=tid, mpos=pb, tlen=pb + L - pa)))
+            items.append((pb, encode_read(tid, pb, 40, 0x1 | 0x10 | 0x80, [("S", 5), ("M", L - 5)], L, qa, name=nm, mtid=tid, mpos=pa, tlen=-(pb + L - pa))))
     items.sort(key=lambda x: x[0])
     return [r for _, r in items]
