@@ -1415,88 +1415,116 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
   struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } evguard{done};
   bool used[2] = {false, false};
   std::vector<uint32_t> rec_off[2];
+  rec_off[0].reserve(kMaxRec / 8); rec_off[1].reserve(kMaxRec / 8);
   const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 
-  uint64_t coff = voff >> 16;            // next block to inflate
-  size_t skip = (size_t)(voff & 0xffff); // bytes of the first block that precede the first record
-  size_t carry = 0;                      // bytes of an unfinished record parked at the front of the buffer being filled
-  bool finished = false;
-  int cur = 0;
-  while (!finished) {
-    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[cur]);
-    // ---- the next run of blocks that fits ----
+  // Pipeline over chunks of inflated bytes: while the host walks the records of chunk k and hands them to the device,
+  // the inflate threads already fill the other buffer with chunk k+1.  The inflated data of a chunk starts at kReserve,
+  // so that the unfinished record at the end of chunk k can be parked right in front of chunk k+1 without waiting.
+  constexpr size_t kReserve = size_t(8) << 20;
+  struct Chunk {
     std::vector<rsih::BgzfBlock> blocks;
-    std::vector<size_t> at;              // where each block lands in buf
-    size_t have = carry;
-    bool eof = false;
+    std::vector<size_t> at;
+    size_t end = kReserve;     // end of the inflated data in the buffer
+    bool eof = false, failed = false;
+    std::string err;
+    double t_inflate = 0;
+    std::thread worker;
+  } chunk[2];
+  uint64_t coff = voff >> 16;            // next block to inflate
+  auto prepare = [&](int b) -> bool {    // choose the blocks of the next chunk and start inflating them into buffer b
+    Chunk& c = chunk[b];
+    c.blocks.clear(); c.at.clear(); c.end = kReserve; c.eof = false; c.failed = false; c.err.clear();
     for (;;) {
-      rsih::BgzfBlock b;
-      err.clear();
-      if (!bam.block_at(coff, b, err)) { if (!err.empty()) return fail(ctx, RSI_ERR_BAD_ARG, err); eof = true; break; }
-      if (have + b.isize > kTextChunk) break;
-      blocks.push_back(b); at.push_back(have);
-      have += b.isize; coff += b.csize;
-      st->bytes_compressed += b.csize;
+      rsih::BgzfBlock blk;
+      std::string e2;
+      if (!bam.block_at(coff, blk, e2)) { if (!e2.empty()) { c.failed = true; c.err = e2; return false; } c.eof = true; break; }
+      if (c.end + blk.isize > kTextChunk) break;
+      c.blocks.push_back(blk); c.at.push_back(c.end);
+      c.end += blk.isize; coff += blk.csize;
+      st->bytes_compressed += blk.csize;
     }
-    if (blocks.empty() && !eof) return fail(ctx, RSI_ERR_UNSUPPORTED, "a BAM record is longer than 64 MB");
-    {   // inflate in parallel
+    if (c.blocks.empty() && !c.eof) { c.failed = true; c.err = "a BGZF block does not fit the staging buffer"; return false; }
+    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[b]);
+    c.worker = std::thread([&c, buf, &bam, nthreads]() {
       const double ti = now_ms();
       std::atomic<size_t> next(0);
-      std::atomic<bool> bad(false);
-      std::string terr;
       std::mutex emu;
       auto work = [&]() {
         for (;;) {
           const size_t k = next.fetch_add(1);
-          if (k >= blocks.size()) break;
+          if (k >= c.blocks.size()) break;
           std::string e2;
-          if (!bam.inflate(blocks[k], buf + at[k], e2)) { bad = true; std::lock_guard<std::mutex> lk(emu); terr = e2; }
+          if (!bam.inflate(c.blocks[k], buf + c.at[k], e2)) { std::lock_guard<std::mutex> lk(emu); c.failed = true; c.err = e2; }
         }
       };
       std::vector<std::thread> th;
-      const unsigned nt = (unsigned)std::min<size_t>(nthreads, blocks.size());
+      const unsigned nt = (unsigned)std::min<size_t>(nthreads, c.blocks.size());
       for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
       work();
       for (auto& t : th) t.join();
-      if (bad) return fail(ctx, RSI_ERR_BAD_ARG, terr);
-      st->t_inflate_ms += now_ms() - ti;
-      st->bytes_inflated += (int64_t)(have - carry);
-    }
+      c.t_inflate = now_ms() - ti;
+    });
+    return true;
+  };
+  struct JoinGuard { Chunk* c; ~JoinGuard() { for (int b = 0; b < 2; ++b) if (c[b].worker.joinable()) c[b].worker.join(); } } joinguard{chunk};
+
+  size_t skip = (size_t)(voff & 0xffff); // bytes of the first block that precede the first record
+  size_t carry = 0;                      // bytes of an unfinished record parked in front of the current chunk's data
+  bool finished = false;
+  int cur = 0;
+  if (!prepare(0)) return fail(ctx, RSI_ERR_BAD_ARG, chunk[0].err);
+  while (!finished) {
+    Chunk& c = chunk[cur];
+    c.worker.join();
+    if (c.failed) return fail(ctx, RSI_ERR_BAD_ARG, c.err);
+    st->t_inflate_ms += c.t_inflate;
+    st->bytes_inflated += (int64_t)(c.end - kReserve);
+    const int other = cur ^ 1;
+    // the other buffer is free once the device has taken its previous chunk: start the next inflate right away
+    { const double tq = now_ms(); if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); used[other] = false; } st->t_wait_ms += now_ms() - tq; }
+    bool more = false;
+    if (!c.eof) { if (!prepare(other)) return fail(ctx, RSI_ERR_BAD_ARG, chunk[other].err); more = true; }
     // ---- record boundaries; the BAM is coordinate sorted, so reading ends with the first read beyond `tid` ----
+    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[cur]);
+    const double tw = now_ms();
     std::vector<uint32_t>& offs = rec_off[cur];
     offs.clear();
-    size_t p = skip;                     // `skip` only applies to the very first chunk (carry == 0 there)
+    const size_t start = kReserve - carry + skip;   // `skip` only applies to the very first chunk (no carry there)
     skip = 0;
+    size_t p = start;
+    const size_t have = c.end;
     while (p + 4 <= have) {
       const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
       if (bs < 32) return fail(ctx, RSI_ERR_BAD_ARG, "malformed BAM record");
       if (p + 4 + bs > have) break;
       const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
       ++st->records;
-      if (rtid == tid) { offs.push_back((uint32_t)p); ++st->on_chrom; }
+      if (rtid == tid) { offs.push_back((uint32_t)(p - start)); ++st->on_chrom; }
       else if (rtid > tid || rtid < 0) { finished = true; break; }
       p += 4 + (size_t)bs;
     }
-    if (eof) finished = true;
-    const size_t len = p;                // bytes of whole records examined
+    if (c.eof) finished = true;
+    st->t_walk_ms += now_ms() - tw;
+    const size_t len = p;                // end of the whole records examined
     if (!offs.empty()) {
       uint32_t* d_off = reinterpret_cast<uint32_t*>(wsb + (size_t)cur * kMaxRec * 4);
-      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf, len, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf + start, len - start, hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(hipMemcpyAsync(d_off, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
       { Timer t(ctx, "bam_depth"); launch_bam_depth(ctx->text_dev[cur].p, d_off, (int)offs.size(), tid, minq, min_baseq, (long long)n, d_diff, d_stats, ctx->stream); }
       HIPCHK(hipEventRecord(done[cur], ctx->stream));
       used[cur] = true;
     }
-    const int other = cur ^ 1;
-    if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); used[other] = false; }
     carry = finished ? 0 : have - len;
-    if (carry) memcpy(ctx->text_pin[other], buf + len, carry);
+    if (carry > kReserve) return fail(ctx, RSI_ERR_UNSUPPORTED, "a BAM record is longer than 8 MB");
+    if (carry && more) memcpy(ctx->text_pin[other] + (kReserve - carry), buf + len, carry);   // in front of the data being inflated there
+    if (!more) finished = true;
     cur = other;
   }
   { Timer t(ctx, "depth_scan"); launch_inclusive_scan_i32(d_diff, (long long)n, reinterpret_cast<int32_t*>(wsb + scan_off), ctx->stream); }
   BamDepthStats hs;
   HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { const double tq = now_ms(); HIPCHK(hipStreamSynchronize(ctx->stream)); st->t_wait_ms += now_ms() - tq; }
   st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs;
   st->t_total_ms = now_ms() - t0;
   return RSI_OK;

@@ -21,7 +21,7 @@ h = api.RsiHot(0)
 for rep in range(3):
     st = h.load_depth_bam(bam, "chrS")
     print(f"loader: {st['t_total_ms']:.0f} ms total ({st['bytes_compressed']/1e6:.0f} MB compressed -> {st['bytes_inflated']/1e6:.0f} MB, "
-          f"{st['records']} reads, {st['runs']} runs; inflate wall {st['t_inflate_ms']:.0f} ms) = {n/st['t_total_ms']/1e3:.1f} Mbases/s of chromosome, "
+          f"{st['records']} reads, {st['runs']} runs; inflate {st['t_inflate_ms']:.0f} ms, walk {st['t_walk_ms']:.0f} ms, device wait {st['t_wait_ms']:.0f} ms) = {n/st['t_total_ms']/1e3:.1f} Mbases/s of chromosome, "
           f"{st['records']/st['t_total_ms']/1e3:.2f} M reads/s, {st['bytes_compressed']/st['t_total_ms']/1e6:.2f} GB/s compressed", flush=True)
 rd = h.fetch("depth_in")
 print("mean depth", rd.mean())
