@@ -277,3 +277,47 @@ def test_depth_text_big_file_matches_arrays(hot, hotlib, tmp_path):
     assert r_txt.text_stats["fallback"] == 0 and r_txt.text_stats["lines"] == n
     ok, why = calls_equal(r_txt.calls("calls_raw"), r_arr.calls("calls_raw"), rtol=0)
     assert ok, why
+
+
+@pytest.mark.parametrize("flag_kw", [dict(epsilon=2.5, chklen=1.5, merge=0), dict(trans=1, threshold=0.8, maxchkbp=2000, m=75),
+                                     dict(epsilon=1.0, cap=2.5, m=201), dict(trans=2, chklen=4.0, minmlen=5.0, buffer=0.2)],
+                         ids=["eps_reflen_nomerge", "med_threshold_maxchkbp_m75", "eps1_cap25_m201", "all_reflen4_minmlen5_buffer02"])
+def test_less_common_flags_parity(hot, hotlib, oracle_cls, flag_kw):
+    """-e, -threshold, -reflen, -maxchkbp, -nomerge and unusual bin sizes: status arrays and calls against the oracle
+    (which test_oracle_vs_ref pins against the compiled reference for the first two combinations)."""
+    import oracle
+    from rsicnv_amd import api
+    plan_kw = dict(n=2_000_003, seed=0xF1A6 + len(flag_kw), model=1, n_events=9, gaps=2, max_len=60000, end_n=10000, gap_len=30000)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(**flag_kw), depth, fasta)
+    res = hot.run(api.make_params(**flag_kw), depth, fasta)
+    trans = flag_kw.get("trans", 0)
+    pre = "med" if trans == 1 else "nb"
+    assert res.stats["Lmax"] == int(O.f64(f"scan_{pre}")[7])
+    for w in ("status1", "status1f", "status2"):
+        assert np.array_equal(hot.fetch(w), O.i32(f"{pre}_{w}")), w
+    segs_o = (O.calls("segs_med") if trans != 0 else []) + (O.calls("segs_nb") if trans != 1 else [])
+    for which, exp in (("segs", segs_o), ("blocks", O.calls("blocks")), ("calls_raw", O.calls("calls_raw")), ("calls", O.calls("calls"))):
+        ok, why = calls_equal(res.calls(which), exp)
+        assert ok, f"{which}: {why}"
+
+
+def test_bin_size_extremes(hot, hotlib, oracle_cls):
+    """m = 1001 (bin medians from LDS, the kernel's general path) against the oracle; m = 3 asks for a scan length of
+    3333 windows, beyond the kernel's 2048: a clean RSI_ERR_UNSUPPORTED, not a wrong answer."""
+    import oracle
+    from rsicnv_amd import api
+    plan_kw = dict(n=3_000_001, seed=0xB161, model=0, n_events=6, gaps=1, max_len=120000, end_n=10000, gap_len=30000)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(m=1001), depth, fasta)
+    res = hot.run(api.make_params(m=1001), depth, fasta)
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    assert np.array_equal(hot.fetch("status2"), O.i32("nb_status2"))
+    for which in ("blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
+    with pytest.raises(api.RsiError) as e:
+        hot.run(api.make_params(m=3), depth[:200_000], fasta[:200_000])
+    assert e.value.code == -5 and "2048" in str(e.value)

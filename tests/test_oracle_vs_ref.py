@@ -41,8 +41,9 @@ def test_exact_median_and_pnorm_match(ref, oracle_cls):
         assert O.pnorm(float(v)) == ref.pnorm(float(v))
 
 
-@pytest.mark.parametrize("flags", [dict(), dict(m=51, trans=1), dict(gcadjust=0, cap=-1.0), dict(trans=2)],
-                         ids=["nb", "med51", "nogc_nocap", "all"])
+@pytest.mark.parametrize("flags", [dict(), dict(m=51, trans=1), dict(gcadjust=0, cap=-1.0), dict(trans=2),
+                                   dict(epsilon=2.5, chklen=1.5, merge=0), dict(trans=1, threshold=0.8, maxchkbp=2000, m=75)],
+                         ids=["nb", "med51", "nogc_nocap", "all", "eps_reflen_nomerge", "med_threshold_maxchkbp_m75"])
 def test_whole_path_2mb(ref, oracle_cls, hotlib, flags):
     plan_kw = dict(n=2_000_003, seed=0xD00D + len(flags), model=1, n_events=9, gaps=2, max_len=60000, end_n=10000, gap_len=30000)
     _, fasta, depth = make_case(hotlib, plan_kw)
