@@ -81,6 +81,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        # One slice of the allowed CPUs per rank (contiguous ids are normally one socket): a rank's dozen worker threads
+        # and the runtime's helper threads then stay next to each other instead of wandering over both sockets.  Only
+        # when the slice is comfortably larger than the pool; RSI_BENCH_PIN=0 turns it off.
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            per = len(allowed) // max(local_world, 1)
+            if os.environ.get("RSI_BENCH_PIN", "1") != "0" and per >= args.workers + 4:
+                os.sched_setaffinity(0, set(allowed[local_rank * per:(local_rank + 1) * per]))
+        except (AttributeError, OSError):
+            pass
 
     lib = api.load_library()
     pool = api.RsiPool(local_rank, args.workers)
