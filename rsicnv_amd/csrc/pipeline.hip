@@ -1425,6 +1425,12 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
   struct Chunk {
     std::vector<rsih::BgzfBlock> blocks;
     std::vector<size_t> at;
+    // speculative record walk of each block, done by the thread that inflated it, as if the block began on a record
+    // boundary (htslib and samtools flush before a record that would not fit, so normally it does): offsets of the
+    // records of `tid` that lie wholly inside the block, how many records were seen, where the walk stopped, and
+    // whether it met a read beyond `tid` (the end of the chromosome in a sorted file)
+    struct BlockWalk { std::vector<uint32_t> offs; uint32_t seen = 0; size_t stop = 0; bool beyond = false, bad = false; };
+    std::vector<BlockWalk> walks;
     size_t end = kReserve;     // end of the inflated data in the buffer
     bool eof = false, failed = false;
     std::string err;
@@ -1446,7 +1452,8 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
     }
     if (c.blocks.empty() && !c.eof) { c.failed = true; c.err = "a BGZF block does not fit the staging buffer"; return false; }
     uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[b]);
-    c.worker = std::thread([&c, buf, &bam, nthreads]() {
+    c.walks.assign(c.blocks.size(), Chunk::BlockWalk());
+    c.worker = std::thread([&c, buf, &bam, nthreads, tid]() {
       const double ti = now_ms();
       std::atomic<size_t> next(0);
       std::mutex emu;
@@ -1455,7 +1462,21 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
           const size_t k = next.fetch_add(1);
           if (k >= c.blocks.size()) break;
           std::string e2;
-          if (!bam.inflate(c.blocks[k], buf + c.at[k], e2)) { std::lock_guard<std::mutex> lk(emu); c.failed = true; c.err = e2; }
+          if (!bam.inflate(c.blocks[k], buf + c.at[k], e2)) { std::lock_guard<std::mutex> lk(emu); c.failed = true; c.err = e2; continue; }
+          Chunk::BlockWalk& w = c.walks[k];
+          size_t p = c.at[k];
+          const size_t lim = c.at[k] + c.blocks[k].isize;
+          while (p + 8 <= lim) {
+            const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
+            if (bs < 32) { w.bad = true; break; }          // not a record start after all (or a broken file): the checker decides
+            if (p + 4 + (size_t)bs > lim) break;
+            const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
+            ++w.seen;
+            if (rtid == tid) w.offs.push_back((uint32_t)(p - c.at[k]));
+            else if (rtid > tid || rtid < 0) { w.beyond = true; break; }
+            p += 4 + (size_t)bs;
+          }
+          w.stop = p;
         }
       };
       std::vector<std::thread> th;
@@ -1494,7 +1515,19 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
     skip = 0;
     size_t p = start;
     const size_t have = c.end;
-    while (p + 4 <= have) {
+    size_t kb = 0;                       // first block that starts at or after p
+    while (p + 4 <= have && !finished) {
+      while (kb < c.blocks.size() && c.at[kb] < p) ++kb;
+      if (kb < c.blocks.size() && c.at[kb] == p && !c.walks[kb].bad) {
+        // the block does begin on a record boundary: its thread has walked it already
+        const Chunk::BlockWalk& w = c.walks[kb];
+        const uint32_t base = (uint32_t)(p - start);
+        for (uint32_t o : w.offs) offs.push_back(base + o);
+        st->records += w.seen; st->on_chrom += (int64_t)w.offs.size();
+        if (w.beyond) { finished = true; p = w.stop; break; }
+        if (w.stop == p) {               // not even one whole record in this block: walk it the plain way below
+        } else { p = w.stop; ++kb; continue; }
+      }
       const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
       if (bs < 32) return fail(ctx, RSI_ERR_BAD_ARG, "malformed BAM record");
       if (p + 4 + bs > have) break;

@@ -41,8 +41,10 @@ def encode_read(tid, pos0, mapq, flag, cigar, seq_len, qual, name=b"r", mtid=-1,
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, refs, records, block=60000):
-    """refs: list of (name, length); records: encoded reads in coordinate order."""
+def write_bam(path, refs, records, block=60000, straddle=False):
+    """refs: list of (name, length); records: encoded reads in coordinate order.  straddle: cut the BGZF blocks at
+    fixed sizes wherever that falls (records, even their length fields, then span blocks -- legal, and what a reader
+    has to survive), instead of flushing before a record that would not fit (what samtools / htslib write)."""
     text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
     for n, l in refs:
@@ -50,6 +52,11 @@ def write_bam(path, refs, records, block=60000):
     with open(path, "wb") as f:
         f.write(_bgzf_block(hdr))
         buf = b""
+        if straddle:
+            data = b"".join(records)
+            for a in range(0, len(data), block):
+                f.write(_bgzf_block(data[a:a + block]))
+            records = []
         for r in records:
             if len(buf) + len(r) > block and buf:       # records may also straddle blocks: every 7th flush splits one
                 f.write(_bgzf_block(buf)); buf = b""

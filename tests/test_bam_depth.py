@@ -157,3 +157,22 @@ def test_bam_12mb_rows_against_reference_binary(hotlib, tmp_path):
     assert a == b, a[:1500] + "\n---\n" + b[:1500]
     rows = [ln.split("\t") for ln in a.splitlines() if not ln.startswith("#")]
     assert len(rows) >= 2 and any(not r[7].startswith("RP=0;") for r in rows), "the test BAM should give some call a supporting pair"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", [777, 4093, 60000])
+def test_records_straddling_bgzf_blocks(hotlib, tmp_path, block):
+    """BGZF blocks cut at arbitrary byte positions (records and their length fields span blocks): the loader's
+    per-block speculative walk has to fall back to the plain walk wherever a block does not begin on a record."""
+    from rsicnv_amd import api
+    g = np.load(GOLDEN)
+    spec = bu.golden_spec()
+    _, refs, recs = bu.build_golden_bam(str(tmp_path))
+    bam = str(tmp_path / f"straddle{block}.bam")
+    bu.write_bam(bam, spec["refs"], recs, block=block, straddle=True)
+    h = api.RsiHot(0)
+    for t, (chrom, n) in enumerate(refs):
+        st = h.load_depth_bam(bam, chrom)
+        assert np.array_equal(h.fetch("depth_in"), g[f"{chrom}_q0_Q13"]), (chrom, block)
+        assert st["on_chrom"] == sum(1 for r in recs if int.from_bytes(r[4:8], "little", signed=True) == t)
+    h.close()
