@@ -50,10 +50,11 @@ struct DevBuf {   // grow-only device allocation
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
     const auto t0 = std::chrono::steady_clock::now();
+    const bool regrow = p != nullptr;   // a buffer whose size depends on the data turned out too small: be generous this time
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     const size_t scaled = (size_t)((double)bytes * tl_grow);
-    const size_t want = scaled + scaled / 8 + 256;
+    const size_t want = (regrow ? 2 * scaled : scaled + scaled / 8) + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     tl_grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
