@@ -321,3 +321,22 @@ def test_bin_size_extremes(hot, hotlib, oracle_cls):
     with pytest.raises(api.RsiError) as e:
         hot.run(api.make_params(m=3), depth[:200_000], fasta[:200_000])
     assert e.value.code == -5 and "2048" in str(e.value)
+
+
+def test_many_n_runs(hot, hotlib, oracle_cls):
+    """About a thousand N runs (2000 run boundaries: more than the 1024 the first round trip brings back): regions,
+    compaction and calls against the oracle."""
+    import oracle
+    from rsicnv_amd import api
+    plan_kw = dict(n=6_000_003, seed=0x4E4E, model=0, n_events=6, gaps=2000, max_len=30000, end_n=3000, gap_len=120)
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert len(res.noncode) // 2 > 512
+    assert np.array_equal(res.noncode, O.i32("noncode"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert np.array_equal(hot.fetch("status2"), O.i32("nb_status2"))
+    for which in ("calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
