@@ -340,3 +340,27 @@ def test_many_n_runs(hot, hotlib, oracle_cls):
     for which in ("calls_raw", "calls"):
         ok, why = calls_equal(res.calls(which), O.calls(which))
         assert ok, f"{which}: {why}"
+
+
+@pytest.mark.gpu
+def test_deep_coverage_sends_tests_to_the_host_walk(hot, hotlib, oracle_cls):
+    """At 12000x the values of a candidate span more integer buckets than the device
+    histogram holds: the kernel declines those tests (CandOut.flags) and the host walk serves them
+    from pages of the device depth.  The mix of device and host tests must still match the oracle."""
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=1_500_003, seed=0xDEE9, model=0, n_events=7, gaps=1,
+                                             max_len=40000, end_n=4000, gap_len=9000))
+    # the generator's sampling tables stop at a few hundred: scale a 30x track up and fill the comb
+    fill = np.random.default_rng(0xDEE9).integers(0, 400, size=depth.size, dtype=np.int32)
+    depth = np.where(depth > 0, depth * 400 + fill, 0).astype(np.int32)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    phases = dict(hot.phase_times())
+    assert phases["calls.host_fallbacks"] > 0, phases
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
+    ok, why = calls_equal(res.calls("calls_raw"), O.calls("calls_raw"))
+    assert ok, why
+    assert len(res.calls("calls")) > 0
