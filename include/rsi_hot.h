@@ -177,7 +177,8 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
 int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap);
 /* Host wall-clock per pipeline phase of the last run (ms, includes waits on the device). */
 int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int cap);
-/* Enable (1) / disable (0) per-kernel event timing (adds an event pair per launch). */
+/* Per-kernel event timing: 0 off, 1 an event pair around every launch, 2 around the per-base (HBM-bound)
+ * kernels only -- some sixty launches per chromosome make the event records themselves cost 13 % of a pooled step. */
 void rsi_hot_set_timing(rsi_ctx* ctx, int on);
 
 /* ---- Pool: several chromosomes in flight on one GPU ------------------------------------------

@@ -238,7 +238,7 @@ class RsiHot:
             raise RsiError(rc, self.lib.rsi_hot_last_error(self.ctx).decode())
 
     def set_timing(self, on=True):
-        self.lib.rsi_hot_set_timing(self.ctx, 1 if on else 0)
+        self.lib.rsi_hot_set_timing(self.ctx, int(on))
 
     def run(self, params, depth, fasta):
         """depth: int32[n] raw per-base depth, fasta: uint8[n] sequence bytes (host arrays)."""
@@ -339,7 +339,7 @@ class RsiPool:
             pass
 
     def set_timing(self, on=True):
-        self.lib.rsi_pool_set_timing(self.pool, 1 if on else 0)
+        self.lib.rsi_pool_set_timing(self.pool, int(on))
 
     def set_schedule(self, isolate=False, streamers=0):
         """isolate: per-base phases run alone on the chip (clean kernel timings); streamers: per-base phases in flight (0 = keep)."""

@@ -115,11 +115,13 @@ constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable e
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del,
                      const double* thr_dup, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
                      hipStream_t stream);
-// histogram of first_del over L (hist[L], L <= Lmax)
-void launch_level_hist(const uint32_t* first, const uint32_t* exclude, uint32_t exclude_max, int64_t nb, int32_t Lmax,
+// histogram of first_del over L (hist[L], L <= Lmax); bins with exclude[j] <= *exclude_max are left out
+void launch_level_hist(const uint32_t* first, const uint32_t* exclude, const uint32_t* exclude_max, int64_t nb, int32_t Lmax,
                        uint32_t* hist, hipStream_t stream);
-// status[j] = -first_del[j] if first_del[j] <= ldel; else +first_dup[j] if <= ldup; else 0
-void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, uint32_t ldel, uint32_t ldup,
+// *level = the L a sweep stops at (first L with more than a fifth of the bins marked, else Lmax)
+void launch_stop_level(const uint32_t* hist, int32_t Lmax, int64_t nb, uint32_t* level, hipStream_t stream);
+// status[j] = -first_del[j] if first_del[j] <= levels[0]; else +first_dup[j] if <= levels[1]; else 0
+void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels,
                            int64_t nb, int32_t* status, hipStream_t stream);
 
 // ---- K9/K10: marked runs and max-score sub-segment (get_continuous_segments rsi.cpp:291;

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
 
 // histogram over L of first[] (bins whose exclude[] <= exclude_max are skipped: DEL marks win)
 __global__ __launch_bounds__(kThreads) void k_level_hist(const uint32_t* __restrict__ first,
-                                                         const uint32_t* __restrict__ exclude, uint32_t exclude_max,
+                                                         const uint32_t* __restrict__ exclude,
+                                                         const uint32_t* __restrict__ exclude_max_ptr,
                                                          int64_t nb, int32_t Lmax, uint32_t* __restrict__ hist) {
   extern __shared__ unsigned int s_l[];
+  const uint32_t exclude_max = exclude ? *exclude_max_ptr : 0u;   // the DEL sweep's stop level, found by k_stop_level
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_l[e] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
@@ -504,9 +506,28 @@ __global__ __launch_bounds__(kThreads) void k_level_hist(const uint32_t* __restr
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) { const unsigned int c = s_l[e]; if (c) atomicAdd(&hist[e], c); }
 }
 
+// Which L does a sweep stop at?  The first L after whose marks more than a fifth of the bins are
+// marked (rsi.cpp:1225, 1255), Lmax when that never happens.  One workgroup; the walk is sequential.
+__global__ __launch_bounds__(kThreads) void k_stop_level(const uint32_t* __restrict__ hist, int32_t Lmax, int64_t nb,
+                                                         uint32_t* __restrict__ level) {
+  extern __shared__ unsigned int s_l[];
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_l[e] = hist[e];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned long long cum = 0;
+  uint32_t lv = (uint32_t)Lmax;
+  for (int L = 1; L <= Lmax; ++L) {
+    cum += s_l[L];
+    if ((double)(int)cum / (double)(int)nb > 0.2) { lv = (uint32_t)L; break; }
+  }
+  *level = lv;
+}
+
 __global__ __launch_bounds__(kThreads) void k_resolve_status(const uint32_t* __restrict__ first_del,
-                                                             const uint32_t* __restrict__ first_dup, uint32_t ldel,
-                                                             uint32_t ldup, int64_t nb, int32_t* __restrict__ status) {
+                                                             const uint32_t* __restrict__ first_dup,
+                                                             const uint32_t* __restrict__ levels, int64_t nb,
+                                                             int32_t* __restrict__ status) {
+  const uint32_t ldel = levels[0], ldup = levels[1];
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
     const uint32_t fd = first_del[i], fu = first_dup[i];
     int s = 0;
@@ -660,14 +681,17 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rsi_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_rsi_scan, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters);
 }
-void launch_level_hist(const uint32_t* first, const uint32_t* exclude, uint32_t exclude_max, int64_t nb, int32_t Lmax,
+void launch_level_hist(const uint32_t* first, const uint32_t* exclude, const uint32_t* exclude_max, int64_t nb, int32_t Lmax,
                        uint32_t* hist, hipStream_t stream) {
   hipLaunchKernelGGL(k_level_hist, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 4, stream, first, exclude,
                      exclude_max, nb, Lmax, hist);
 }
-void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, uint32_t ldel, uint32_t ldup, int64_t nb,
+void launch_stop_level(const uint32_t* hist, int32_t Lmax, int64_t nb, uint32_t* level, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stop_level, dim3(1), dim3(kThreads), (size_t)(Lmax + 1) * 4, stream, hist, Lmax, nb, level);
+}
+void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb,
                            int32_t* status, hipStream_t stream) {
-  hipLaunchKernelGGL(k_resolve_status, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, first_del, first_dup, ldel, ldup, nb, status);
+  hipLaunchKernelGGL(k_resolve_status, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, first_del, first_dup, levels, nb, status);
 }
 void launch_find_runs(const int32_t* status, int64_t nb, uint64_t* runs, uint32_t* count, uint32_t cap, hipStream_t stream) {
   hipLaunchKernelGGL(k_find_runs, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, status, nb, runs, count, cap);

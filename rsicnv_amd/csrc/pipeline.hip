@@ -128,7 +128,7 @@ struct rsi_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
   std::string err;
-  bool timing = false;
+  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base (HBM-bound) kernels only
   std::vector<KernelTime> ktimes;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
@@ -138,7 +138,7 @@ struct rsi_ctx {
   char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
   size_t text_pin_cap = 0;
   int64_t n_in = 0;                          // length of the depth currently in in_depth
-  DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del, first_dup;
+  DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64;   // candidate tests on the device (kernels_cand.hip)
@@ -245,8 +245,9 @@ constexpr size_t kOffCounters = 4864;                             // uint32[8]: 
 constexpr size_t kOffRawMin = 5120;                               // uint32
 constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
 constexpr size_t kOffTable = 5376;                                // double[202]
-constexpr size_t kOffLevelHist = 8192;                            // uint32[4096]
-constexpr size_t kOffBreaks = 8192 + 16384;                       // int64 cbreak[4096], cum[4097]
+constexpr size_t kOffScanPass = 8192;                             // 2 x ScanPassWork (one per rsistatus pass)
+constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
+constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4096], cum[4097]
 constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
 constexpr int kMaxRegions = 4096;
 constexpr uint32_t kMaxTransitions = 1u << 16;
@@ -255,8 +256,8 @@ constexpr int kMaxL = 2048;
 
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
-  Timer(rsi_ctx* c, const char* nm) : ctx(c), name(nm) {
-    if (!ctx->timing) return;
+  Timer(rsi_ctx* c, const char* nm, bool per_base = false) : ctx(c), name(nm) {
+    if (!ctx->timing || (ctx->timing == 2 && !per_base)) return;
     auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
     a = get(); b = get();
     (void)hipEventRecord(a, ctx->stream);
@@ -288,6 +289,8 @@ struct Phase {   // wall-clock bracket of one pipeline phase (host view)
   }
   ~Phase() { stop(); }
 };
+
+struct ScanPassOut { uint32_t escapes, inexact, ldel, ldup; };   // what one rsistatus pass leaves in `small`
 
 struct ScanOut {
   double tmedian1 = 0, tsigma1 = 0, tlamda1 = 0, tmedian2 = 0, tsigma2 = 0, tlamda2 = 0;
@@ -537,9 +540,11 @@ class DeviceTester : public rsih::NeighbourTester {
   bool failed = false;
 };
 
-// One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status
-int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
-              double tlamda, int Lmax, int32_t* d_status, uint32_t* escapes, uint32_t* inexact) {
+// One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status.  Nothing in it needs the host: the levels at which the
+// two sweeps stop are found on the device (k_stop_level), so the pass is one chain of launches without a round trip;
+// its counters (ScanPassOut slot `pass`) travel with the caller's next transfer.
+int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
+              double tlamda, int Lmax, int32_t* d_status) {
   uint8_t* small = ctx->small.as<uint8_t>();
   std::vector<double> del, dup;
   scan_thresholds(tmedian, tlamda, Lmax, del, dup);
@@ -547,43 +552,25 @@ int scan_pass(rsi_ctx* ctx, const float* d_T, const int32_t* d_medint, int64_t n
   HIPCHK(ctx->thr.ensure(nthr * 16));
   double* d_del = ctx->thr.as<double>();
   double* d_dup = d_del + nthr;
-  HIPCHK(copy_h2d(ctx, d_del, del.data(), nthr * 8));
-  HIPCHK(copy_h2d(ctx, d_dup, dup.data(), nthr * 8));
-  uint32_t* d_counters = reinterpret_cast<uint32_t*>(small + kOffCounters);
-  HIPCHK(hipMemsetAsync(d_counters, 0, 8, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->first_del.p, 0xff, (size_t)nb * 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->first_dup.p, 0xff, (size_t)nb * 4, ctx->stream));
+  del.insert(del.end(), dup.begin(), dup.end());
+  HIPCHK(copy_h2d(ctx, d_del, del.data(), 2 * nthr * 8));
+  uint8_t* work = small + kOffScanPass + (size_t)pass * kScanPassBytes;
+  ScanPassOut* d_out = reinterpret_cast<ScanPassOut*>(work);
+  uint32_t* d_lh_del = reinterpret_cast<uint32_t*>(work + 64);
+  uint32_t* d_lh_dup = reinterpret_cast<uint32_t*>(work + 64 + 8256);
+  uint32_t* d_first_del = ctx->first_del.as<uint32_t>();
+  uint32_t* d_first_dup = d_first_del + ((nb + 3) & ~int64_t(3));
+  HIPCHK(hipMemsetAsync(work, 0, kScanPassBytes, ctx->stream));
+  HIPCHK(hipMemsetAsync(d_first_del, 0xff, (size_t)(d_first_dup - d_first_del + nb) * 4, ctx->stream));
   ScanParams sp;
   sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
   sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
-  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, ctx->first_del.as<uint32_t>(), ctx->first_dup.as<uint32_t>(), d_counters, ctx->stream); }
-  // which L does each sweep stop at? (portion > 0.2 after marking with L, rsi.cpp:1225, 1255)
-  uint32_t* d_lh = reinterpret_cast<uint32_t*>(small + kOffLevelHist);
-  std::vector<uint32_t> lh((size_t)Lmax + 1);
-  auto stop_level = [&](uint32_t& level) {
-    uint64_t cum = 0;
-    level = (uint32_t)Lmax;
-    for (int L = 1; L <= Lmax; ++L) {
-      cum += lh[L];
-      if (double((int)cum) / double((int)nb) > 0.2) { level = (uint32_t)L; break; }
-    }
-  };
-  uint32_t ldel = 0, ldup = 0;
-  HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
-  { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_del.as<uint32_t>(), nullptr, 0, nb, Lmax, d_lh, ctx->stream); }
-  HIPCHK(copy_d2h(ctx, lh.data(), d_lh, (size_t)(Lmax + 1) * 4));
-  HIPCHK(CTX_SYNC());
-  stop_level(ldel);
-  HIPCHK(hipMemsetAsync(d_lh, 0, (size_t)(Lmax + 1) * 4, ctx->stream));
-  { Timer t(ctx, "level_hist"); launch_level_hist(ctx->first_dup.as<uint32_t>(), ctx->first_del.as<uint32_t>(), ldel, nb, Lmax, d_lh, ctx->stream); }
-  HIPCHK(copy_d2h(ctx, lh.data(), d_lh, (size_t)(Lmax + 1) * 4));
-  uint32_t cnts[2];
-  HIPCHK(copy_d2h(ctx, cnts, d_counters, 8));
-  HIPCHK(CTX_SYNC());
-  stop_level(ldup);
-  *escapes += cnts[0];
-  *inexact = cnts[1];
-  { Timer t(ctx, "resolve_status"); launch_resolve_status(ctx->first_del.as<uint32_t>(), ctx->first_dup.as<uint32_t>(), ldel, ldup, nb, d_status, ctx->stream); }
+  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, d_first_del, d_first_dup, &d_out->escapes, ctx->stream); }
+  { Timer t(ctx, "level_hist"); launch_level_hist(d_first_del, nullptr, nullptr, nb, Lmax, d_lh_del, ctx->stream); }
+  launch_stop_level(d_lh_del, Lmax, nb, &d_out->ldel, ctx->stream);
+  { Timer t(ctx, "level_hist"); launch_level_hist(d_first_dup, d_first_del, &d_out->ldel, nb, Lmax, d_lh_dup, ctx->stream); }
+  launch_stop_level(d_lh_dup, Lmax, nb, &d_out->ldup, ctx->stream);
+  { Timer t(ctx, "resolve_status"); launch_resolve_status(d_first_del, d_first_dup, &d_out->ldel, nb, d_status, ctx->stream); }
   return RSI_OK;
 }
 
@@ -630,7 +617,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int32_t* d_st1 = ctx->status1.as<int32_t>();
   int32_t* d_st1f = ctx->status1f.as<int32_t>();
   int32_t* d_st2 = ctx->status2.as<int32_t>();
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1)) != RSI_OK) return rc; }
 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
@@ -642,7 +629,10 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  ScanPassOut pass_out[2];
+  HIPCHK(copy_d2h(ctx, &pass_out[0], ctx->small.as<uint8_t>() + kOffScanPass, sizeof(ScanPassOut)));
   { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
+  out.escapes += pass_out[0].escapes; out.inexact = pass_out[0].inexact;
   {
     Phase phs(ctx, "fs.sums");
     // status values lie in [-Lmax, Lmax]; the unmarked level (almost every bin) is summed in a register.
@@ -704,7 +694,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
   ph_q2.stop();
   gs_q2.release();
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, &out.escapes, &out.inexact)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 1, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2)) != RSI_OK) return rc; }
   Phase ph_seg(ctx, "scan.segments");
   GateShared gs_seg(ctx);
 
@@ -712,7 +702,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
   HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));   // into out.status2 after the next sync
   std::vector<Region> runs;
+  HIPCHK(copy_d2h(ctx, &pass_out[1], ctx->small.as<uint8_t>() + kOffScanPass + kScanPassBytes, sizeof(ScanPassOut)));
   if ((rc = marked_runs_device(ctx, d_st2, nb, runs)) != RSI_OK) return rc;   // synchronises
+  out.escapes += pass_out[1].escapes; out.inexact = pass_out[1].inexact;
   out.status2.assign(ctx->h_status2.as<int>(), ctx->h_status2.as<int>() + nb);
   out.segs.clear();
   if (runs.empty()) return RSI_OK;
@@ -824,7 +816,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   // median walk.  The GC table is built on the device, so nothing in this chain needs the host; the N-run list,
   // the GC accumulators (for the checks and the log) and the median come back in ONE round trip. ----
   uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
-  { Timer t(ctx, "fasta_classify"); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
+  { Timer t(ctx, "fasta_classify", true); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
   { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, st); }
   constexpr uint32_t kEagerRuns = 1024;
   uint32_t n_trans = 0;
@@ -847,17 +839,17 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   // then issued once more with the two-atomic form
   auto issue_gc_chain = [&](int packed) -> int {
     if (P.gcadjust) {
-      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide"); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, packed, ctx->slabs.p, st); }
+      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, packed, ctx->slabs.p, st); }
       { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
       HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
       { Timer t(ctx, "gc_table"); launch_gc_table(d_acc, d_table, st); }
       HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-      { Timer t(ctx, "gc_rescale"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+      { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
       { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
       { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
     } else if (want_cap) {
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-      { Timer t(ctx, "value_hist"); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
+      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
       launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st);
       launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
     }
@@ -962,7 +954,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, res_vals * kResClasses * 4, st));
   BinAccum* d_bacc = reinterpret_cast<BinAccum*>(small + kOffBinAcc);
   HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
-  { Timer t(ctx, "cap_compact_bin"); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, ctx->slabs.p, st); }
+  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, ctx->slabs.p, st); }
   { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, ctx->hist_res.as<uint32_t>(), ctx->slabs.p, st); }
   BinAccum bacc;
   std::vector<uint32_t> hres(res_vals * kResClasses);
@@ -1013,8 +1005,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     const double factor = sqrt(2.0 * (1.0 + P.epsilon) * log(3.1E9));   // rsi.cpp:1829
     const int LmaxBase = std::max(20, 10000 / P.m);                      // rsi.cpp:1830-1831
 
-    HIPCHK(ctx->first_del.ensure((size_t)nb * 4));
-    HIPCHK(ctx->first_dup.ensure((size_t)nb * 4));
+    HIPCHK(ctx->first_del.ensure((size_t)(2 * nb + 8) * 4));   // first_del | first_dup, set to "no L" by one memset
     HIPCHK(ctx->status1.ensure((size_t)nb * 4));
     HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
     HIPCHK(ctx->status2.ensure((size_t)nb * 4));
@@ -1186,7 +1177,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
 
 const char* rsi_hot_last_error(const rsi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on != 0; }
+void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on < 0 ? 0 : on > 2 ? 1 : on; }
 
 int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n, rsi_result** out) {
   if (!ctx || !p || !d_depth || !d_fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
@@ -1771,7 +1762,7 @@ void rsi_pool_destroy(rsi_pool* pool) {
 
 int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
 rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
-void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) c->timing = on != 0; }
+void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) rsi_hot_set_timing(c, on); }
 void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
   if (!pool) return;
   std::lock_guard<std::mutex> lk(pool->gate.m);

@@ -64,6 +64,8 @@ def main():
     def run(name, pool, kv, timed):
         for k in keys:
             os.environ[k] = kv.get(k, "0")
+        pool.set_timing(kv.get("timing", "1") != "0")   # HIP events around every launch (what bench.py runs with)
+        timed = timed and kv.get("timing", "1") != "0"
         pool.times = tables[name]
         torch.cuda.synchronize()
         th0 = throttled()
