@@ -97,6 +97,14 @@ void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin,
                      uint32_t* hist, uint32_t np, hipStream_t stream);
 
+// The whole median as one chain of launches (min/max -> plan -> histogram -> walk); `out` receives the result, or the
+// flag of the first test that failed.  d_center != NULL: the centre is read from device memory (an earlier chain's `med`).
+// `mm` must hold the "nothing seen" record on entry ({0xffffffff, 0, 0, 0}) and does again on exit; hist has cap entries.
+struct GridMedian { double med, ymin; unsigned long long count; uint32_t np, flags; };
+enum { kGridEmpty = 1, kGridNonFinite = 2, kGridDegenerate = 4, kGridTooWide = 8 };
+void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                        MinMaxF* mm, uint32_t* hist, uint32_t cap, GridMedian* out, hipStream_t stream);
+
 // ---- K7: RSI scan (rsistatus, rsi.cpp:1191-1259; runmeantp wufunctions.cpp:573-647) ----
 struct ScanParams {
   int64_t nb;

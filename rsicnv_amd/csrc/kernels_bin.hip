@@ -77,8 +77,8 @@ __device__ inline float sel_value(const float* __restrict__ x, int64_t i, int us
   return use_abs ? (float)fabs((double)v - center) : v;   // RDtmp[i] = abs(RDtrans[i]-tmedian), rsi.cpp:1276
 }
 
-__global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict__ x, const int32_t* __restrict__ mask,
-                                                         int64_t nb, int use_abs, double center, MinMaxF* __restrict__ mm) {
+__device__ __forceinline__ void minmax_body(const float* __restrict__ x, const int32_t* __restrict__ mask, int64_t nb,
+                                            int use_abs, double center, MinMaxF* __restrict__ mm) {
   uint32_t kmin = 0xffffffffu, kmax = 0;
   unsigned int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
@@ -104,6 +104,17 @@ __global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                         int64_t nb, int use_abs, double center, MinMaxF* __restrict__ mm) {
+  minmax_body(x, mask, nb, use_abs, center, mm);
+}
+// the same with the centre taken from an earlier link of a device-side chain (the median just found)
+__global__ __launch_bounds__(kThreads) void k_minmax_f32_at(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                            int64_t nb, int use_abs, const double* __restrict__ center,
+                                                            MinMaxF* __restrict__ mm) {
+  minmax_body(x, mask, nb, use_abs, *center, mm);
+}
+
 constexpr uint32_t kLdsBins = 32768;   // 128 KB of LDS counters (one workgroup per CU): covers a value range of 327
 
 // Each thread takes kHistRun consecutive elements and merges equal neighbouring buckets before the
@@ -111,10 +122,9 @@ constexpr uint32_t kLdsBins = 32768;   // 128 KB of LDS counters (one workgroup 
 // one-atomic-per-element histogram serialises on it (271 ms per 3 Gb step with global atomics).
 constexpr int kHistRun = 8;
 
-__global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__ x, const int32_t* __restrict__ mask,
-                                                       int64_t nb, int use_abs, double center, double ymin,
-                                                       uint32_t* __restrict__ hist, uint32_t np, int use_lds) {
-  extern __shared__ unsigned int s_h[];
+__device__ __forceinline__ void hist_body(const float* __restrict__ x, const int32_t* __restrict__ mask, int64_t nb, int use_abs,
+                                          double center, double ymin, uint32_t* __restrict__ hist, uint32_t np, int use_lds,
+                                          unsigned int* s_h) {
   if (use_lds) { for (uint32_t e = threadIdx.x; e < np; e += kThreads) s_h[e] = 0; __syncthreads(); }
   const int64_t nchunks = (nb + kHistRun - 1) / kHistRun;
   for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
@@ -137,6 +147,76 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
   if (use_lds) {
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < np; e += kThreads) { const unsigned int c = s_h[e]; if (c) atomicAdd(&hist[e], c); }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                       int64_t nb, int use_abs, double center, double ymin,
+                                                       uint32_t* __restrict__ hist, uint32_t np, int use_lds) {
+  extern __shared__ unsigned int s_h[];
+  hist_body(x, mask, nb, use_abs, center, ymin, hist, np, use_lds, s_h);
+}
+
+// ---- the same median as one device-side chain: min/max -> plan -> histogram -> walk, nothing returns to the
+// host in between; a second chain can take its centre from the first one's result (median, then MAD) ----
+__device__ inline float f32_unkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Every workgroup derives the grid (anchor, number of buckets) from the min/max record and clears its share of the
+// buckets; the first one publishes the plan.  The tests and their order are grid_median()'s (pipeline.hip).
+__global__ __launch_bounds__(kThreads) void k_grid_plan(const MinMaxF* __restrict__ mm, uint32_t cap, uint32_t* __restrict__ hist,
+                                                        GridMedian* __restrict__ g) {
+  const uint32_t kmin = mm->min_bits, kmax = mm->max_bits;
+  uint32_t flags = 0, np = 0;
+  double ymin = 0.0;
+  if (kmin == 0xffffffffu) flags = kGridEmpty;
+  else if (mm->nonfinite) flags = kGridNonFinite;
+  else {
+    ymin = (double)f32_unkey(kmin);
+    const double ymax = (double)f32_unkey(kmax);
+    if ((ymax - ymin) < 0.01) flags = kGridDegenerate;
+    else {
+      const size_t n = (size_t)((ymax - ymin) / 0.01 + 2);
+      if (n > cap) flags = kGridTooWide; else np = (uint32_t)n;
+    }
+  }
+  for (uint32_t e = blockIdx.x * kThreads + threadIdx.x; e < np; e += gridDim.x * kThreads) hist[e] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g->med = 0.0; g->ymin = ymin; g->count = 0; g->np = np; g->flags = flags; }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hist_f32_planned(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                               int64_t nb, int use_abs, double center,
+                                                               const double* __restrict__ center_ptr,
+                                                               const GridMedian* __restrict__ g, uint32_t* __restrict__ hist) {
+  extern __shared__ unsigned int s_h[];
+  if (g->flags) return;
+  const uint32_t np = g->np;
+  hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, np <= kLdsBins, s_h);
+}
+
+// hist_median_grid (hostmath.h) by one workgroup: the bucket in which the running count first reaches total/2.
+// Leaves the min/max record ready for the next chain.
+__global__ __launch_bounds__(kThreads) void k_grid_walk(const uint32_t* __restrict__ hist, GridMedian* __restrict__ g,
+                                                        MinMaxF* __restrict__ mm) {
+  __shared__ unsigned long long s_sum[kThreads];
+  if (threadIdx.x == 0) { mm->min_bits = 0xffffffffu; mm->max_bits = 0; mm->nonfinite = 0; }
+  if (g->flags) return;
+  const uint32_t np = g->np;
+  const uint32_t chunk = (np + kThreads - 1) / kThreads;
+  const uint32_t b0 = threadIdx.x * chunk < np ? threadIdx.x * chunk : np;
+  const uint32_t b1 = b0 + chunk < np ? b0 + chunk : np;
+  unsigned long long mine = 0;
+  for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
+  s_sum[threadIdx.x] = mine;
+  __syncthreads();
+  unsigned long long seen = 0, total = 0;
+  for (int t = 0; t < kThreads; ++t) { const unsigned long long v = s_sum[t]; if (t < (int)threadIdx.x) seen += v; total += v; }
+  const unsigned long long r2 = total / 2;
+  if (threadIdx.x == 0) { g->count = total; if (r2 == 0) g->med = g->ymin; }
+  if (r2 == 0) return;
+  for (uint32_t b = b0; b < b1; ++b) {
+    const unsigned long long upto = seen + hist[b];
+    if (seen < r2 && upto >= r2) g->med = g->ymin + (double)b * 0.01;
+    seen = upto;
   }
 }
 
@@ -665,6 +745,19 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
   hipLaunchKernelGGL(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
+}
+void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                        MinMaxF* mm, uint32_t* hist, uint32_t cap, GridMedian* out, hipStream_t stream) {
+  const int g = grid_for(nb, kThreads * 16);
+  if (d_center) hipLaunchKernelGGL(k_minmax_f32_at, dim3(g), dim3(kThreads), 0, stream, x, mask, nb, use_abs, d_center, mm);
+  else hipLaunchKernelGGL(k_minmax_f32, dim3(g), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
+  hipLaunchKernelGGL(k_grid_plan, dim3(64), dim3(kThreads), 0, stream, mm, cap, hist, out);
+  const size_t lds = (size_t)kLdsBins * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_f32_planned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int grid = grid_for(nb, kThreads * kHistRun * 8);
+  if (grid > 128) grid = 128;
+  hipLaunchKernelGGL(k_hist_f32_planned, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, hist);
+  hipLaunchKernelGGL(k_grid_walk, dim3(1), dim3(kThreads), 0, stream, hist, out, mm);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {

@@ -245,6 +245,7 @@ constexpr size_t kOffCounters = 4864;                             // uint32[8]: 
 constexpr size_t kOffRawMin = 5120;                               // uint32
 constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
 constexpr size_t kOffTable = 5376;                                // double[202]
+constexpr size_t kOffGrid = 7168;                                 // GridMedian[2]: the two links of a median -> MAD chain
 constexpr size_t kOffScanPass = 8192;                             // 2 x ScanPassWork (one per rsistatus pass)
 constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
 constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4096], cum[4097]
@@ -328,6 +329,38 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   for (uint32_t c : h) total += c;
   *count = total;
   *med = rsih::hist_median_grid(h.data(), np, total, ymin);
+  return RSI_OK;
+}
+
+// The device-side form (kernels_bin.hip, launch_grid_median): median of the selection into slot 0 and, chained to it,
+// the median of the absolute deviations from it (or from `center` when `first` is false) into slot 1 -- one round trip
+// for the pair instead of four.  A range wider than the resident histogram falls back to grid_median().
+constexpr uint32_t kGridCap = 1u << 20;
+int grid_pair_issue(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, bool first, double center, GridMedian out[2]) {
+  uint8_t* small = ctx->small.as<uint8_t>();
+  MinMaxF* d_mm = reinterpret_cast<MinMaxF*>(small + kOffMinMax);
+  GridMedian* d_g = reinterpret_cast<GridMedian*>(small + kOffGrid);
+  HIPCHK(ctx->hist_f.ensure((size_t)kGridCap * 4));
+  const MinMaxF init{0xffffffffu, 0u, 0u, 0u};
+  HIPCHK(copy_h2d(ctx, d_mm, &init, sizeof(init)));
+  if (first) {
+    Timer t(ctx, "grid_median");
+    launch_grid_median(d_x, d_mask, nb, 0, 0.0, nullptr, d_mm, ctx->hist_f.as<uint32_t>(), kGridCap, d_g, ctx->stream);
+  }
+  {
+    Timer t(ctx, "grid_median");
+    launch_grid_median(d_x, d_mask, nb, 1, center, first ? &d_g->med : nullptr, d_mm, ctx->hist_f.as<uint32_t>(), kGridCap, d_g + 1, ctx->stream);
+  }
+  HIPCHK(copy_d2h(ctx, out + (first ? 0 : 1), d_g + (first ? 0 : 1), (first ? 2 : 1) * sizeof(GridMedian)));
+  return RSI_OK;
+}
+// what grid_median() would have returned for this record (same tests, same order, same messages)
+int grid_result(rsi_ctx* ctx, const GridMedian& g, double* med, uint64_t* count) {
+  if (g.flags & kGridEmpty) { *count = 0; *med = 0; return RSI_OK; }
+  if (g.flags & kGridNonFinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
+  if (g.flags & kGridDegenerate)
+    return fail(ctx, RSI_ERR_UNSUPPORTED, "degenerate transform: all selected bins within 0.01 (the reference returns their mean)");
+  *med = g.med; *count = g.count;
   return RSI_OK;
 }
 
@@ -584,12 +617,21 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   {
     Phase ph(ctx, "scan.quantiles");
     GateShared gs(ctx);
-    if (!use_med) {
-      if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
+    GridMedian g[2];
+    if ((rc = grid_pair_issue(ctx, d_T, nullptr, nb, !use_med, RDmedian, g)) != RSI_OK) return rc;
+    HIPCHK(CTX_SYNC());
+    if ((!use_med && (g[0].flags & kGridTooWide)) || (g[1].flags & kGridTooWide)) {   // host-driven path, any range
+      if (!use_med) {
+        if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
+      } else {
+        tmedian = RDmedian;
+      }
+      if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
     } else {
       tmedian = RDmedian;
+      if (!use_med && (rc = grid_result(ctx, g[0], &tmedian, &cnt)) != RSI_OK) return rc;
+      if ((rc = grid_result(ctx, g[1], &absmed, &cnt)) != RSI_OK) return rc;
     }
-    if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
   }
   tsigma = absmed / 0.6745;
   tlamda = factor * tsigma;
@@ -683,10 +725,15 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   GateShared gs_q2(ctx);
   double tmed2;
   uint64_t k = 0;
-  if ((rc = grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k)) != RSI_OK) return rc;
+  GridMedian g2[2];
+  if ((rc = grid_pair_issue(ctx, d_T, d_st1f, nb, true, 0.0, g2)) != RSI_OK) return rc;
+  HIPCHK(CTX_SYNC());
+  const bool wide2 = (g2[0].flags & kGridTooWide) != 0;
+  if ((rc = wide2 ? grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k) : grid_result(ctx, g2[0], &tmed2, &k)) != RSI_OK) return rc;
   if (k > (uint64_t)(nb / 2)) {
     tmedian = tmed2;
-    if ((rc = grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
+    if ((rc = (wide2 || (g2[1].flags & kGridTooWide)) ? grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)
+                                                      : grid_result(ctx, g2[1], &absmed, &cnt)) != RSI_OK) return rc;
     tsigma = absmed / 0.6745;
     tlamda = factor * tsigma;
     tlamda = std::max(tlamda, target);
