@@ -80,7 +80,7 @@ void launch_cap_compact_fold(int m, int32_t capval, int64_t ncompact, uint32_t* 
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =
-// min over bins as float bits (values are >= 0).
+// complement of the smallest order key over the bins (atomicMax; zero on entry = nothing seen).
 void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, double r, float* raw,
                    uint32_t* rawmin_bits, hipStream_t stream);
 // x = (float)(raw - tmin); x = (float)(x / med_nbt * med); bins 0..2 <- lev[0..2]
@@ -89,7 +89,8 @@ void launch_nb_scale(float* x, int64_t nb, double tmin, double med_nbt, double m
 void launch_i32_to_f32(const int32_t* in, float* out, int64_t nb, hipStream_t stream);
 
 // ---- K6: 0.01-grid histogram quantiles of float arrays (partition_stat_tp, wufunctions.cpp:364) ----
-struct MinMaxF { uint32_t min_bits, max_bits; unsigned int nonfinite; unsigned int pad; };   // non-negative floats
+// min_inv = complement of the smallest order key seen, max_bits = largest key; all zero = nothing seen yet
+struct MinMaxF { uint32_t min_inv, max_bits; unsigned int nonfinite; unsigned int pad; };
 // min/max over x[i] (or |x[i]-center| rounded to float when use_abs), restricted to mask[i]==0 when mask != NULL
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
                        hipStream_t stream);
@@ -99,7 +100,7 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
 
 // The whole median as one chain of launches (min/max -> plan -> histogram -> walk); `out` receives the result, or the
 // flag of the first test that failed.  d_center != NULL: the centre is read from device memory (an earlier chain's `med`).
-// `mm` must hold the "nothing seen" record on entry ({0xffffffff, 0, 0, 0}) and does again on exit; hist has cap entries.
+// `mm` must hold the "nothing seen" record on entry (all zero) and does again on exit; hist has cap entries.
 struct GridMedian { double med, ymin; unsigned long long count; uint32_t np, flags; };
 enum { kGridEmpty = 1, kGridNonFinite = 2, kGridDegenerate = 4, kGridTooWide = 8 };
 void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,

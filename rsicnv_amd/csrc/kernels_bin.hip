@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kThreads) void k_nb_raw(const int64_t* __restrict__
     kmin = k < kmin ? k : kmin;
   }
   for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(kmin, d); kmin = o < kmin ? o : kmin; }
-  if (lane_id() == 0 && kmin != 0xffffffffu) atomicMin(rawmin_key, kmin);
+  if (lane_id() == 0 && kmin != 0xffffffffu) atomicMax(rawmin_key, ~kmin);   // complement: all zero = nothing seen
 }
 
 // rsi.cpp:1176-1185: subtract the minimum, rescale to the depth scale, overwrite bins 0..2
@@ -98,7 +98,7 @@ __device__ __forceinline__ void minmax_body(const float* __restrict__ x, const i
   __syncthreads();
   if (threadIdx.x == 0) {   // one set of atomics per workgroup
     for (int w = 1; w < kThreads / 64; ++w) { kmin = s_min[w] < kmin ? s_min[w] : kmin; kmax = s_max[w] > kmax ? s_max[w] : kmax; bad |= s_bad[w]; }
-    if (kmin != 0xffffffffu) atomicMin(&mm->min_bits, kmin);
+    if (kmin != 0xffffffffu) atomicMax(&mm->min_inv, ~kmin);
     if (kmax != 0) atomicMax(&mm->max_bits, kmax);
     if (bad) atomicOr(&mm->nonfinite, 1u);
   }
@@ -165,7 +165,7 @@ __device__ inline float f32_unkey(uint32_t k) { return __uint_as_float((k & 0x80
 // buckets; the first one publishes the plan.  The tests and their order are grid_median()'s (pipeline.hip).
 __global__ __launch_bounds__(kThreads) void k_grid_plan(const MinMaxF* __restrict__ mm, uint32_t cap, uint32_t* __restrict__ hist,
                                                         GridMedian* __restrict__ g) {
-  const uint32_t kmin = mm->min_bits, kmax = mm->max_bits;
+  const uint32_t kmin = ~mm->min_inv, kmax = mm->max_bits;
   uint32_t flags = 0, np = 0;
   double ymin = 0.0;
   if (kmin == 0xffffffffu) flags = kGridEmpty;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32_planned(const float* __re
 __global__ __launch_bounds__(kThreads) void k_grid_walk(const uint32_t* __restrict__ hist, GridMedian* __restrict__ g,
                                                         MinMaxF* __restrict__ mm) {
   __shared__ unsigned long long s_sum[kThreads];
-  if (threadIdx.x == 0) { mm->min_bits = 0xffffffffu; mm->max_bits = 0; mm->nonfinite = 0; }
+  if (threadIdx.x == 0) { mm->min_inv = 0; mm->max_bits = 0; mm->nonfinite = 0; }
   if (g->flags) return;
   const uint32_t np = g->np;
   const uint32_t chunk = (np + kThreads - 1) / kThreads;

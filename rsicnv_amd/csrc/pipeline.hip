@@ -138,7 +138,7 @@ struct rsi_ctx {
   char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
   size_t text_pin_cap = 0;
   int64_t n_in = 0;                          // length of the depth currently in in_depth
-  DevBuf gcbits, nbits, ntrans, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
+  DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64;   // candidate tests on the device (kernels_cand.hip)
@@ -239,19 +239,21 @@ int fail(rsi_ctx* ctx, int code, const std::string& msg) {
 // offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
 constexpr size_t kOffGcAcc = 0;                                   // GcAccum
 constexpr size_t kOffValAux = 4096;                               // ValueHistAux
-constexpr size_t kOffBinAcc = 4352;                               // BinAccum
 constexpr size_t kOffMinMax = 4608;                               // MinMaxF
 constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
 constexpr size_t kOffRawMin = 5120;                               // uint32
 constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
-constexpr size_t kOffTable = 5376;                                // double[202]
-constexpr size_t kOffGrid = 7168;                                 // GridMedian[2]: the two links of a median -> MAD chain
-constexpr size_t kOffScanPass = 8192;                             // 2 x ScanPassWork (one per rsistatus pass)
+constexpr size_t kHeaderBytes = 5376;                             // everything above: zeroed at the start of a run, fetched in one copy
+constexpr uint32_t kMaxTransitions = 1u << 16;
+constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:
+                                                                  // the header and the first entries travel as one transfer
+constexpr size_t kOffTable = kOffNtrans + (size_t)kMaxTransitions * 8;   // double[202]
+constexpr size_t kOffGrid = kOffTable + 1792;                     // GridMedian[2]: the two links of a median -> MAD chain
+constexpr size_t kOffScanPass = kOffGrid + 1024;                  // 2 x ScanPassWork (one per rsistatus pass)
 constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
-constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4096], cum[4097]
+constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4100], cum[4097]
 constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
 constexpr int kMaxRegions = 4096;
-constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr uint32_t kMaxRunEntries = 1u << 20;
 constexpr int kMaxL = 2048;
 
@@ -305,16 +307,15 @@ struct ScanOut {
 int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, int use_abs, double center,
                 double* med, uint64_t* count) {
   uint8_t* small = ctx->small.as<uint8_t>();
-  MinMaxF init{0xffffffffu, 0u, 0u, 0u};
-  HIPCHK(copy_h2d(ctx, small + kOffMinMax, &init, sizeof(init)));
   { Timer t(ctx, "minmax_f32"); launch_minmax_f32(d_x, d_mask, nb, use_abs, center, reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->stream); }
   MinMaxF mm;
   HIPCHK(copy_d2h(ctx, &mm, small + kOffMinMax, sizeof(mm)));
+  HIPCHK(hipMemsetAsync(small + kOffMinMax, 0, sizeof(MinMaxF), ctx->stream));   // "nothing seen" again for the next user
   HIPCHK(CTX_SYNC());
-  if (mm.min_bits == 0xffffffffu) { *count = 0; *med = 0; return RSI_OK; }
+  if (mm.min_inv == 0u) { *count = 0; *med = 0; return RSI_OK; }
   if (mm.nonfinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
   auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
-  const double ymin = unkey(mm.min_bits), ymax = unkey(mm.max_bits);
+  const double ymin = unkey(~mm.min_inv), ymax = unkey(mm.max_bits);
   if ((ymax - ymin) < 0.01)
     return fail(ctx, RSI_ERR_UNSUPPORTED, "degenerate transform: all selected bins within 0.01 (the reference returns their mean)");
   const size_t np = (size_t)((ymax - ymin) / 0.01 + 2);
@@ -341,8 +342,7 @@ int grid_pair_issue(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64
   MinMaxF* d_mm = reinterpret_cast<MinMaxF*>(small + kOffMinMax);
   GridMedian* d_g = reinterpret_cast<GridMedian*>(small + kOffGrid);
   HIPCHK(ctx->hist_f.ensure((size_t)kGridCap * 4));
-  const MinMaxF init{0xffffffffu, 0u, 0u, 0u};
-  HIPCHK(copy_h2d(ctx, d_mm, &init, sizeof(init)));
+  // d_mm holds "nothing seen" (all zero) here: the run's first memset covers it and every user leaves it that way
   if (first) {
     Timer t(ctx, "grid_median");
     launch_grid_median(d_x, d_mask, nb, 0, 0.0, nullptr, d_mm, ctx->hist_f.as<uint32_t>(), kGridCap, d_g, ctx->stream);
@@ -852,24 +852,24 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   HIPCHK(ctx->small.ensure(kSmallBytes));
   HIPCHK(ctx->gcbits.ensure((size_t)nwords * 8));
   HIPCHK(ctx->nbits.ensure((size_t)nwords * 8));
-  HIPCHK(ctx->ntrans.ensure((size_t)kMaxTransitions * 8));
   HIPCHK(ctx->hist_val.ensure((size_t)kHistValues * 4));
   uint8_t* small = ctx->small.as<uint8_t>();
   ph_a1a.stop();
   Phase ph_a1b(ctx, "a1b.launch K1-K3");
-  HIPCHK(hipMemsetAsync(small, 0, kOffTable, st));
+  HIPCHK(hipMemsetAsync(small, 0, kHeaderBytes, st));
 
   // ---- A1-A4 are issued back to back: GC mask and N runs (K1, K1b), GC table and rescale (K2, K3), the cap
   // median walk.  The GC table is built on the device, so nothing in this chain needs the host; the N-run list,
   // the GC accumulators (for the checks and the log) and the median come back in ONE round trip. ----
   uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
   { Timer t(ctx, "fasta_classify", true); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
-  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, ctx->ntrans.as<uint64_t>(), d_ncount, kMaxTransitions, st); }
+  uint64_t* d_ntrans = reinterpret_cast<uint64_t*>(small + kOffNtrans);
+  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, st); }
   constexpr uint32_t kEagerRuns = 1024;
   uint32_t n_trans = 0;
   std::vector<uint64_t> trans_raw(kEagerRuns);
-  HIPCHK(copy_d2h(ctx, &n_trans, d_ncount, 4));
-  HIPCHK(copy_d2h(ctx, trans_raw.data(), ctx->ntrans.p, (size_t)kEagerRuns * 8));
+  // the header (accumulators, counters, median) and the first entries of the N-run list: one transfer at the end of the chain
+  std::vector<unsigned char> head(kHeaderBytes + (size_t)kEagerRuns * 8);
 
   const int32_t* d_src = d_depth;
   const bool want_cap = P.cap > 1;
@@ -888,7 +888,6 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     if (P.gcadjust) {
       { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, packed, ctx->slabs.p, st); }
       { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
-      HIPCHK(copy_d2h(ctx, &acc, d_acc, sizeof(acc)));
       { Timer t(ctx, "gc_table"); launch_gc_table(d_acc, d_table, st); }
       HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
       { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
@@ -903,10 +902,16 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     if (want_cap) {
       // the median walk runs on the device (one small workgroup): 24 bytes come back instead of the 256 KB histogram
       { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
-      HIPCHK(copy_d2h(ctx, &vm, d_vm, sizeof(vm)));
-      HIPCHK(copy_d2h(ctx, &aux, d_aux, sizeof(aux)));
     }
+    HIPCHK(copy_d2h(ctx, head.data(), small, head.size()));
     return RSI_OK;
+  };
+  auto unpack_head = [&]() {
+    memcpy(&acc, head.data() + kOffGcAcc, sizeof(acc));
+    memcpy(&aux, head.data() + kOffValAux, sizeof(aux));
+    memcpy(&vm, head.data() + kOffValMedian, sizeof(vm));
+    memcpy(&n_trans, head.data() + kOffCounters + 5 * 4, 4);
+    memcpy(trans_raw.data(), head.data() + kOffNtrans, (size_t)kEagerRuns * 8);
   };
   // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
   if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), gc_rescale_slab_bytes(n))));
@@ -914,6 +919,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   if (rc != RSI_OK) return rc;
   ph_a1b.stop();
   { Phase ph_a1c(ctx, "a1c.wait K1-K3"); HIPCHK(CTX_SYNC()); }
+  unpack_head();
   if (P.gcadjust && (acc.negatives & 2u)) {
     Phase ph_w(ctx, "a2-3.gc wide redo");
     HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
@@ -921,6 +927,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     HIPCHK(hipMemsetAsync(d_aux, 0, sizeof(ValueHistAux), st));
     if ((rc = issue_gc_chain(0)) != RSI_OK) return rc;
     HIPCHK(CTX_SYNC());
+    unpack_head();
   }
 
   // ---- N runs -> padded, merged regions (get_noseq_regions, loaddata.cpp:243-273) ----
@@ -929,7 +936,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     if (n_trans > kMaxTransitions) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
     trans_raw.resize(n_trans > kEagerRuns ? n_trans : std::max<uint32_t>(n_trans, 0));
     if (n_trans > kEagerRuns) {
-      HIPCHK(copy_d2h(ctx, trans_raw.data() + kEagerRuns, ctx->ntrans.as<uint64_t>() + kEagerRuns, (size_t)(n_trans - kEagerRuns) * 8));
+      HIPCHK(copy_d2h(ctx, trans_raw.data() + kEagerRuns, d_ntrans + kEagerRuns, (size_t)(n_trans - kEagerRuns) * 8));
       HIPCHK(CTX_SYNC());
     }
     std::vector<int64_t> rs, re;
@@ -991,23 +998,32 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   if (ncompact <= 0 || nb < 8) return fail(ctx, RSI_ERR_TOO_SMALL, "nothing left after removing N regions");
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  if (!noncode.empty()) HIPCHK(copy_h2d(ctx, d_cbreak, cbreak.data(), cbreak.size() * 8));
-  HIPCHK(copy_h2d(ctx, d_cum, cum.data(), cum.size() * 8));
+  {   // cbreak[4100] | cum: one upload
+    std::vector<int64_t> both((size_t)4100 + cum.size(), 0);
+    std::copy(cbreak.begin(), cbreak.end(), both.begin());
+    std::copy(cum.begin(), cum.end(), both.begin() + 4100);
+    HIPCHK(copy_h2d(ctx, d_cbreak, both.data(), both.size() * 8));
+  }
   HIPCHK(ctx->rdc.ensure((size_t)(ncompact + 4) * 4));
   HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
   HIPCHK(ctx->binsum.ensure((size_t)nb * 8));
-  HIPCHK(ctx->hist_res.ensure((size_t)kHistValues * kResClasses * 4));
+  // BinAccum sits in a 256-byte header of the residue-class histogram: cleared and fetched together with it
+  constexpr size_t kResHead = 256;
+  static_assert(sizeof(BinAccum) <= kResHead, "BinAccum outgrew its header");
+  HIPCHK(ctx->hist_res.ensure(kResHead + (size_t)kHistValues * kResClasses * 4));
   const size_t res_vals = want_cap && capval < kHistValues - 1 ? (size_t)std::max(capval, 0) + 1 : (size_t)kHistValues;
-  HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, res_vals * kResClasses * 4, st));
-  BinAccum* d_bacc = reinterpret_cast<BinAccum*>(small + kOffBinAcc);
+  HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, kResHead + res_vals * kResClasses * 4, st));
+  BinAccum* d_bacc = reinterpret_cast<BinAccum*>(ctx->hist_res.p);
+  uint32_t* d_res = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead);
   HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
-  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), ctx->hist_res.as<uint32_t>(), d_bacc, ctx->slabs.p, st); }
-  { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, ctx->hist_res.as<uint32_t>(), ctx->slabs.p, st); }
+  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, st); }
+  { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, d_res, ctx->slabs.p, st); }
   BinAccum bacc;
-  std::vector<uint32_t> hres(res_vals * kResClasses);
-  HIPCHK(copy_d2h(ctx, &bacc, d_bacc, sizeof(bacc)));
-  HIPCHK(copy_d2h(ctx, hres.data(), ctx->hist_res.p, hres.size() * 4));
-  HIPCHK(CTX_SYNC());   // also covers cbreak/cum going out of use
+  std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);
+  HIPCHK(copy_d2h(ctx, hres_all.data(), ctx->hist_res.p, hres_all.size() * 4));
+  HIPCHK(CTX_SYNC());
+  memcpy(&bacc, hres_all.data(), sizeof(bacc));
+  const uint32_t* hres = hres_all.data() + kResHead / 4;
   if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");
   // chromosome median / SD (rsi.cpp:2202-2203)
   std::vector<uint64_t> hall(res_vals, 0);
@@ -1061,11 +1077,11 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     // ---- A10: NB transform (K5), always computed as the reference does (Q10) ----
     HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
     uint32_t* d_rawmin = reinterpret_cast<uint32_t*>(small + kOffRawMin);
-    HIPCHK(hipMemsetAsync(d_rawmin, 0xff, 4, st));
     { Timer t(ctx, "nb_raw"); launch_nb_raw(ctx->binsum.as<int64_t>(), nb, P.m, ncompact, r, ctx->tnb.as<float>(), d_rawmin, st); }
     uint32_t minkey;
-    HIPCHK(copy_d2h(ctx, &minkey, d_rawmin, 4));
+    HIPCHK(copy_d2h(ctx, &minkey, d_rawmin, 4));   // zeroed with the header at the start of the run, used once
     HIPCHK(CTX_SYNC());
+    minkey = ~minkey;
     float tminf;
     { uint32_t b = (minkey & 0x80000000u) ? (minkey & 0x7fffffffu) : ~minkey; memcpy(&tminf, &b, 4); }
     const double tmin = tminf;
