@@ -177,11 +177,11 @@ struct CandOut {
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
 };
 void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
-// one launch = one call of optimize_with_derivative for every job; part_v / part_i: sharpen_part_slots(njobs) entries, done: njobs
-// counters, zero before the first launch (each launch leaves them zero again)
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* part_v, int32_t* part_i,
-                          uint32_t* done, hipStream_t stream);
-size_t sharpen_part_slots(int njobs);
+// one launch = one call of optimize_with_derivative for every job; ws: sharpen_workspace_bytes(njobs) bytes whose first
+// sharpen_workspace_zero_bytes(njobs) are zero before the first launch (each launch leaves them zero again)
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream);
+size_t sharpen_workspace_bytes(int njobs);
+size_t sharpen_workspace_zero_bytes(int njobs);
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
 

@@ -84,11 +84,15 @@ __device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f,
 // the len values from q on; the new start is the first maximum (DEL) / minimum (DUP) of dd over its
 // first 2*reach entries, the new end the first minimum / maximum over its last 2*reach entries; only
 // strictly positive / negative values count and index 0 never moves anything.
-// Each of the two search windows of a candidate is cut into kEdgeChunks pieces, one workgroup each:
-// the workgroup gets dd at its first index directly (a reduction over 2*len values), then walks its
-// piece in tiles of 256 with dd[i+1] - dd[i] = -p[q-len] + 2 p[q] - p[q+len] and an exact int64 block
-// scan.  The last workgroup of a candidate to finish folds the pieces (smallest index wins ties, as
-// the reference's strict comparisons do) and writes the new coordinates.
+// Each of the two search windows of a candidate is cut into kEdgeChunks pieces, one workgroup each.
+// A workgroup walks its piece in tiles of 256 with dd[i+1] - dd[i] = -p[q-len] + 2 p[q] - p[q+len] and an
+// exact int64 block scan, RELATIVE to the piece's first index: the extremum of a piece sits at the same index
+// whatever the offset, and the sign test is monotone in the value, so both wait for the fold.  dd at a
+// window's first index (a sum over 2*len values) is itself shared out: every workgroup of the window adds
+// a sixteenth of it to the window's accumulator.  The last workgroup of a candidate to finish chains the
+// pieces (offset of piece c = window start + totals of the pieces before it), applies the sign test, folds
+// (smallest index wins ties, as the reference's strict comparisons do) and writes the new coordinates.
+// Per candidate this reads about 7*len values instead of 2*len per workgroup.
 constexpr int kEdgeChunks = 16;
 struct ArgBest { long long v; int i; };
 __device__ inline ArgBest arg_pick(ArgBest a, ArgBest b, bool want_max) {
@@ -98,13 +102,34 @@ __device__ inline ArgBest arg_pick(ArgBest a, ArgBest b, bool want_max) {
   return b.i < a.i ? b : a;
 }
 
+struct SharpenWs {   // views into the workspace of one launch (sharpen_workspace_bytes)
+  unsigned long long* start_acc;   // [njobs][2]   dd at the first index of each window, accumulated; zero between launches
+  uint32_t* done;                  // [njobs]      finished workgroups; zero between launches
+  long long* part_v;               // [njobs][32]  extremum of the piece, relative to its first index
+  long long* part_t;               // [njobs][32]  sum of the piece's steps
+  int32_t* part_i;                 // [njobs][32]  index of the extremum (-1: empty piece)
+};
+__host__ __device__ inline size_t sharpen_zero_bytes(int njobs) { return ((size_t)njobs * 16 + (size_t)njobs * 4 + 15) & ~size_t(15); }
+__host__ __device__ inline SharpenWs sharpen_views(void* ws, int njobs) {
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  const size_t slots = (size_t)njobs * 2 * kEdgeChunks;
+  SharpenWs w;
+  w.start_acc = reinterpret_cast<unsigned long long*>(p);
+  w.done = reinterpret_cast<uint32_t*>(p + (size_t)njobs * 16);
+  p += sharpen_zero_bytes(njobs);
+  w.part_v = reinterpret_cast<long long*>(p);
+  w.part_t = w.part_v + slots;
+  w.part_i = reinterpret_cast<int32_t*>(w.part_t + slots);
+  return w;
+}
+
 __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __restrict__ rdc, int64_t ncompact,
-                                                            EdgeJob* __restrict__ jobs, long long* __restrict__ part_v,
-                                                            int32_t* __restrict__ part_i, uint32_t* __restrict__ done) {
+                                                            EdgeJob* __restrict__ jobs, int njobs, void* __restrict__ ws) {
   __shared__ long long s_l[kMaxWaves];
   __shared__ long long s_v[kThreads / 64];
   __shared__ int s_i[kThreads / 64];
   __shared__ int s_last;
+  const SharpenWs W = sharpen_views(ws, njobs);
   const int jb = blockIdx.y;
   const EdgeJob job = jobs[jb];
   const int len = job.end - job.start + 1;
@@ -121,22 +146,26 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __res
   int i1 = i0 + cs; if (i1 > wbase + wlen) i1 = wbase + wlen;
   const bool del = job.type == 0;
   const bool want_max = win == 0 ? del : !del;
-  ArgBest best{0, -1};
-  if (i0 < i1) {
-    // dd at the piece's first index
-    const int q0 = from + i0;
+  {   // this workgroup's share of dd at the window's first index
+    const int q0 = from + wbase;
+    const int js = (len + kEdgeChunks - 1) / kEdgeChunks;
+    const int j0 = chunk * js;
+    int j1 = j0 + js; if (j1 > len) j1 = len;
     long long acc = 0;
-    for (int j = threadIdx.x; j < len; j += kThreads) acc += (long long)rdc[q0 - len + j] - (long long)rdc[q0 + j];
-    long long cur = block_reduce(acc, [](long long a, long long b) { return a + b; }, s_l);
-    for (int t0 = i0; t0 < i1; t0 += kThreads) {
-      const int i = t0 + (int)threadIdx.x;
-      long long delta = 0;
-      if (i < i1) { const int q = from + i; delta = -(long long)rdc[q - len] + 2ll * rdc[q] - (long long)rdc[q + len]; }
-      long long total;
-      const long long dd = cur + block_exscan_i64(delta, s_l, &total);
-      if (i < i1 && (want_max ? dd > 0 : dd < 0)) best = arg_pick(best, ArgBest{dd, i}, want_max);
-      cur += total;
-    }
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += kThreads) acc += (long long)rdc[q0 - len + j] - (long long)rdc[q0 + j];
+    acc = block_reduce(acc, [](long long a, long long b) { return a + b; }, s_l);
+    if (threadIdx.x == 0 && acc != 0) atomicAdd(&W.start_acc[jb * 2 + win], (unsigned long long)acc);
+  }
+  ArgBest best{0, -1};
+  long long cur = 0;   // dd relative to the piece's first index
+  for (int t0 = i0; t0 < i1; t0 += kThreads) {
+    const int i = t0 + (int)threadIdx.x;
+    long long delta = 0;
+    if (i < i1) { const int q = from + i; delta = -(long long)rdc[q - len] + 2ll * rdc[q] - (long long)rdc[q + len]; }
+    long long total;
+    const long long dd = cur + block_exscan_i64(delta, s_l, &total);
+    if (i < i1) best = arg_pick(best, ArgBest{dd, i}, want_max);
+    cur += total;
   }
   // block arg-reduction (values first, then smallest index)
   for (int d = 32; d >= 1; d >>= 1) { ArgBest o; o.v = __shfl_xor(best.v, d); o.i = __shfl_xor(best.i, d); best = arg_pick(best, o, want_max); }
@@ -147,22 +176,30 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __res
     ArgBest r{s_v[0], s_i[0]};
     for (int w = 1; w < kThreads / 64; ++w) r = arg_pick(r, ArgBest{s_v[w], s_i[w]}, want_max);
     const size_t slot = (size_t)jb * 2 * kEdgeChunks + blockIdx.x;
-    part_v[slot] = r.v; part_i[slot] = r.i;
+    W.part_v[slot] = r.v; W.part_i[slot] = r.i; W.part_t[slot] = cur;
     __threadfence();
-    s_last = atomicAdd(&done[jb], 1u) == 2 * kEdgeChunks - 1;
+    s_last = atomicAdd(&W.done[jb], 1u) == 2 * kEdgeChunks - 1;
   }
   __syncthreads();
-  if (s_last && threadIdx.x == 0) {   // every piece of this candidate is in: fold them
+  if (s_last && threadIdx.x == 0) {   // every piece of this candidate is in: chain and fold them
     __threadfence();
-    ArgBest lo{0, -1}, hi{0, -1};
-    for (int c = 0; c < kEdgeChunks; ++c) {
-      const size_t a = (size_t)jb * 2 * kEdgeChunks + c, b = a + kEdgeChunks;
-      lo = arg_pick(lo, ArgBest{part_v[a], part_i[a]}, del);
-      hi = arg_pick(hi, ArgBest{part_v[b], part_i[b]}, !del);
+    ArgBest pick[2] = {{0, -1}, {0, -1}};
+    for (int w = 0; w < 2; ++w) {
+      const bool wmax = w == 0 ? del : !del;
+      long long off = (long long)atomicAdd(&W.start_acc[jb * 2 + w], 0ull);   // dd at the window's first index
+      for (int c = 0; c < kEdgeChunks; ++c) {
+        const size_t a = (size_t)jb * 2 * kEdgeChunks + w * kEdgeChunks + c;
+        if (W.part_i[a] >= 0) {
+          const long long v = W.part_v[a] + off;
+          if (wmax ? v > 0 : v < 0) pick[w] = arg_pick(pick[w], ArgBest{v, W.part_i[a]}, wmax);
+        }
+        off += W.part_t[a];
+      }
+      W.start_acc[jb * 2 + w] = 0;   // ready for the second call
     }
-    if (lo.i > 0) jobs[jb].start = from + lo.i;
-    if (hi.i > 0) jobs[jb].end = to - nstep + hi.i;
-    done[jb] = 0;   // ready for the second call
+    if (pick[0].i > 0) jobs[jb].start = from + pick[0].i;
+    if (pick[1].i > 0) jobs[jb].end = to - nstep + pick[1].i;
+    W.done[jb] = 0;
   }
 }
 
@@ -497,12 +534,12 @@ void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long
   hipLaunchKernelGGL(k_range_sums, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums);
 }
 
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, long long* part_v, int32_t* part_i,
-                          uint32_t* done, hipStream_t stream) {
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, part_v, part_i, done);
+  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, njobs, ws);
 }
-size_t sharpen_part_slots(int njobs) { return (size_t)njobs * 2 * kEdgeChunks; }
+size_t sharpen_workspace_bytes(int njobs) { return sharpen_zero_bytes(njobs) + (size_t)njobs * 2 * kEdgeChunks * (8 + 8 + 4); }
+size_t sharpen_workspace_zero_bytes(int njobs) { return sharpen_zero_bytes(njobs); }
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;

@@ -443,18 +443,16 @@ class DeviceTester : public rsih::NeighbourTester {
     if (L.empty()) return true;
     std::vector<EdgeJob> jobs(L.size());
     for (size_t i = 0; i < L.size(); ++i) jobs[i] = {L[i].start, L[i].end, L[i].type, 0};
-    const size_t slots = sharpen_part_slots((int)jobs.size());
-    const size_t off_i = slots * 8, off_done = off_i + slots * 4;
-    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(off_done + jobs.size() * 4))) return false; }
+    const int nj = (int)jobs.size();
+    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(sharpen_workspace_bytes(nj)))) return false; }
     uint8_t* ws = ctx->cand_i64.as<uint8_t>();
     GateShared gs(ctx);
     Phase ph(ctx, "cand.sharpen");
     if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob)))) return false;
-    if (!ok(hipMemsetAsync(ws + off_done, 0, jobs.size() * 4, ctx->stream))) return false;
+    if (!ok(hipMemsetAsync(ws, 0, sharpen_workspace_zero_bytes(nj), ctx->stream))) return false;
     for (int pass = 0; pass < 2; ++pass) {   // rsi.cpp:1876-1877
       Timer t(ctx, "sharpen_edges");
-      launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), (int)jobs.size(), reinterpret_cast<long long*>(ws),
-                           reinterpret_cast<int32_t*>(ws + off_i), reinterpret_cast<uint32_t*>(ws + off_done), ctx->stream);
+      launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), nj, ws, ctx->stream);
     }
     if (!ok(copy_d2h(ctx, jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob)))) return false;
     if (!wait()) return false;
