@@ -432,11 +432,18 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   {   // tiles of four consecutive values per thread: one 16-byte load, one block scan per 4096 values
     long long carry = 0;
     if (threadIdx.x == 0) P[0] = 0;
-    for (int t0 = 0; t0 < nref; t0 += 4 * kTestThreads) {
+    auto load_tile = [&](int t0) {
       const int e = t0 + 4 * (int)threadIdx.x;
       int4 v = make_int4(0, 0, 0, 0);
       if (e + 3 < nref) v = *reinterpret_cast<const int4*>(R + e);
       else { if (e < nref) v.x = R[e]; if (e + 1 < nref) v.y = R[e + 1]; if (e + 2 < nref) v.z = R[e + 2]; }
+      return v;
+    };
+    int4 vnext = load_tile(0);
+    for (int t0 = 0; t0 < nref; t0 += 4 * kTestThreads) {
+      const int e = t0 + 4 * (int)threadIdx.x;
+      const int4 v = vnext;
+      if (t0 + 4 * kTestThreads < nref) vnext = load_tile(t0 + 4 * kTestThreads);   // in flight during this tile's scan
       const long long a1 = v.x, a2 = a1 + v.y, a3 = a2 + v.z, a4 = a3 + v.w;
       long long total;
       const long long b = carry + block_exscan_i64(a4, s_l, &total);
