@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink chromosome lengths (debug only; invalidates the metric)")
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the side measurement of the single-chromosome configs")
     ap.add_argument("--workers", type=int, default=12, help="host threads / HIP streams per GPU (chromosomes in flight)")
     args = ap.parse_args()
 
@@ -212,6 +213,33 @@ def main():
     pool.times = timed_table
     phase_ms = pool.phase_table()
 
+    # ---- the single-chromosome configurations (configs[1], configs[2]) on the same pool: latency of ONE chromosome, i.e.
+    # no other chromosome to overlap with; reported next to `value`, never part of it ----
+    single = None
+    if rank == 0 and world == 1 and args.config == 4 and args.scale == 1.0 and not args.no_single:
+        single = {}
+        pool.set_timing(0)
+        for cfg, label in ((2, "configs[1]: one 60 Mb chromosome, 30x Poisson"), (3, "configs[2]: one 250 Mb chromosome, 30x gamma-Poisson + GC")):
+            sp = synth.config_plan(cfg)
+            s_fa = torch.empty(sp["n"] + 64, dtype=torch.uint8, device=dev)
+            s_rd = torch.empty(sp["n"] + 16, dtype=torch.int32, device=dev)
+            synth.generate_device(lib, sp, s_fa.data_ptr(), s_rd.data_ptr())
+            torch.cuda.synchronize()
+            sparams = api.make_params(**synth.config_flags(cfg))
+            one = [(s_rd.data_ptr(), s_fa.data_ptr(), sp["n"])]
+            for _ in range(2):
+                pool.run(sparams, one)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                r1 = pool.run(sparams, one)
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / reps
+            single[label] = {"ms": round(dt1 * 1e3, 3), "bases_per_s": round(sp["n"] / dt1, 1), "calls": len(r1[0].calls("calls"))}
+            del s_fa, s_rd
+        pool.set_timing(2)
+
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -229,7 +257,7 @@ def main():
                        "parallelism": f"{world} rank(s), one genome per GPU, {args.workers} chromosomes in flight per GPU, "
                                       "all_gather of per-chromosome summaries"},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
-            "kernel_ms_all_launches_extra_pass": kernel_ms_all,
+            "kernel_ms_all_launches_extra_pass": kernel_ms_all, "single_chromosome_configs": single,
             "worker_phase_ms_per_step": {k: round(v / args.steps, 2) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
         }
         print(json.dumps(out), flush=True)
