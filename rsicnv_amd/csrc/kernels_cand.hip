@@ -346,6 +346,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   __shared__ double s_d[kMaxWaves];
   __shared__ float s_f[kMaxWaves];
   __shared__ long long s_l[kMaxWaves];
+  __shared__ long long s_x[2][4 * kMaxWaves];   // prefix rounds: wave totals of four tiles, by round parity
   __shared__ int s_i2[kMaxWaves];
   __shared__ int s_q[3];
   const CandJob J = jobs[blockIdx.x];
@@ -429,9 +430,12 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
     }
   }
   // ---- running mean of width `width` over the neighbourhood (rsi.cpp:113-124): exact prefix, float means ----
-  {   // tiles of four consecutive values per thread: one 16-byte load, one block scan per 4096 values
+  {   // rounds of four tiles (4096 values each, four consecutive values per thread and tile, one 16-byte load each): the
+      // four wave scans of a round share ONE barrier, the exchange buffer alternates with the round's parity
+    constexpr int kTile = 4 * kTestThreads, kRound = 4 * kTile;
     long long carry = 0;
     if (threadIdx.x == 0) P[0] = 0;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     auto load_tile = [&](int t0) {
       const int e = t0 + 4 * (int)threadIdx.x;
       int4 v = make_int4(0, 0, 0, 0);
@@ -439,19 +443,44 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
       else { if (e < nref) v.x = R[e]; if (e + 1 < nref) v.y = R[e + 1]; if (e + 2 < nref) v.z = R[e + 2]; }
       return v;
     };
-    int4 vnext = load_tile(0);
-    for (int t0 = 0; t0 < nref; t0 += 4 * kTestThreads) {
+    int4 nx0 = load_tile(0), nx1 = load_tile(kTile), nx2 = load_tile(2 * kTile), nx3 = load_tile(3 * kTile);
+    int par = 0;
+    for (int t0 = 0; t0 < nref; t0 += kRound, par ^= 1) {
+      const int4 v0 = nx0, v1 = nx1, v2 = nx2, v3 = nx3;
+      if (t0 + kRound < nref) {   // the next round's loads fly during this round's scans
+        nx0 = load_tile(t0 + kRound); nx1 = load_tile(t0 + kRound + kTile);
+        nx2 = load_tile(t0 + kRound + 2 * kTile); nx3 = load_tile(t0 + kRound + 3 * kTile);
+      }
+      // named variables only: a runtime-indexed array would live in scratch memory
+      auto quad = [](const int4& v) { return (long long)v.x + v.y + v.z + v.w; };
+      long long i0 = quad(v0), i1 = quad(v1), i2 = quad(v2), i3 = quad(v3);   // inclusive wave scans of the quad sums
+      for (int d = 1; d < 64; d <<= 1) {
+        const long long u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d), u3 = __shfl_up(i3, d);
+        if (lane >= d) { i0 += u0; i1 += u1; i2 += u2; i3 += u3; }
+      }
+      long long* X = s_x[par];   // [4][kMaxWaves] wave totals
+      if (lane == 63) { X[wave] = i0; X[kMaxWaves + wave] = i1; X[2 * kMaxWaves + wave] = i2; X[3 * kMaxWaves + wave] = i3; }
+      __syncthreads();
+      long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, T0 = 0, T1 = 0, T2 = 0, T3 = 0;
+#pragma unroll 1
+      for (int w = 0; w < kMaxWaves; ++w) {
+        const long long c0 = X[w], c1 = X[kMaxWaves + w], c2 = X[2 * kMaxWaves + w], c3 = X[3 * kMaxWaves + w];
+        if (w < wave) { b0 += c0; b1 += c1; b2 += c2; b3 += c3; }
+        T0 += c0; T1 += c1; T2 += c2; T3 += c3;
+      }
+      auto store_quad = [&](int e, const int4& v, long long before) {   // P[e+1..e+4] = before + running sums of v
+        const long long a1 = before + v.x, a2 = a1 + v.y, a3 = a2 + v.z, a4 = a3 + v.w;
+        if (e < nref) P[e + 1] = a1;
+        if (e + 1 < nref) P[e + 2] = a2;
+        if (e + 2 < nref) P[e + 3] = a3;
+        if (e + 3 < nref) P[e + 4] = a4;
+      };
       const int e = t0 + 4 * (int)threadIdx.x;
-      const int4 v = vnext;
-      if (t0 + 4 * kTestThreads < nref) vnext = load_tile(t0 + 4 * kTestThreads);   // in flight during this tile's scan
-      const long long a1 = v.x, a2 = a1 + v.y, a3 = a2 + v.z, a4 = a3 + v.w;
-      long long total;
-      const long long b = carry + block_exscan_i64(a4, s_l, &total);
-      if (e < nref) P[e + 1] = b + a1;
-      if (e + 1 < nref) P[e + 2] = b + a2;
-      if (e + 2 < nref) P[e + 3] = b + a3;
-      if (e + 3 < nref) P[e + 4] = b + a4;
-      carry += total;
+      store_quad(e, v0, carry + b0 + i0 - quad(v0));
+      store_quad(e + kTile, v1, carry + T0 + b1 + i1 - quad(v1));
+      store_quad(e + 2 * kTile, v2, carry + T0 + T1 + b2 + i2 - quad(v2));
+      store_quad(e + 3 * kTile, v3, carry + T0 + T1 + T2 + b3 + i3 - quad(v3));
+      carry += T0 + T1 + T2 + T3;
     }
     __syncthreads();
   }
