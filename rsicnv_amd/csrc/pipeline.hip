@@ -4,294 +4,14 @@
 // C ABI.  There is no CPU fallback anywhere in this file: every array-sized computation is a
 // kernel from kernels_base.hip / kernels_bin.hip / kernels_cand.hip; the host only walks
 // device-built histograms and runs the candidate list logic (host_calls.cpp).
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <fcntl.h>
-#include <unistd.h>
-#include <sys/stat.h>
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <string>
-#include <vector>
-
-#include "../../include/rsi_hot.h"
-#include "bam_host.h"
-#include "host_calls.h"
-#include "hostmath.h"
-#include "kernels.h"
+#include "pipeline_internal.h"
 
 using namespace rsik;
+using namespace rsip;
 using rsih::Candidate;
 using rsih::Region;
 
 namespace {
-
-std::string g_last_error;   // last failure of any context (diagnostic; guarded by g_err_mu)
-std::mutex g_err_mu;
-void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_last_error = m; }
-
-// Growth hint of the running thread: (largest chromosome its pool has been handed) / (this one).
-// A buffer that has to grow is sized for the largest chromosome right away, so that after a
-// worker's first chromosome no hipFree/hipMalloc -- a device-wide synchronisation that stalls every
-// other worker, and slow on recycled VRAM -- happens in steady state.
-thread_local double tl_grow = 1.0;
-thread_local double tl_grow_ms = 0.0;   // time this thread spent re-allocating during the current run
-
-struct DevBuf {   // grow-only device allocation
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    const auto t0 = std::chrono::steady_clock::now();
-    const bool regrow = p != nullptr;   // a buffer whose size depends on the data turned out too small: be generous this time
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
-    const size_t scaled = (size_t)((double)bytes * tl_grow);
-    const size_t want = (regrow ? 2 * scaled : scaled + scaled / 8) + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    tl_grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return e;
-  }
-  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
-struct PinBuf {   // grow-only pinned host allocation: destination of the large device -> host copies.  From pageable memory
-                  // the runtime stages such a copy synchronously under its own lock, which stalls every other worker's
-                  // HIP calls for milliseconds per copy.
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr; cap = 0;
-    const size_t scaled = (size_t)((double)bytes * tl_grow);
-    const size_t want = scaled + scaled / 8 + 256;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-  ~PinBuf() { if (p) (void)hipHostFree(p); }
-};
-
-struct KernelTime { const char* name; hipEvent_t a, b; };
-
-// One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
-// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
-// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
-// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
-// a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
-// sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
-struct GpuGate {
-  std::mutex m;
-  std::condition_variable cv;
-  int sharers = 0, streamers_waiting = 0, streaming = 0;
-  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
-  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
-  void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
-  void lock(bool exclude_sharers) {
-    std::unique_lock<std::mutex> lk(m);
-    ++streamers_waiting;
-    cv.wait(lk, [&] { return exclude_sharers ? (streaming == 0 && sharers == 0) : streaming < max_streamers; });
-    --streamers_waiting;
-    ++streaming;
-  }
-  void unlock() { { std::lock_guard<std::mutex> lk(m); --streaming; } cv.notify_all(); }
-};
-
-double now_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-}  // namespace
-
-struct rsi_result {
-  std::vector<rsi_call> lists[4];
-  std::vector<int32_t> noncode;   // pairs
-  std::vector<int32_t> rp;        // per final call, after rsi_result_annotate_bam
-  std::vector<double> q0;
-  rsi_chrom_stats stats;
-  rsi_params params;
-};
-
-struct rsi_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
-  std::string err;
-  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base (HBM-bound) kernels only
-  std::vector<KernelTime> ktimes;
-  std::vector<hipEvent_t> event_pool;
-  size_t event_next = 0;
-  // workspace
-  DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
-  DevBuf text_dev[2], text_wg;               // depth text ingestion: two chunks of file bytes in HBM, per-workgroup order records
-  char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
-  size_t text_pin_cap = 0;
-  int64_t n_in = 0;                          // length of the depth currently in in_depth
-  DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
-  DevBuf slabs;   // per-workgroup partial results of the streaming kernels
-  DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
-  DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64;   // candidate tests on the device (kernels_cand.hip)
-  // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
-  int64_t n = 0, ncompact = 0, nb = 0;
-  bool have_gc = false, have_nb = false, have_med = false;
-  int last_scan_med = 0;
-  // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
-  std::vector<std::pair<const char*, double>> phases;
-  // when the context belongs to a pool: arbitration of the GPU between workers
-  PinBuf h_T, h_status, h_status2, h_medint;   // pinned host copies of the bin arrays (filterstatus, block tests)
-  // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
-  char* mailbox = nullptr;
-  size_t mb_cap = 0, mb_used = 0;
-  struct Pending { void* dst; const void* src; size_t bytes; };
-  std::vector<Pending> pending;   // mailbox -> destination copies to finish at the next synchronisation
-  int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
-  size_t mirror_cap = 0;
-  GpuGate* gate = nullptr;
-  int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
-  bool gate_shared = false;   // RSI_HOT_ISOLATE_STREAMING=1: bin-level kernels wait while a per-base phase runs (clean kernel timings, ~20 % less throughput)
-};
-
-namespace {
-
-#define HIPCHK(expr)                                                                          \
-  do {                                                                                        \
-    hipError_t e__ = (expr);                                                                  \
-    if (e__ != hipSuccess) {                                                                  \
-      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);                          \
-      set_global_error(ctx->err);                                                             \
-      return RSI_ERR_HIP;                                                                     \
-    }                                                                                         \
-  } while (0)
-
-// Wait for the context's stream without burning a core: poll briefly (most waits are a few
-// microseconds), then sleep on a blocking-sync event.  With one busy-spinning thread per worker a
-// 16-CPU quota is exhausted by the waits alone and the whole process gets throttled.
-hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
-  hipError_t e = hipEventRecord(ev, stream);
-  if (e != hipSuccess) return e;
-  for (int spin = 0; spin < 2000; ++spin) {
-    e = hipEventQuery(ev);
-    if (e == hipSuccess) return hipSuccess;
-    if (e != hipErrorNotReady) return e;
-  }
-  return hipEventSynchronize(ev);
-}
-
-// Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
-// runtime and blocks the calling thread; with a dozen workers issuing some fifty small copies per
-// chromosome that serialises them.  From / to pinned memory the copy is a plain asynchronous DMA:
-//  * host -> device: the bytes are parked in the mailbox first, so the caller's buffer is free at once;
-//  * device -> host: the bytes land in the mailbox and are moved to their destination by the next
-//    ctx_sync() -- exactly when the caller may look at them anyway.
-// Slots live until the end of the run (bump allocation); large transfers take the direct path.
-constexpr size_t kMailboxBytes = size_t(8) << 20, kMailboxMaxCopy = size_t(512) << 10;
-void* mb_alloc(rsi_ctx* ctx, size_t bytes) {
-  if (!ctx->mailbox) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), kMailboxBytes, hipHostMallocDefault) != hipSuccess) { ctx->mailbox = nullptr; return nullptr; }
-    ctx->mb_cap = kMailboxBytes;
-  }
-  const size_t need = (bytes + 63) & ~size_t(63);
-  if (ctx->mb_used + need > ctx->mb_cap) return nullptr;
-  void* p = ctx->mailbox + ctx->mb_used;
-  ctx->mb_used += need;
-  return p;
-}
-hipError_t copy_d2h(rsi_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
-  if (bytes == 0) return hipSuccess;
-  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
-  if (!slot) return hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
-  ctx->pending.push_back({dst, slot, bytes});
-  return hipMemcpyAsync(slot, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
-}
-hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
-  if (bytes == 0) return hipSuccess;
-  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
-  if (!slot) return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-  memcpy(slot, src, bytes);
-  return hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
-}
-hipError_t ctx_sync(rsi_ctx* ctx) {
-  const hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
-  if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
-  ctx->pending.clear();
-  return e;
-}
-void mailbox_reset(rsi_ctx* ctx) { ctx->mb_used = 0; ctx->pending.clear(); }
-#define CTX_SYNC() ctx_sync(ctx)
-
-int fail(rsi_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
-  set_global_error(msg);
-  return code;
-}
-
-// offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
-constexpr size_t kOffGcAcc = 0;                                   // GcAccum
-constexpr size_t kOffValAux = 4096;                               // ValueHistAux
-constexpr size_t kOffMinMax = 4608;                               // MinMaxF
-constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
-constexpr size_t kOffRawMin = 5120;                               // uint32
-constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
-constexpr size_t kHeaderBytes = 5376;                             // everything above: zeroed at the start of a run, fetched in one copy
-constexpr uint32_t kMaxTransitions = 1u << 16;
-constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:
-                                                                  // the header and the first entries travel as one transfer
-constexpr size_t kOffTable = kOffNtrans + (size_t)kMaxTransitions * 8;   // double[202]
-constexpr size_t kOffGrid = kOffTable + 1792;                     // GridMedian[2]: the two links of a median -> MAD chain
-constexpr size_t kOffScanPass = kOffGrid + 1024;                  // 2 x ScanPassWork (one per rsistatus pass)
-constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
-constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4100], cum[4097]
-constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
-constexpr int kMaxRegions = 4096;
-constexpr uint32_t kMaxRunEntries = 1u << 20;
-constexpr int kMaxL = 2048;
-
-struct Timer {   // optional HIP-event bracket around one launch
-  rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
-  Timer(rsi_ctx* c, const char* nm, bool per_base = false) : ctx(c), name(nm) {
-    if (!ctx->timing || (ctx->timing == 2 && !per_base)) return;
-    auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
-    a = get(); b = get();
-    (void)hipEventRecord(a, ctx->stream);
-  }
-  ~Timer() { if (a) { (void)hipEventRecord(b, ctx->stream); ctx->ktimes.push_back({name, a, b}); } }
-};
-
-// Device-built integer histogram -> rsih::Quantiles
-bool int_quantiles(const std::vector<uint64_t>& h, uint64_t total, rsih::Quantiles& q) {
-  return rsih::hist_quantiles_int(h.data(), h.size(), total, q);
-}
-
-struct GateShared {   // RAII: a bin-level GPU section of a pooled context (only when the pool isolates streaming)
-  GpuGate* g;
-  explicit GateShared(rsi_ctx* ctx) : g(ctx->gate_shared ? ctx->gate : nullptr) { if (g) g->lock_shared(); }
-  void release() { if (g) { g->unlock_shared(); g = nullptr; } }
-  ~GateShared() { release(); }
-};
-
-struct Phase {   // wall-clock bracket of one pipeline phase (host view)
-  rsi_ctx* ctx; const char* name; double t0; bool open = true;
-  Phase(rsi_ctx* c, const char* nm) : ctx(c), name(nm), t0(now_ms()) {}
-  void stop() {
-    if (!open) return;
-    open = false;
-    const double dt = now_ms() - t0;
-    for (auto& p : ctx->phases) if (p.first == name) { p.second += dt; return; }
-    ctx->phases.push_back({name, dt});
-  }
-  ~Phase() { stop(); }
-};
 
 struct ScanPassOut { uint32_t escapes, inexact, ldel, ldup; };   // what one rsistatus pass leaves in `small`
 
@@ -1250,404 +970,6 @@ int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, c
 }
 
 
-namespace {
-
-// The sequential parse loop (the reference's rules in the reference's order), used when the device
-// cannot prove that positions are strictly increasing.
-void parse_depth_text_host(const char* p, size_t sz, int64_t size, std::vector<int32_t>& rd, rsi_text_stats* st) {
-  const char* end = p + sz;
-  auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
-  auto parse_int = [&](const char*& q, const char* e, long long& v) {
-    while (q < e && blank(*q)) ++q;
-    bool neg = false;
-    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
-    if (q >= e || *q < '0' || *q > '9') { v = 0; return false; }
-    long long x = 0;
-    while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; }
-    v = neg ? -x : x;
-    return true;
-  };
-  const char* q = p;
-  while (q < end) {
-    const char* eol = (const char*)memchr(q, '\n', (size_t)(end - q));
-    if (!eol) eol = end;
-    if (eol > q && *q != '#') {
-      const char* c = q;
-      long long pos = 0, d = 0;
-      if (parse_int(c, eol, pos)) {
-        parse_int(c, eol, d);
-        if (pos >= 1) {
-          ++st->lines;
-          if (pos >= size) { ++st->beyond; break; }       // loaddata.cpp:514
-          rd[(size_t)pos - 1] = (int32_t)d;
-          ++st->stored;
-        }
-      }
-    }
-    q = eol + 1;
-  }
-}
-
-constexpr size_t kTextChunk = size_t(64) << 20;   // bytes of text per transfer + kernel
-
-}  // namespace
-
-int rsi_hot_load_depth_text(rsi_ctx* ctx, const char* path, int64_t n, rsi_text_stats* stats) {
-  rsi_text_stats local;
-  rsi_text_stats* st = stats ? stats : &local;
-  memset(st, 0, sizeof(*st));
-  if (!ctx || !path) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
-  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
-  const double t0 = now_ms();
-  HIPCHK(hipSetDevice(ctx->device));
-  const int fd = open(path, O_RDONLY);
-  if (fd < 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("Cannot open file ") + path);
-  struct FdGuard { int fd; ~FdGuard() { close(fd); } } guard{fd};
-  struct stat sb;
-  if (fstat(fd, &sb) != 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("Cannot stat file ") + path);
-  st->bytes = (int64_t)sb.st_size;
-  mailbox_reset(ctx);
-  HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
-  HIPCHK(hipMemsetAsync(ctx->in_depth.p, 0, (size_t)n * 4, ctx->stream));
-  ctx->n_in = n;
-  if (ctx->text_pin_cap < kTextChunk) {
-    for (int b = 0; b < 2; ++b) {
-      if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
-      ctx->text_pin[b] = nullptr;
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->text_pin[b]), kTextChunk, hipHostMallocDefault) != hipSuccess)
-        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the text staging");
-    }
-    ctx->text_pin_cap = kTextChunk;
-  }
-  const int max_wg = text_parse_workgroups((long long)kTextChunk);
-  HIPCHK(ctx->text_dev[0].ensure(kTextChunk));
-  HIPCHK(ctx->text_dev[1].ensure(kTextChunk));
-  HIPCHK(ctx->text_wg.ensure((size_t)max_wg * 16 * 2 + 256));   // (first, max) per workgroup, two chunks in flight, + stats
-  uint8_t* wgbase = ctx->text_wg.as<uint8_t>();
-  TextParseStats* d_stats = reinterpret_cast<TextParseStats*>(wgbase + (size_t)max_wg * 32);
-  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(TextParseStats), ctx->stream));
-  std::vector<long long> wg_host[2];
-  wg_host[0].resize((size_t)max_wg * 2); wg_host[1].resize((size_t)max_wg * 2);
-
-  // Double buffering: while the device parses chunk k the host reads chunk k+1 from the file.  A chunk ends on
-  // a line end; the partial last line is carried to the front of the next chunk.
-  size_t carry = 0;            // bytes of an unfinished line already at the front of the buffer being filled
-  bool eof = false, unsorted = false;
-  long long run_max = -1;      // largest position seen in the chunks checked so far
-  int inflight_wgs[2] = {0, 0};
-  hipEvent_t done[2] = {nullptr, nullptr};
-  for (int b = 0; b < 2; ++b) if (hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) return fail(ctx, RSI_ERR_HIP, "hipEventCreate failed");
-  struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } evguard{done};
-  auto check_chunk = [&](int b) {   // cross-workgroup order of a finished chunk
-    const long long* f = wg_host[b].data();
-    const long long* m = f + inflight_wgs[b];
-    for (int w = 0; w < inflight_wgs[b]; ++w) {
-      if (f[w] < 0) continue;
-      if (run_max >= 0 && f[w] <= run_max) unsorted = true;
-      run_max = m[w] > run_max ? m[w] : run_max;
-    }
-    inflight_wgs[b] = 0;
-  };
-  int cur = 0;
-  bool used[2] = {false, false};
-  while (!eof) {
-    char* buf = ctx->text_pin[cur];   // free: its previous chunk was waited for before `carry` was parked in it
-    size_t have = carry;
-    while (have < kTextChunk) {
-      const ssize_t got = read(fd, buf + have, kTextChunk - have);
-      if (got < 0) return fail(ctx, RSI_ERR_INTERNAL, std::string("read error on ") + path);
-      if (got == 0) { eof = true; break; }
-      have += (size_t)got;
-    }
-    size_t len = have;
-    if (!eof) {   // cut at the last line end
-      while (len > 0 && buf[len - 1] != '\n') --len;
-      if (len == 0) return fail(ctx, RSI_ERR_UNSUPPORTED, "a line of the depth file is longer than 64 MB");
-    }
-    if (len > 0) {
-      const int nwg = text_parse_workgroups((long long)len);
-      long long* d_first = reinterpret_cast<long long*>(wgbase + (size_t)cur * max_wg * 16);
-      long long* d_max = d_first + nwg;
-      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf, len, hipMemcpyHostToDevice, ctx->stream));
-      { Timer t(ctx, "parse_depth_text"); launch_parse_depth_text(ctx->text_dev[cur].p, (long long)len, (long long)n, ctx->in_depth.as<int32_t>(), d_first, d_max, d_stats, ctx->stream); }
-      HIPCHK(hipMemcpyAsync(wg_host[cur].data(), d_first, (size_t)nwg * 16, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipEventRecord(done[cur], ctx->stream));
-      inflight_wgs[cur] = nwg;
-      used[cur] = true;
-    }
-    // the other buffer's chunk (the older one) has to be through before the unfinished line is parked in it
-    // and the next read fills it; the chunk just launched keeps the device busy meanwhile
-    const int other = cur ^ 1;
-    if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); check_chunk(other); used[other] = false; }
-    carry = have - len;
-    if (carry) memcpy(ctx->text_pin[other], buf + len, carry);
-    cur = other;
-  }
-  for (int b = 0; b < 2; ++b) if (used[b] && inflight_wgs[b]) { HIPCHK(hipEventSynchronize(done[b])); check_chunk(b); }
-  TextParseStats hs;
-  HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  st->lines = (int64_t)hs.lines; st->stored = (int64_t)hs.stored; st->beyond = (int64_t)hs.beyond;
-  if (hs.unsorted || unsorted) {
-    // order-dependent rules in play: redo the file with the sequential loop
-    st->fallback = 1; st->lines = st->stored = st->beyond = 0;
-    std::vector<int32_t> rd((size_t)n, 0);
-    std::vector<char> all((size_t)st->bytes);
-    if (lseek(fd, 0, SEEK_SET) != 0) return fail(ctx, RSI_ERR_INTERNAL, "seek error");
-    size_t have = 0;
-    while (have < all.size()) { const ssize_t got = read(fd, all.data() + have, all.size() - have); if (got <= 0) break; have += (size_t)got; }
-    parse_depth_text_host(all.data(), have, n, rd, st);
-    HIPCHK(hipMemcpyAsync(ctx->in_depth.p, rd.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
-  st->t_total_ms = now_ms() - t0;
-  if (ctx->timing) { double tot = 0; for (const KernelTime& k : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, k.a, k.b); tot += ms; } st->t_parse_kernel_ms = tot; }
-  return RSI_OK;
-}
-
-int rsi_hot_run_text(rsi_ctx* ctx, const rsi_params* p, const char* depth_path, const uint8_t* fasta, int64_t n, rsi_result** out,
-                     rsi_text_stats* stats) {
-  if (!ctx || !p || !depth_path || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
-  ctx->ktimes.clear(); ctx->event_next = 0;
-  int rc = rsi_hot_load_depth_text(ctx, depth_path, n, stats);
-  if (rc != RSI_OK) return rc;
-  HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
-  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
-}
-
-
-int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats) {
-  rsi_bam_stats local;
-  rsi_bam_stats* st = stats ? stats : &local;
-  memset(st, 0, sizeof(*st));
-  if (!ctx || !bam_path || !chrom) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
-  const double t0 = now_ms();
-  HIPCHK(hipSetDevice(ctx->device));
-  std::string err;
-  rsih::BamFile bam;
-  if (!bam.open(bam_path, err)) return fail(ctx, RSI_ERR_BAD_ARG, err);
-  std::vector<std::pair<std::string, int64_t>> refs;
-  uint64_t voff = 0;
-  if (!bam.read_header(refs, voff, err)) return fail(ctx, RSI_ERR_BAD_ARG, err);
-  int tid = -1;
-  for (size_t r = 0; r < refs.size(); ++r) if (refs[r].first == chrom) tid = (int)r;
-  if (tid < 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("chromosome not in the BAM header: ") + chrom);
-  const int64_t n = refs[(size_t)tid].second;
-  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
-  st->tid = tid; st->n = n;
-  uint64_t idx_off = 0;
-  if (rsih::bai_first_offset(std::string(bam_path) + ".bai", tid, idx_off)) { voff = idx_off; st->indexed = 1; }
-
-  mailbox_reset(ctx);
-  HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
-  int32_t* d_diff = ctx->in_depth.as<int32_t>();     // difference array first, scanned in place into the depth
-  HIPCHK(hipMemsetAsync(d_diff, 0, (size_t)(n + 1) * 4, ctx->stream));
-  ctx->n_in = n;
-  if (ctx->text_pin_cap < kTextChunk) {
-    for (int b = 0; b < 2; ++b) {
-      if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
-      ctx->text_pin[b] = nullptr;
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->text_pin[b]), kTextChunk, hipHostMallocDefault) != hipSuccess)
-        return fail(ctx, RSI_ERR_INTERNAL, "out of pinned host memory for the BAM staging");
-    }
-    ctx->text_pin_cap = kTextChunk;
-  }
-  HIPCHK(ctx->text_dev[0].ensure(kTextChunk));
-  HIPCHK(ctx->text_dev[1].ensure(kTextChunk));
-  constexpr size_t kMaxRec = kTextChunk / 36 + 16;   // a record is at least 36 bytes
-  const size_t stats_off = 2 * kMaxRec * 4, scan_off = stats_off + 256;
-  HIPCHK(ctx->text_wg.ensure(scan_off + (size_t)scan_tiles(n) * 4 + 64));
-  uint8_t* wsb = ctx->text_wg.as<uint8_t>();
-  BamDepthStats* d_stats = reinterpret_cast<BamDepthStats*>(wsb + stats_off);
-  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(BamDepthStats), ctx->stream));
-
-  hipEvent_t done[2] = {nullptr, nullptr};
-  for (int b = 0; b < 2; ++b) if (hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) return fail(ctx, RSI_ERR_HIP, "hipEventCreate failed");
-  struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } evguard{done};
-  bool used[2] = {false, false};
-  std::vector<uint32_t> rec_off[2];
-  rec_off[0].reserve(kMaxRec / 8); rec_off[1].reserve(kMaxRec / 8);
-  const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-
-  // Pipeline over chunks of inflated bytes: while the host walks the records of chunk k and hands them to the device,
-  // the inflate threads already fill the other buffer with chunk k+1.  The inflated data of a chunk starts at kReserve,
-  // so that the unfinished record at the end of chunk k can be parked right in front of chunk k+1 without waiting.
-  constexpr size_t kReserve = size_t(8) << 20;
-  struct Chunk {
-    std::vector<rsih::BgzfBlock> blocks;
-    std::vector<size_t> at;
-    // speculative record walk of each block, done by the thread that inflated it, as if the block began on a record
-    // boundary (htslib and samtools flush before a record that would not fit, so normally it does): offsets of the
-    // records of `tid` that lie wholly inside the block, how many records were seen, where the walk stopped, and
-    // whether it met a read beyond `tid` (the end of the chromosome in a sorted file)
-    struct BlockWalk { std::vector<uint32_t> offs; uint32_t seen = 0; size_t stop = 0; bool beyond = false, bad = false; };
-    std::vector<BlockWalk> walks;
-    size_t end = kReserve;     // end of the inflated data in the buffer
-    bool eof = false, failed = false;
-    std::string err;
-    double t_inflate = 0;
-    std::thread worker;
-  } chunk[2];
-  uint64_t coff = voff >> 16;            // next block to inflate
-  auto prepare = [&](int b) -> bool {    // choose the blocks of the next chunk and start inflating them into buffer b
-    Chunk& c = chunk[b];
-    c.blocks.clear(); c.at.clear(); c.end = kReserve; c.eof = false; c.failed = false; c.err.clear();
-    for (;;) {
-      rsih::BgzfBlock blk;
-      std::string e2;
-      if (!bam.block_at(coff, blk, e2)) { if (!e2.empty()) { c.failed = true; c.err = e2; return false; } c.eof = true; break; }
-      if (c.end + blk.isize > kTextChunk) break;
-      c.blocks.push_back(blk); c.at.push_back(c.end);
-      c.end += blk.isize; coff += blk.csize;
-      st->bytes_compressed += blk.csize;
-    }
-    if (c.blocks.empty() && !c.eof) { c.failed = true; c.err = "a BGZF block does not fit the staging buffer"; return false; }
-    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[b]);
-    c.walks.assign(c.blocks.size(), Chunk::BlockWalk());
-    c.worker = std::thread([&c, buf, &bam, nthreads, tid]() {
-      const double ti = now_ms();
-      std::atomic<size_t> next(0);
-      std::mutex emu;
-      auto work = [&]() {
-        for (;;) {
-          const size_t k = next.fetch_add(1);
-          if (k >= c.blocks.size()) break;
-          std::string e2;
-          if (!bam.inflate(c.blocks[k], buf + c.at[k], e2)) { std::lock_guard<std::mutex> lk(emu); c.failed = true; c.err = e2; continue; }
-          Chunk::BlockWalk& w = c.walks[k];
-          size_t p = c.at[k];
-          const size_t lim = c.at[k] + c.blocks[k].isize;
-          while (p + 8 <= lim) {
-            const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
-            if (bs < 32) { w.bad = true; break; }          // not a record start after all (or a broken file): the checker decides
-            if (p + 4 + (size_t)bs > lim) break;
-            const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
-            ++w.seen;
-            if (rtid == tid) w.offs.push_back((uint32_t)(p - c.at[k]));
-            else if (rtid > tid || rtid < 0) { w.beyond = true; break; }
-            p += 4 + (size_t)bs;
-          }
-          w.stop = p;
-        }
-      };
-      std::vector<std::thread> th;
-      const unsigned nt = (unsigned)std::min<size_t>(nthreads, c.blocks.size());
-      for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-      work();
-      for (auto& t : th) t.join();
-      c.t_inflate = now_ms() - ti;
-    });
-    return true;
-  };
-  struct JoinGuard { Chunk* c; ~JoinGuard() { for (int b = 0; b < 2; ++b) if (c[b].worker.joinable()) c[b].worker.join(); } } joinguard{chunk};
-
-  size_t skip = (size_t)(voff & 0xffff); // bytes of the first block that precede the first record
-  size_t carry = 0;                      // bytes of an unfinished record parked in front of the current chunk's data
-  bool finished = false;
-  int cur = 0;
-  if (!prepare(0)) return fail(ctx, RSI_ERR_BAD_ARG, chunk[0].err);
-  while (!finished) {
-    Chunk& c = chunk[cur];
-    c.worker.join();
-    if (c.failed) return fail(ctx, RSI_ERR_BAD_ARG, c.err);
-    st->t_inflate_ms += c.t_inflate;
-    st->bytes_inflated += (int64_t)(c.end - kReserve);
-    const int other = cur ^ 1;
-    // the other buffer is free once the device has taken its previous chunk: start the next inflate right away
-    { const double tq = now_ms(); if (used[other]) { HIPCHK(hipEventSynchronize(done[other])); used[other] = false; } st->t_wait_ms += now_ms() - tq; }
-    bool more = false;
-    if (!c.eof) { if (!prepare(other)) return fail(ctx, RSI_ERR_BAD_ARG, chunk[other].err); more = true; }
-    // ---- record boundaries; the BAM is coordinate sorted, so reading ends with the first read beyond `tid` ----
-    uint8_t* buf = reinterpret_cast<uint8_t*>(ctx->text_pin[cur]);
-    const double tw = now_ms();
-    std::vector<uint32_t>& offs = rec_off[cur];
-    offs.clear();
-    const size_t start = kReserve - carry + skip;   // `skip` only applies to the very first chunk (no carry there)
-    skip = 0;
-    size_t p = start;
-    const size_t have = c.end;
-    size_t kb = 0;                       // first block that starts at or after p
-    while (p + 4 <= have && !finished) {
-      while (kb < c.blocks.size() && c.at[kb] < p) ++kb;
-      if (kb < c.blocks.size() && c.at[kb] == p && !c.walks[kb].bad) {
-        // the block does begin on a record boundary: its thread has walked it already
-        const Chunk::BlockWalk& w = c.walks[kb];
-        const uint32_t base = (uint32_t)(p - start);
-        for (uint32_t o : w.offs) offs.push_back(base + o);
-        st->records += w.seen; st->on_chrom += (int64_t)w.offs.size();
-        if (w.beyond) { finished = true; p = w.stop; break; }
-        if (w.stop == p) {               // not even one whole record in this block: walk it the plain way below
-        } else { p = w.stop; ++kb; continue; }
-      }
-      const uint32_t bs = (uint32_t)buf[p] | ((uint32_t)buf[p + 1] << 8) | ((uint32_t)buf[p + 2] << 16) | ((uint32_t)buf[p + 3] << 24);
-      if (bs < 32) return fail(ctx, RSI_ERR_BAD_ARG, "malformed BAM record");
-      if (p + 4 + bs > have) break;
-      const int32_t rtid = (int32_t)((uint32_t)buf[p + 4] | ((uint32_t)buf[p + 5] << 8) | ((uint32_t)buf[p + 6] << 16) | ((uint32_t)buf[p + 7] << 24));
-      ++st->records;
-      if (rtid == tid) { offs.push_back((uint32_t)(p - start)); ++st->on_chrom; }
-      else if (rtid > tid || rtid < 0) { finished = true; break; }
-      p += 4 + (size_t)bs;
-    }
-    if (c.eof) finished = true;
-    st->t_walk_ms += now_ms() - tw;
-    const size_t len = p;                // end of the whole records examined
-    if (!offs.empty()) {
-      uint32_t* d_off = reinterpret_cast<uint32_t*>(wsb + (size_t)cur * kMaxRec * 4);
-      HIPCHK(hipMemcpyAsync(ctx->text_dev[cur].p, buf + start, len - start, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(d_off, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-      { Timer t(ctx, "bam_depth"); launch_bam_depth(ctx->text_dev[cur].p, d_off, (int)offs.size(), tid, minq, min_baseq, (long long)n, d_diff, d_stats, ctx->stream); }
-      HIPCHK(hipEventRecord(done[cur], ctx->stream));
-      used[cur] = true;
-    }
-    carry = finished ? 0 : have - len;
-    if (carry > kReserve) return fail(ctx, RSI_ERR_UNSUPPORTED, "a BAM record is longer than 8 MB");
-    if (carry && more) memcpy(ctx->text_pin[other] + (kReserve - carry), buf + len, carry);   // in front of the data being inflated there
-    if (!more) finished = true;
-    cur = other;
-  }
-  { Timer t(ctx, "depth_scan"); launch_inclusive_scan_i32(d_diff, (long long)n, reinterpret_cast<int32_t*>(wsb + scan_off), ctx->stream); }
-  BamDepthStats hs;
-  HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-  { const double tq = now_ms(); HIPCHK(hipStreamSynchronize(ctx->stream)); st->t_wait_ms += now_ms() - tq; }
-  st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs;
-  st->t_total_ms = now_ms() - t0;
-  return RSI_OK;
-}
-
-int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs) {
-  if (!bam_path) return RSI_ERR_BAD_ARG;
-  std::string err;
-  rsih::BamFile bam;
-  std::vector<std::pair<std::string, int64_t>> refs;
-  uint64_t voff = 0;
-  if (!bam.open(bam_path, err) || !bam.read_header(refs, voff, err)) { set_global_error(err); return RSI_ERR_BAD_ARG; }
-  std::string all;
-  for (size_t r = 0; r < refs.size(); ++r) {
-    if (r) all += '\n';
-    all += refs[r].first;
-    if (lengths && (int)r < max_refs) lengths[r] = refs[r].second;
-  }
-  if (names && names_cap > 0) { strncpy(names, all.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
-  return (int)refs.size();
-}
-
-int rsi_hot_run_bam(rsi_ctx* ctx, const rsi_params* p, const char* bam_path, const char* chrom, int minq, int min_baseq,
-                    const uint8_t* fasta, int64_t n, rsi_result** out, rsi_bam_stats* stats) {
-  if (!ctx || !p || !bam_path || !chrom || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
-  rsi_bam_stats local;
-  rsi_bam_stats* st = stats ? stats : &local;
-  ctx->ktimes.clear(); ctx->event_next = 0;
-  int rc = rsi_hot_load_depth_bam(ctx, bam_path, chrom, minq, min_baseq, st);
-  if (rc != RSI_OK) return rc;
-  if (st->n != n) return fail(ctx, RSI_ERR_BAD_ARG, "reference and target not same size (loaddata.cpp:284-287)");
-  HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
-  HIPCHK(hipMemcpyAsync(ctx->in_fasta.p, fasta, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);
-}
-
 int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const uint8_t* fasta, int64_t n, rsi_result** out) {
   if (!ctx || !p || !depth || !fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
   if (n <= 0) return fail(ctx, RSI_ERR_BAD_ARG, "empty chromosome");
@@ -1778,133 +1100,6 @@ int rsi_result_annotate_bam(rsi_result* r, const char* bam_path, const char* chr
   r->rp.clear(); r->q0.clear();
   for (const rsih::CallSpan& c : spans) { r->rp.push_back(c.rp); r->q0.push_back(c.q0); }
   return RSI_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// Pool: `nworkers` host threads, each with its own context (stream + workspace) on one GPU.
-// Chromosomes are independent iterations of the reference's loop (rsi.cpp:2189-2217); the pool
-// hands them out longest first.
-struct rsi_pool {
-  int device = 0;
-  std::vector<rsi_ctx*> workers;
-  GpuGate gate;
-  std::string err;
-};
-
-rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
-  if (nworkers < 1) nworkers = 1;
-  if (nworkers > 64) nworkers = 64;
-  rsi_pool* pool = new rsi_pool();
-  pool->device = device;
-  for (int w = 0; w < nworkers; ++w) {
-    int st = 0;
-    rsi_ctx* c = rsi_hot_create(device, &st);
-    if (!c) {
-      if (status) *status = st;
-      for (rsi_ctx* x : pool->workers) rsi_hot_destroy(x);
-      delete pool;
-      return nullptr;
-    }
-    c->gate = &pool->gate;
-    if (const char* ms = getenv("RSI_HOT_STREAMERS")) pool->gate.max_streamers = std::max(1, atoi(ms));
-    const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
-    c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
-    pool->workers.push_back(c);
-  }
-  if (status) *status = RSI_OK;
-  return pool;
-}
-
-void rsi_pool_destroy(rsi_pool* pool) {
-  if (!pool) return;
-  for (rsi_ctx* c : pool->workers) rsi_hot_destroy(c);
-  delete pool;
-}
-
-int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
-rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
-void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) rsi_hot_set_timing(c, on); }
-void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
-  if (!pool) return;
-  std::lock_guard<std::mutex> lk(pool->gate.m);
-  for (rsi_ctx* c : pool->workers) c->gate_shared = isolate != 0;
-  if (streamers >= 1) pool->gate.max_streamers = streamers;
-}
-const char* rsi_pool_last_error(const rsi_pool* pool) { return pool ? pool->err.c_str() : g_last_error.c_str(); }
-
-int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
-                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
-  if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
-  std::vector<int> order((size_t)nchrom);
-  for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
-  {
-    int64_t largest = 0;
-    for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
-    for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
-  }
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
-  std::atomic<int> next(std::min<int>(nchrom, (int)pool->workers.size()));
-  std::vector<int> rcs((size_t)nchrom, RSI_OK);
-  std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
-  std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
-  std::vector<std::vector<int64_t>> kbases(pool->workers.size());
-  static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
-  const double t_run0 = now_ms();
-  std::mutex trace_mu;
-  auto work = [&](size_t w) {
-    rsi_ctx* ctx = pool->workers[w];
-    bool first = true;
-    for (;;) {
-      // the W longest chromosomes always go to the same workers (rank k -> worker k): a context then
-      // meets its biggest workload in the first batch and never has to grow its workspace again
-      int k;
-      if (first && (int)w < nchrom) { k = (int)w; first = false; }
-      else { first = false; k = next.fetch_add(1); }
-      if (k >= nchrom) break;
-      const int i = order[(size_t)k];
-      out[i] = nullptr;
-      const double t_a = now_ms();
-      rcs[(size_t)i] = rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
-      if (trace) {
-        std::lock_guard<std::mutex> lk(trace_mu);
-        fprintf(stderr, "[trace] worker %zu chrom %d n %lld start %.2f end %.2f :", w, i, (long long)n[i], t_a - t_run0, now_ms() - t_run0);
-        for (const auto& ph : ctx->phases) fprintf(stderr, " %s=%.2f", ph.first, ph.second);
-        fprintf(stderr, "\n");
-      }
-      if (times) {
-        for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); ktimes[w].push_back({t.name, ms}); kbases[w].push_back(n[i]); }
-        for (const auto& ph : ctx->phases) ptimes[w].push_back(ph);
-      }
-    }
-  };
-  std::vector<std::thread> th;
-  for (size_t w = 1; w < pool->workers.size(); ++w) th.emplace_back(work, w);
-  work(0);
-  const double t_work = now_ms() - t_run0;
-  for (auto& t : th) t.join();
-  if (trace) fprintf(stderr, "[trace] pool_run: own work done at %.2f ms, all workers joined at %.2f ms\n", t_work, now_ms() - t_run0);
-  int worst = RSI_OK;
-  for (int i = 0; i < nchrom; ++i) {
-    if (status) status[i] = rcs[(size_t)i];
-    if (rcs[(size_t)i] != RSI_OK && worst == RSI_OK) { worst = rcs[(size_t)i]; pool->err = g_last_error; }
-  }
-  if (times) {   // accumulate into the caller's table (names are static strings)
-    for (size_t w = 0; w < pool->workers.size(); ++w) {
-      for (size_t e = 0; e < ktimes[w].size(); ++e) {
-        int slot = -1;
-        for (int q = 0; q < times->nkernels; ++q) if (times->kernel_name[q] == ktimes[w][e].first) { slot = q; break; }
-        if (slot < 0 && times->nkernels < RSI_MAX_TIMED) { slot = times->nkernels++; times->kernel_name[slot] = ktimes[w][e].first; times->kernel_ms[slot] = 0; times->kernel_launches[slot] = 0; times->kernel_bases[slot] = 0; }
-        if (slot >= 0) { times->kernel_ms[slot] += ktimes[w][e].second; times->kernel_launches[slot] += 1; times->kernel_bases[slot] += kbases[w][e]; }
-      }
-      for (const auto& ph : ptimes[w]) {
-        int slot = -1;
-        for (int q = 0; q < times->nphases; ++q) if (times->phase_name[q] == ph.first) { slot = q; break; }
-        if (slot < 0 && times->nphases < RSI_MAX_TIMED) { slot = times->nphases++; times->phase_name[slot] = ph.first; times->phase_ms[slot] = 0; }
-        if (slot >= 0) times->phase_ms[slot] += ph.second;
-      }
-    }
-  }
-  return worst;
 }
 
 }  // extern "C"

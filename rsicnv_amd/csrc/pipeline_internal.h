@@ -1,0 +1,303 @@
+// pipeline_internal.h -- what the translation units behind include/rsi_hot.h share: the context (device workspace,
+// stream, pinned mailbox), the pool's gate, the small-transfer and timing helpers, the layout of the `small` buffer.
+// pipeline.hip: one chromosome through the path; ingest.hip: depth from text / BAM; pool.hip: several chromosomes at once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include "../../include/rsi_hot.h"
+#include "bam_host.h"
+#include "host_calls.h"
+#include "hostmath.h"
+#include "kernels.h"
+
+using namespace rsik;
+using rsih::Candidate;
+using rsih::Region;
+
+
+namespace rsip {
+
+
+inline std::string g_last_error;   // last failure of any context (diagnostic; guarded by g_err_mu)
+inline std::mutex g_err_mu;
+inline void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_last_error = m; }
+
+// Growth hint of the running thread: (largest chromosome its pool has been handed) / (this one).
+// A buffer that has to grow is sized for the largest chromosome right away, so that after a
+// worker's first chromosome no hipFree/hipMalloc -- a device-wide synchronisation that stalls every
+// other worker, and slow on recycled VRAM -- happens in steady state.
+inline thread_local double tl_grow = 1.0;
+inline thread_local double tl_grow_ms = 0.0;   // time this thread spent re-allocating during the current run
+
+struct DevBuf {   // grow-only device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool regrow = p != nullptr;   // a buffer whose size depends on the data turned out too small: be generous this time
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t scaled = (size_t)((double)bytes * tl_grow);
+    const size_t want = (regrow ? 2 * scaled : scaled + scaled / 8) + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    tl_grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct PinBuf {   // grow-only pinned host allocation: destination of the large device -> host copies.  From pageable memory
+                  // the runtime stages such a copy synchronously under its own lock, which stalls every other worker's
+                  // HIP calls for milliseconds per copy.
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t scaled = (size_t)((double)bytes * tl_grow);
+    const size_t want = scaled + scaled / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct KernelTime { const char* name; hipEvent_t a, b; };
+
+// One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
+// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
+// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
+// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
+// a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
+// sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
+struct GpuGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int sharers = 0, streamers_waiting = 0, streaming = 0;
+  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
+  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
+  void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
+  void lock(bool exclude_sharers) {
+    std::unique_lock<std::mutex> lk(m);
+    ++streamers_waiting;
+    cv.wait(lk, [&] { return exclude_sharers ? (streaming == 0 && sharers == 0) : streaming < max_streamers; });
+    --streamers_waiting;
+    ++streaming;
+  }
+  void unlock() { { std::lock_guard<std::mutex> lk(m); --streaming; } cv.notify_all(); }
+};
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+
+}  // namespace rsip
+
+using rsip::DevBuf;
+using rsip::PinBuf;
+using rsip::KernelTime;
+using rsip::GpuGate;
+
+struct rsi_result {
+  std::vector<rsi_call> lists[4];
+  std::vector<int32_t> noncode;   // pairs
+  std::vector<int32_t> rp;        // per final call, after rsi_result_annotate_bam
+  std::vector<double> q0;
+  rsi_chrom_stats stats;
+  rsi_params params;
+};
+
+struct rsi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
+  std::string err;
+  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base (HBM-bound) kernels only
+  std::vector<KernelTime> ktimes;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+  // workspace
+  DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
+  DevBuf text_dev[2], text_wg;               // depth text ingestion: two chunks of file bytes in HBM, per-workgroup order records
+  char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
+  size_t text_pin_cap = 0;
+  int64_t n_in = 0;                          // length of the depth currently in in_depth
+  DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
+  DevBuf slabs;   // per-workgroup partial results of the streaming kernels
+  DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
+  DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64;   // candidate tests on the device (kernels_cand.hip)
+  // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
+  int64_t n = 0, ncompact = 0, nb = 0;
+  bool have_gc = false, have_nb = false, have_med = false;
+  int last_scan_med = 0;
+  // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
+  std::vector<std::pair<const char*, double>> phases;
+  // when the context belongs to a pool: arbitration of the GPU between workers
+  PinBuf h_T, h_status, h_status2, h_medint;   // pinned host copies of the bin arrays (filterstatus, block tests)
+  // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
+  char* mailbox = nullptr;
+  size_t mb_cap = 0, mb_used = 0;
+  struct Pending { void* dst; const void* src; size_t bytes; };
+  std::vector<Pending> pending;   // mailbox -> destination copies to finish at the next synchronisation
+  int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
+  size_t mirror_cap = 0;
+  GpuGate* gate = nullptr;
+  int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
+  bool gate_shared = false;   // RSI_HOT_ISOLATE_STREAMING=1: bin-level kernels wait while a per-base phase runs (clean kernel timings, ~20 % less throughput)
+};
+
+namespace rsip {
+
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);                          \
+      set_global_error(ctx->err);                                                             \
+      return RSI_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+// Wait for the context's stream without burning a core: poll briefly (most waits are a few
+// microseconds), then sleep on a blocking-sync event.  With one busy-spinning thread per worker a
+// 16-CPU quota is exhausted by the waits alone and the whole process gets throttled.
+inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
+  hipError_t e = hipEventRecord(ev, stream);
+  if (e != hipSuccess) return e;
+  for (int spin = 0; spin < 2000; ++spin) {
+    e = hipEventQuery(ev);
+    if (e == hipSuccess) return hipSuccess;
+    if (e != hipErrorNotReady) return e;
+  }
+  return hipEventSynchronize(ev);
+}
+
+// Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
+// runtime and blocks the calling thread; with a dozen workers issuing some fifty small copies per
+// chromosome that serialises them.  From / to pinned memory the copy is a plain asynchronous DMA:
+//  * host -> device: the bytes are parked in the mailbox first, so the caller's buffer is free at once;
+//  * device -> host: the bytes land in the mailbox and are moved to their destination by the next
+//    ctx_sync() -- exactly when the caller may look at them anyway.
+// Slots live until the end of the run (bump allocation); large transfers take the direct path.
+constexpr size_t kMailboxBytes = size_t(8) << 20, kMailboxMaxCopy = size_t(512) << 10;
+inline void* mb_alloc(rsi_ctx* ctx, size_t bytes) {
+  if (!ctx->mailbox) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), kMailboxBytes, hipHostMallocDefault) != hipSuccess) { ctx->mailbox = nullptr; return nullptr; }
+    ctx->mb_cap = kMailboxBytes;
+  }
+  const size_t need = (bytes + 63) & ~size_t(63);
+  if (ctx->mb_used + need > ctx->mb_cap) return nullptr;
+  void* p = ctx->mailbox + ctx->mb_used;
+  ctx->mb_used += need;
+  return p;
+}
+inline hipError_t copy_d2h(rsi_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
+  if (!slot) return hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  ctx->pending.push_back({dst, slot, bytes});
+  return hipMemcpyAsync(slot, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+inline hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  void* slot = bytes <= kMailboxMaxCopy ? mb_alloc(ctx, bytes) : nullptr;
+  if (!slot) return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  memcpy(slot, src, bytes);
+  return hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+inline hipError_t ctx_sync(rsi_ctx* ctx) {
+  const hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
+  if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
+  ctx->pending.clear();
+  return e;
+}
+inline void mailbox_reset(rsi_ctx* ctx) { ctx->mb_used = 0; ctx->pending.clear(); }
+#define CTX_SYNC() ctx_sync(ctx)
+
+inline int fail(rsi_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  set_global_error(msg);
+  return code;
+}
+
+// offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
+constexpr size_t kOffGcAcc = 0;                                   // GcAccum
+constexpr size_t kOffValAux = 4096;                               // ValueHistAux
+constexpr size_t kOffMinMax = 4608;                               // MinMaxF
+constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
+constexpr size_t kOffRawMin = 5120;                               // uint32
+constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
+constexpr size_t kHeaderBytes = 5376;                             // everything above: zeroed at the start of a run, fetched in one copy
+constexpr uint32_t kMaxTransitions = 1u << 16;
+constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:
+                                                                  // the header and the first entries travel as one transfer
+constexpr size_t kOffTable = kOffNtrans + (size_t)kMaxTransitions * 8;   // double[202]
+constexpr size_t kOffGrid = kOffTable + 1792;                     // GridMedian[2]: the two links of a median -> MAD chain
+constexpr size_t kOffScanPass = kOffGrid + 1024;                  // 2 x ScanPassWork (one per rsistatus pass)
+constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
+constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4100], cum[4097]
+constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
+constexpr int kMaxRegions = 4096;
+constexpr uint32_t kMaxRunEntries = 1u << 20;
+constexpr int kMaxL = 2048;
+
+struct Timer {   // optional HIP-event bracket around one launch
+  rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  Timer(rsi_ctx* c, const char* nm, bool per_base = false) : ctx(c), name(nm) {
+    if (!ctx->timing || (ctx->timing == 2 && !per_base)) return;
+    auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~Timer() { if (a) { (void)hipEventRecord(b, ctx->stream); ctx->ktimes.push_back({name, a, b}); } }
+};
+
+// Device-built integer histogram -> rsih::Quantiles
+inline bool int_quantiles(const std::vector<uint64_t>& h, uint64_t total, rsih::Quantiles& q) {
+  return rsih::hist_quantiles_int(h.data(), h.size(), total, q);
+}
+
+struct GateShared {   // RAII: a bin-level GPU section of a pooled context (only when the pool isolates streaming)
+  GpuGate* g;
+  explicit GateShared(rsi_ctx* ctx) : g(ctx->gate_shared ? ctx->gate : nullptr) { if (g) g->lock_shared(); }
+  void release() { if (g) { g->unlock_shared(); g = nullptr; } }
+  ~GateShared() { release(); }
+};
+
+struct Phase {   // wall-clock bracket of one pipeline phase (host view)
+  rsi_ctx* ctx; const char* name; double t0; bool open = true;
+  Phase(rsi_ctx* c, const char* nm) : ctx(c), name(nm), t0(now_ms()) {}
+  void stop() {
+    if (!open) return;
+    open = false;
+    const double dt = now_ms() - t0;
+    for (auto& p : ctx->phases) if (p.first == name) { p.second += dt; return; }
+    ctx->phases.push_back({name, dt});
+  }
+  ~Phase() { stop(); }
+};
+
+}  // namespace rsip

@@ -1,0 +1,138 @@
+// pool.hip -- several chromosomes at once on one GPU (the reference's loop over chromosomes, rsi.cpp:2189-2217, whose
+// iterations are independent): `nworkers` host threads, each with its own context (stream + workspace), and the gate
+// that lets at most two per-base phases stream at a time.
+#include "pipeline_internal.h"
+
+using namespace rsik;
+using namespace rsip;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------
+// Pool: `nworkers` host threads, each with its own context (stream + workspace) on one GPU.
+// Chromosomes are independent iterations of the reference's loop (rsi.cpp:2189-2217); the pool
+// hands them out longest first.
+struct rsi_pool {
+  int device = 0;
+  std::vector<rsi_ctx*> workers;
+  GpuGate gate;
+  std::string err;
+};
+
+rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
+  if (nworkers < 1) nworkers = 1;
+  if (nworkers > 64) nworkers = 64;
+  rsi_pool* pool = new rsi_pool();
+  pool->device = device;
+  for (int w = 0; w < nworkers; ++w) {
+    int st = 0;
+    rsi_ctx* c = rsi_hot_create(device, &st);
+    if (!c) {
+      if (status) *status = st;
+      for (rsi_ctx* x : pool->workers) rsi_hot_destroy(x);
+      delete pool;
+      return nullptr;
+    }
+    c->gate = &pool->gate;
+    if (const char* ms = getenv("RSI_HOT_STREAMERS")) pool->gate.max_streamers = std::max(1, atoi(ms));
+    const char* iso = getenv("RSI_HOT_ISOLATE_STREAMING");
+    c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
+    pool->workers.push_back(c);
+  }
+  if (status) *status = RSI_OK;
+  return pool;
+}
+
+void rsi_pool_destroy(rsi_pool* pool) {
+  if (!pool) return;
+  for (rsi_ctx* c : pool->workers) rsi_hot_destroy(c);
+  delete pool;
+}
+
+int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
+rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
+void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) rsi_hot_set_timing(c, on); }
+void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
+  if (!pool) return;
+  std::lock_guard<std::mutex> lk(pool->gate.m);
+  for (rsi_ctx* c : pool->workers) c->gate_shared = isolate != 0;
+  if (streamers >= 1) pool->gate.max_streamers = streamers;
+}
+const char* rsi_pool_last_error(const rsi_pool* pool) { return pool ? pool->err.c_str() : g_last_error.c_str(); }
+
+int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+  if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
+  std::vector<int> order((size_t)nchrom);
+  for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
+  {
+    int64_t largest = 0;
+    for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
+    for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
+  std::atomic<int> next(std::min<int>(nchrom, (int)pool->workers.size()));
+  std::vector<int> rcs((size_t)nchrom, RSI_OK);
+  std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
+  std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
+  std::vector<std::vector<int64_t>> kbases(pool->workers.size());
+  static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
+  const double t_run0 = now_ms();
+  std::mutex trace_mu;
+  auto work = [&](size_t w) {
+    rsi_ctx* ctx = pool->workers[w];
+    bool first = true;
+    for (;;) {
+      // the W longest chromosomes always go to the same workers (rank k -> worker k): a context then
+      // meets its biggest workload in the first batch and never has to grow its workspace again
+      int k;
+      if (first && (int)w < nchrom) { k = (int)w; first = false; }
+      else { first = false; k = next.fetch_add(1); }
+      if (k >= nchrom) break;
+      const int i = order[(size_t)k];
+      out[i] = nullptr;
+      const double t_a = now_ms();
+      rcs[(size_t)i] = rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
+      if (trace) {
+        std::lock_guard<std::mutex> lk(trace_mu);
+        fprintf(stderr, "[trace] worker %zu chrom %d n %lld start %.2f end %.2f :", w, i, (long long)n[i], t_a - t_run0, now_ms() - t_run0);
+        for (const auto& ph : ctx->phases) fprintf(stderr, " %s=%.2f", ph.first, ph.second);
+        fprintf(stderr, "\n");
+      }
+      if (times) {
+        for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); ktimes[w].push_back({t.name, ms}); kbases[w].push_back(n[i]); }
+        for (const auto& ph : ctx->phases) ptimes[w].push_back(ph);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 1; w < pool->workers.size(); ++w) th.emplace_back(work, w);
+  work(0);
+  const double t_work = now_ms() - t_run0;
+  for (auto& t : th) t.join();
+  if (trace) fprintf(stderr, "[trace] pool_run: own work done at %.2f ms, all workers joined at %.2f ms\n", t_work, now_ms() - t_run0);
+  int worst = RSI_OK;
+  for (int i = 0; i < nchrom; ++i) {
+    if (status) status[i] = rcs[(size_t)i];
+    if (rcs[(size_t)i] != RSI_OK && worst == RSI_OK) { worst = rcs[(size_t)i]; pool->err = g_last_error; }
+  }
+  if (times) {   // accumulate into the caller's table (names are static strings)
+    for (size_t w = 0; w < pool->workers.size(); ++w) {
+      for (size_t e = 0; e < ktimes[w].size(); ++e) {
+        int slot = -1;
+        for (int q = 0; q < times->nkernels; ++q) if (times->kernel_name[q] == ktimes[w][e].first) { slot = q; break; }
+        if (slot < 0 && times->nkernels < RSI_MAX_TIMED) { slot = times->nkernels++; times->kernel_name[slot] = ktimes[w][e].first; times->kernel_ms[slot] = 0; times->kernel_launches[slot] = 0; times->kernel_bases[slot] = 0; }
+        if (slot >= 0) { times->kernel_ms[slot] += ktimes[w][e].second; times->kernel_launches[slot] += 1; times->kernel_bases[slot] += kbases[w][e]; }
+      }
+      for (const auto& ph : ptimes[w]) {
+        int slot = -1;
+        for (int q = 0; q < times->nphases; ++q) if (times->phase_name[q] == ph.first) { slot = q; break; }
+        if (slot < 0 && times->nphases < RSI_MAX_TIMED) { slot = times->nphases++; times->phase_name[slot] = ph.first; times->phase_ms[slot] = 0; }
+        if (slot >= 0) times->phase_ms[slot] += ph.second;
+      }
+    }
+  }
+  return worst;
+}
+
+}  // extern "C"
