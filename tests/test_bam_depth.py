@@ -176,3 +176,42 @@ def test_records_straddling_bgzf_blocks(hotlib, tmp_path, block):
         assert np.array_equal(h.fetch("depth_in"), g[f"{chrom}_q0_Q13"]), (chrom, block)
         assert st["on_chrom"] == sum(1 for r in recs if int.from_bytes(r[4:8], "little", signed=True) == t)
     h.close()
+
+
+@pytest.mark.gpu
+def test_ingest_error_paths(hotlib, tmp_path):
+    """Loaders fail loudly and leave the context usable: missing files, a chromosome the BAM does not have, a file that is
+    not BGZF, a BAM cut off in the middle of a block, a chromosome without reads."""
+    from rsicnv_amd import api
+    bam, refs, recs = bu.build_golden_bam(str(tmp_path))
+    chrom, n = refs[0]
+    h = api.RsiHot(0)
+    with pytest.raises(api.RsiError):
+        h.load_depth_bam(str(tmp_path / "nothing.bam"), chrom)
+    with pytest.raises(api.RsiError):
+        h.load_depth_bam(bam, "chrNotThere")
+    junk = tmp_path / "junk.bam"
+    junk.write_bytes(b"this is not a BGZF file at all\n" * 100)
+    with pytest.raises(api.RsiError):
+        h.load_depth_bam(str(junk), chrom)
+    cut = tmp_path / "cut.bam"
+    raw = open(bam, "rb").read()
+    cut.write_bytes(raw[: len(raw) * 2 // 3])
+    with pytest.raises(api.RsiError):
+        h.load_depth_bam(str(cut), refs[-1][0])
+    with pytest.raises(api.RsiError):
+        h.load_depth_text(str(tmp_path / "nothing.txt"), 1000)
+    # a chromosome of the header that no read maps to: all-zero depth, not an error
+    empty = str(tmp_path / "empty.bam")
+    import struct
+    bu.write_bam(empty, refs, [r for r in recs if struct.unpack("<i", r[4:8])[0] != len(refs) - 1])
+    st = h.load_depth_bam(empty, refs[-1][0])
+    assert st["n"] == refs[-1][1] and st["used"] == 0
+    assert not h.fetch("depth_in").any()
+    # and the context still works
+    st = h.load_depth_bam(bam, chrom)
+    g = np.load(GOLDEN)
+    q, Q = 0, 13
+    if f"{chrom}_q{q}_Q{Q}" in g:
+        assert np.array_equal(h.fetch("depth_in"), g[f"{chrom}_q{q}_Q{Q}"])
+    h.close()
