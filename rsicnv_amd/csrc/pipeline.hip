@@ -529,23 +529,21 @@ void to_call(const Candidate& c, rsi_call* o) {
   o->refmed = c.refmed; o->refsd = c.refsd; o->refiqr = c.refiqr;
 }
 
-int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n,
-                    rsi_result* res) {
-  const rsi_params& P = *Pp;
-  const double t_begin = now_ms();
-  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
-  if (P.m < 1 || (P.m % 2) != 1) return fail(ctx, RSI_ERR_BAD_ARG, "m must be odd (the reference forces it, rsi.cpp:2061-2064)");
-  if (P.m > 3000) return fail(ctx, RSI_ERR_UNSUPPORTED, "bin size above 3000 is not supported by the bin kernel");
-  if (((uintptr_t)d_depth & 15) || ((uintptr_t)d_fasta & 15)) return fail(ctx, RSI_ERR_BAD_ARG, "device inputs must be 16-byte aligned");
-  if (P.gcadjust && n / 20 <= 201)
-    return fail(ctx, RSI_ERR_TOO_SMALL, "size of RDA should be much larger than bin size (gccontent.cpp:66-71)");
-  HIPCHK(hipSetDevice(ctx->device));
-  ctx->ktimes.clear();
-  ctx->event_next = 0;
-  ctx->phases.clear();
-  tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
-  tl_grow_ms = 0.0;
-  mailbox_reset(ctx);
+// What the per-base phase leaves for the bin-level stages.
+struct PerBase {
+  std::vector<Region> noncode;       // padded, merged N regions (reference coordinates)
+  int64_t ncompact = 0, nb = 0;
+  size_t res_vals = 0;               // values covered by the residue-class histogram
+  std::vector<uint32_t> hres_all;    // BinAccum header + [value][MAD residue class] counts of the compacted depth
+  double RDmedian = 0;
+};
+constexpr size_t kResHead = 256;     // BinAccum sits in a header of the residue-class histogram: cleared and fetched with it
+
+// A1-A9: GC mask and N runs, GC table and rescale, cap, compaction, bins, chromosome statistics (K1-K4).  The kernels are
+// HBM-bound: workers of a pool take turns through this phase (GpuGate, held until the function returns).
+int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n, rsi_result* res,
+                   PerBase& pb) {
+  std::vector<Region>& noncode = pb.noncode;
   // The per-base kernels are HBM-bound: workers of a pool take turns through this phase (GpuGate).
   struct StreamTurn {
     GpuGate* g = nullptr;
@@ -664,7 +662,6 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     std::sort(re.begin(), re.end());
     for (size_t i = 0; i < rs.size(); ++i) nruns.push_back({(int)rs[i], (int)(re[i] - 1)});
   }
-  std::vector<Region> noncode;
   {
     const int dx = std::max(50, P.m / 4);
     for (const Region& r : nruns) {
@@ -725,8 +722,6 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   HIPCHK(ctx->rdc.ensure((size_t)(ncompact + 4) * 4));
   HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
   HIPCHK(ctx->binsum.ensure((size_t)nb * 8));
-  // BinAccum sits in a 256-byte header of the residue-class histogram: cleared and fetched together with it
-  constexpr size_t kResHead = 256;
   static_assert(sizeof(BinAccum) <= kResHead, "BinAccum outgrew its header");
   HIPCHK(ctx->hist_res.ensure(kResHead + (size_t)kHistValues * kResClasses * 4));
   const size_t res_vals = want_cap && capval < kHistValues - 1 ? (size_t)std::max(capval, 0) + 1 : (size_t)kHistValues;
@@ -757,10 +752,25 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     S.RDsd = sqrt(d2 / double((int)ncompact) - mean * mean);
   }
   S.RDmedian = RDmedian;
-  ph_bins.stop();
-  hbm_turn.release();
+  pb.ncompact = ncompact; pb.nb = nb; pb.res_vals = res_vals; pb.RDmedian = RDmedian;
+  pb.hres_all = std::move(hres_all);
+  return RSI_OK;
+}
 
-  std::vector<Candidate> blocks, raw, kept, segs_all;
+// A9-A19 on the bins and the candidates: MAD, NB transform, the two scans, segments, block tests, candidate stages.
+int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* res, const PerBase& pb,
+                     std::vector<Candidate>& blocks, std::vector<Candidate>& raw, std::vector<Candidate>& kept,
+                     std::vector<Candidate>& segs_all) {
+  rsi_chrom_stats& S = res->stats;
+  uint8_t* small = ctx->small.as<uint8_t>();
+  hipStream_t st = ctx->stream;
+  const std::vector<Region>& noncode = pb.noncode;
+  const int64_t ncompact = pb.ncompact, nb = pb.nb;
+  const size_t res_vals = pb.res_vals;
+  const uint32_t* hres = pb.hres_all.data() + kResHead / 4;
+  const double RDmedian = pb.RDmedian;
+  int rc = RSI_OK;
+
   if (!(RDmedian < 5)) {   // rsi.cpp:1809-1812
     Phase ph_nb(ctx, "a9-10.mad+nb");
     GateShared gs_nb(ctx);
@@ -894,6 +904,32 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
     ctx->phases.push_back({"calls.merge(incl tests)", prof.merge});
     ctx->phases.push_back({"calls.ntests", (double)prof.tests});
   }
+  return RSI_OK;
+}
+
+int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n,
+                    rsi_result* res) {
+  const rsi_params& P = *Pp;
+  const double t_begin = now_ms();
+  if (n <= 0 || n >= (1ll << 31) - 4096) return fail(ctx, RSI_ERR_BAD_ARG, "chromosome length must be in (0, 2^31)");
+  if (P.m < 1 || (P.m % 2) != 1) return fail(ctx, RSI_ERR_BAD_ARG, "m must be odd (the reference forces it, rsi.cpp:2061-2064)");
+  if (P.m > 3000) return fail(ctx, RSI_ERR_UNSUPPORTED, "bin size above 3000 is not supported by the bin kernel");
+  if (((uintptr_t)d_depth & 15) || ((uintptr_t)d_fasta & 15)) return fail(ctx, RSI_ERR_BAD_ARG, "device inputs must be 16-byte aligned");
+  if (P.gcadjust && n / 20 <= 201)
+    return fail(ctx, RSI_ERR_TOO_SMALL, "size of RDA should be much larger than bin size (gccontent.cpp:66-71)");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->ktimes.clear();
+  ctx->event_next = 0;
+  ctx->phases.clear();
+  tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
+  tl_grow_ms = 0.0;
+  mailbox_reset(ctx);
+  PerBase pb;
+  int rc = per_base_phase(ctx, P, d_depth, d_fasta, n, res, pb);
+  if (rc != RSI_OK) return rc;
+  rsi_chrom_stats& S = res->stats;
+  std::vector<Candidate> blocks, raw, kept, segs_all;
+  if ((rc = bin_level_stages(ctx, P, n, res, pb, blocks, raw, kept, segs_all)) != RSI_OK) return rc;
   Phase ph_fin(ctx, "z.finish");
   const std::vector<Candidate>* lists[4] = {&kept, &raw, &segs_all, &blocks};
   for (int w = 0; w < 4; ++w) {
