@@ -130,17 +130,12 @@ def main():
     def step(timed=False):
         results = pool.run(params, chrom_args, collect_times=timed)
         host_block = np.zeros((len(data), 4 + 4 * MAX_CALLS), dtype=np.float64)
-        ncalls = 0
-        for ci, res in enumerate(results):
-            calls = res.calls("calls")
-            ncalls += len(calls)
-            host_block[ci, 0:4] = (ci, res.stats["RDmedian"], res.stats["RDsd"], len(calls))
-            for k, c in enumerate(calls[:MAX_CALLS]):
-                host_block[ci, 4 + 4 * k: 8 + 4 * k] = (c["start"], c["end"], c["type"], c["qscore"])
+        for ci, res in enumerate(results):   # per chromosome: median, SD, number of calls, calls (start, end, type, qscore)
+            res.summary_into(host_block[ci], MAX_CALLS)
         if world > 1:   # the one exchange of the path: per-chromosome summaries to every rank
             gather_in.copy_(torch.from_numpy(host_block))
             dist.all_gather(gather_out, gather_in)
-        return ncalls
+        return int(host_block[:, 2].sum())
 
     def fence():
         if world > 1:

@@ -138,6 +138,11 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
  * defaults (-1) there. */
 int rsi_result_annotate_bam(rsi_result* r, const char* bam_path, const char* chrom);
 int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0);
+/* Fixed-size summary of one chromosome for the gather across ranks (the collection of per-chromosome results that
+ * replaces the reference's sequential output loop, rsi.cpp:1594-1608): out[0..3] = chromosome median, SD, number of final
+ * calls, number of calls stored; then (start, end, type, qscore) per stored call, at most max_calls of them.
+ * Returns the number of doubles written (4 + 4 * stored). */
+int rsi_result_summary(const rsi_result* r, double* out, int max_calls);
 /* Reference sequences of the BAM header: names as one '\n'-separated string into names[names_cap], lengths into
  * lengths[max_refs]; returns their number (also when the buffers are too small or NULL), < 0 on error. */
 int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs);

@@ -1110,6 +1110,17 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
   return k;
 }
 
+int rsi_result_summary(const rsi_result* r, double* out, int max_calls) {
+  if (!r || !out || max_calls < 0) return RSI_ERR_BAD_ARG;
+  const std::vector<rsi_call>& L = r->lists[0];
+  const int stored = (int)std::min<size_t>(L.size(), (size_t)max_calls);
+  out[0] = r->stats.RDmedian; out[1] = r->stats.RDsd; out[2] = (double)L.size(); out[3] = (double)stored;
+  for (int i = 0; i < stored; ++i) {
+    out[4 + 4 * i] = L[(size_t)i].start; out[5 + 4 * i] = L[(size_t)i].end; out[6 + 4 * i] = L[(size_t)i].type; out[7 + 4 * i] = L[(size_t)i].qscore;
+  }
+  return 4 + 4 * stored;
+}
+
 int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0) {
   if (!r || i < 0 || i >= (int)r->lists[0].size()) return RSI_ERR_BAD_ARG;
   if (rp) *rp = (size_t)i < r->rp.size() ? r->rp[(size_t)i] : -1;
