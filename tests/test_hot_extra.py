@@ -54,6 +54,14 @@ def test_pool_equals_single_context(hot, hotlib):
             ok, why = calls_equal(a.calls("calls_raw"), b.calls("calls_raw"), rtol=0)
             assert ok, why
             assert a.stats["RDmedian"] == b.stats["RDmedian"] and a.stats["RDsd"] == b.stats["RDsd"]
+            # the fixed-size summary row of the cross-rank gather (rsi_result_summary), here with room for two calls only
+            row = np.full(4 + 4 * 2, -7.0)
+            calls = b.calls("calls")
+            assert b.summary_into(row, 2) == 4 + 4 * min(len(calls), 2)
+            assert list(row[:4]) == [b.stats["RDmedian"], b.stats["RDsd"], len(calls), min(len(calls), 2)]
+            for k, c in enumerate(calls[:2]):
+                assert list(row[4 + 4 * k: 8 + 4 * k]) == [c["start"], c["end"], c["type"], c["qscore"]]
+            assert (row[4 + 4 * min(len(calls), 2):] == -7.0).all()
     pool.close()
 
 
