@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace rsik {
 
@@ -150,6 +151,19 @@ void launch_best_items(const void* items, int nitems, const int64_t* poff, const
 // edge trimming of filterstatus (rsi.cpp:1023-1044): one thread per run
 void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, int nruns,
                       double delthr, double addthr, hipStream_t stream);
+
+// Dynamic LDS beyond 48 KB has to be allowed per kernel.  Done once per kernel and for all the CU has left next to the
+// kernel's static use: a per-launch setting from several host threads (a pool) would race with the other threads' launches.
+#define RSI_ALLOW_FULL_LDS(kernel)                                                                                  \
+  do {                                                                                                              \
+    static std::once_flag once__;                                                                                   \
+    std::call_once(once__, [] {                                                                                     \
+      hipFuncAttributes a__;                                                                                        \
+      if (hipFuncGetAttributes(&a__, reinterpret_cast<const void*>(kernel)) != hipSuccess) return;                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024 - (int)a__.sharedSizeBytes);                                             \
+    });                                                                                                             \
+  } while (0)
 
 // ---- candidate stages on the device (kernels_cand.hip) ----
 constexpr unsigned kCandHistBins = 16384;   // LDS counters of the per-test quantile histograms

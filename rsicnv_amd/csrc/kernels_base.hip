@@ -901,8 +901,9 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   const int maxv = (quads + kThreads - 1) / kThreads;          // 16-byte loads per thread and tile
   const int parts = kThreads / TB, ept = (m + parts - 1) / parts;   // values per thread in the median phase
   unsigned int* sl = static_cast<unsigned int*>(slabs);
-#define RSI_K4(MV, EP) hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg, \
-                                          ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl)
+#define RSI_K4(MV, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin<MV, EP>));                                                            \
+    hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
+                       ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl); } while (0)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
   else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)
   else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile

@@ -740,7 +740,7 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
                      uint32_t np, hipStream_t stream) {
   const int use_lds = np <= kLdsBins;
   const size_t lds = use_lds ? (size_t)np * 4 : 0;
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RSI_ALLOW_FULL_LDS(k_hist_f32);
   // few, long-lived workgroups: every one flushes np counters at the end
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
@@ -753,7 +753,7 @@ void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use
   else hipLaunchKernelGGL(k_minmax_f32, dim3(g), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
   hipLaunchKernelGGL(k_grid_plan, dim3(64), dim3(kThreads), 0, stream, mm, cap, hist, out);
   const size_t lds = (size_t)kLdsBins * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_f32_planned), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RSI_ALLOW_FULL_LDS(k_hist_f32_planned);
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
   hipLaunchKernelGGL(k_hist_f32_planned, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, hist);
@@ -771,7 +771,7 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   sp.kcap = kcap;
   const size_t lds = scan_lds_bytes(count, kcap);
   const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rsi_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RSI_ALLOW_FULL_LDS(k_rsi_scan);
   hipLaunchKernelGGL(k_rsi_scan, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters);
 }
 void launch_level_hist(const uint32_t* first, const uint32_t* exclude, const uint32_t* exclude_max, int64_t nb, int32_t Lmax,

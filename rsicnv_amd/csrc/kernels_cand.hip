@@ -580,8 +580,7 @@ void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* 
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;
   const size_t lds = (size_t)kCandHistBins * 4;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_candidate_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  RSI_ALLOW_FULL_LDS(k_candidate_test);
   hipLaunchKernelGGL(k_candidate_test, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch,
                      lscratch, RDmedian, outs);
 }

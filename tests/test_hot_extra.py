@@ -326,6 +326,16 @@ def test_bin_size_extremes(hot, hotlib, oracle_cls):
     for which in ("blocks", "calls_raw", "calls"):
         ok, why = calls_equal(res.calls(which), O.calls(which))
         assert ok, f"{which}: {why}"
+    # bins of 1501 at four times the depth: the cap (4 x 120) needs the 256-value LDS histogram (32 KB) next to a 48 KB
+    # tile, more than the 64 KB a kernel gets without asking for it
+    deep = (depth * 4 + (np.arange(depth.size, dtype=np.int64) * 2654435761 % 4).astype(np.int32) * (depth > 0)).astype(np.int32)
+    O.run(oracle.make_params(m=1501), deep, fasta)
+    res = hot.run(api.make_params(m=1501), deep, fasta)
+    assert res.stats["RDmedian"] > 100
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
     with pytest.raises(api.RsiError) as e:
         hot.run(api.make_params(m=3), depth[:200_000], fasta[:200_000])
     assert e.value.code == -5 and "2048" in str(e.value)
