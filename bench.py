@@ -78,10 +78,16 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # RSI_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the
+    # collectives run on host tensors); the driver's runs use nccl (= RCCL) with one GPU per rank.
+    backend = os.environ.get("RSI_BENCH_BACKEND", "nccl")
+    cpu_slot = local_rank
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         # One slice of the allowed CPUs per rank (contiguous ids are normally one socket): a rank's dozen worker threads
         # and the runtime's helper threads then stay next to each other instead of wandering over both sockets.  Only
         # when the slice is comfortably larger than the pool; RSI_BENCH_PIN=0 turns it off.
@@ -90,7 +96,7 @@ def main():
             local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
             per = len(allowed) // max(local_world, 1)
             if os.environ.get("RSI_BENCH_PIN", "1") != "0" and per >= args.workers + 4:
-                os.sched_setaffinity(0, set(allowed[local_rank * per:(local_rank + 1) * per]))
+                os.sched_setaffinity(0, set(allowed[cpu_slot * per:(cpu_slot + 1) * per]))
         except (AttributeError, OSError):
             pass
 
@@ -122,7 +128,8 @@ def main():
     if rank == 0:
         log(f"[bench] generated {len(data)} chromosomes, {total_bases/1e9:.3f} Gb per rank in {time.time()-t0:.1f} s")
 
-    gather_in = torch.zeros(len(data), 4 + 4 * MAX_CALLS, dtype=torch.float64, device=dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    gather_in = torch.zeros(len(data), 4 + 4 * MAX_CALLS, dtype=torch.float64, device=coll_dev)
     gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
 
     chrom_args = [(d_rd.data_ptr(), d_fa.data_ptr(), n) for d_rd, d_fa, n in data]
@@ -153,7 +160,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
