@@ -196,6 +196,23 @@ void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi incl
 void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream);
 size_t sharpen_workspace_bytes(int njobs);
 size_t sharpen_workspace_zero_bytes(int njobs);
+// The same test spread over several workgroups (four launches: the two walks side by side; chunked prefix + the candidate's
+// statistics; chunked window means; chunked histogram with a last-workgroup fold).  iscratch carries a fourth piece per job
+// (the right walk's own `capacity` slots, after the three of the single-workgroup form); mid: njobs CandMid records, `done`
+// zero before the first launch (each launch leaves it zero); ghist: njobs x kCandHistBins counters, zero likewise.
+constexpr int kCandChunks = 16;
+struct CandMid {
+  int32_t lcnt, lreach, lused, rcnt_max, rreach, rused;
+  uint32_t done, body_flags;
+  long long totals[kCandChunks];
+  float flo[kCandChunks], fhi[kCandChunks];
+  double m1[kCandChunks], m2[kCandChunks];
+  int32_t body_min, body_max;
+  double body_q[3], body_s1, body_s2;
+};
+void launch_candidate_test_split(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+                                 int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,
+                                 CandOut* outs, hipStream_t stream);
 void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
 

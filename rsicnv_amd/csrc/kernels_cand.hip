@@ -552,6 +552,261 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
   if (threadIdx.x == 0) outs[blockIdx.x] = O;
 }
 
+// ------------------------------------------------------------------------------------------
+// The neighbourhood test over several workgroups.  Same arithmetic as k_candidate_test (see there for the reference
+// lines); only the order in which the two float moments of the window means are summed differs (chunks, then a fixed
+// order over the chunks).  The neighbourhood is not materialised: ref(j) = left part ++ right part is read in place.
+struct CandGeom { int used0, rcnt, nref_raw, nref, nbody, nbody_eff, width, nwin; bool thin; };
+
+__device__ inline CandGeom cand_geometry(const CandJob& J, const CandMid& M) {
+  CandGeom g;
+  g.used0 = J.top >= 0 ? (M.lcnt < J.top + 1 ? M.lcnt : J.top + 1) : 0;
+  int room = J.capacity - g.used0;
+  const int lim = (int)ceil(J.right_cap);                  // `used < 2*chklen*d` (rsi.cpp:243)
+  if (lim - g.used0 < room) room = lim - g.used0;
+  if (room < 0) room = 0;
+  g.rcnt = M.rcnt_max < room ? M.rcnt_max : room;
+  g.nref_raw = g.used0 + g.rcnt;
+  g.nbody = J.end - J.start + 1;
+  g.nref = g.nref_raw; g.nbody_eff = g.nbody; g.thin = false;
+  if (g.nref_raw + g.nbody > J.budget) {                    // thinning (rsi.cpp:264-282)
+    const int total = g.nref_raw + g.nbody;
+    g.nref = (int)((double)g.nref_raw / (double)total * (double)J.budget);
+    g.nbody_eff = (int)((double)g.nbody / (double)total * (double)J.budget);
+    g.thin = true;
+  }
+  g.width = g.nbody_eff;
+  g.nwin = g.nref - g.width;
+  return g;
+}
+struct CandBufs { int32_t *left, *ref, *thin, *right; long long* P; };
+__device__ inline CandBufs cand_buffers(const CandJob& J, int32_t* iscratch, long long* lscratch) {
+  CandBufs b;
+  b.left = iscratch + J.iscratch_off;
+  b.ref = b.left + (((J.top + 1 > 0 ? J.top + 1 : 0) + 3) & ~3);
+  b.thin = b.ref + ((J.capacity + 3) & ~3);
+  const int nthin = J.capacity < J.budget ? J.capacity : J.budget;
+  b.right = b.thin + ((nthin + 3) & ~3);
+  b.P = lscratch + J.lscratch_off;
+  return b;
+}
+// element i of the (possibly thinned) neighbourhood
+__device__ inline int cand_value(const CandJob& J, const CandGeom& g, const CandBufs& b, int i) {
+  const int j = g.thin ? (int)((double)i / (double)g.nref * (double)g.nref_raw) : i;
+  return j < g.used0 ? b.left[J.top + 1 - g.used0 + j] : b.right[j - g.used0];
+}
+__device__ inline int cand_chunk_len(int n) { return (((n + kCandChunks - 1) / kCandChunks) + 3) & ~3; }
+
+// launch 1: grid (2, njobs) -- the left and the right walk of every test side by side
+__global__ __launch_bounds__(kTestThreads) void k_cand_gather(const int32_t* __restrict__ A, int64_t N, const CandJob* __restrict__ jobs,
+                                                          const int2* __restrict__ chains, int32_t* __restrict__ iscratch,
+                                                          long long* __restrict__ lscratch, double RDmedian, CandMid* __restrict__ mid) {
+  __shared__ WalkShared W;
+  const CandJob J = jobs[blockIdx.y];
+  const CandBufs b = cand_buffers(J, iscratch, lscratch);
+  const double too_high = RDmedian * 3.0, too_low = RDmedian * 0.15;
+  CandMid& M = mid[blockIdx.y];
+  if (blockIdx.x == 0) {
+    int lreach = J.start, lused = 0, lcnt = 0;
+    if (J.top >= 0)
+      lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, b.left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
+    if (threadIdx.x == 0) { M.lcnt = lcnt; M.lreach = lreach; M.lused = lused; }
+  } else {
+    // the right walk does not know yet how many slots the left one leaves: it fills as many as it could ever get
+    int room = J.capacity;
+    const int lim = (int)ceil(J.right_cap);
+    if (lim < room) room = lim;
+    if (room < 0) room = 0;
+    int rreach = J.end, rused = 0;
+    const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, b.right, 0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused);
+    if (threadIdx.x == 0) { M.rcnt_max = rcnt; M.rreach = rreach; M.rused = rused; }
+  }
+}
+
+// launch 2: grid (kCandChunks + 1, njobs) -- chunk-local exact prefix of the neighbourhood (+ chunk totals); the last
+// workgroup of a job computes the candidate's own statistics meanwhile
+__global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const int32_t* __restrict__ A, const CandJob* __restrict__ jobs,
+                                                          int32_t* __restrict__ iscratch, long long* __restrict__ lscratch,
+                                                          CandMid* __restrict__ mid) {
+  extern __shared__ unsigned int s_hist[];   // kCandHistBins counters (candidate statistics only)
+  __shared__ long long s_l[kMaxWaves];
+  __shared__ int s_i2[kMaxWaves];
+  __shared__ int s_scan[kMaxWaves];
+  __shared__ int s_q[3];
+  const CandJob J = jobs[blockIdx.y];
+  CandMid& M = mid[blockIdx.y];
+  const CandGeom g = cand_geometry(J, M);
+  const CandBufs b = cand_buffers(J, iscratch, lscratch);
+  if (g.nwin <= 0 || g.width <= 0) return;
+  if (blockIdx.x < kCandChunks) {
+    const int Lc = cand_chunk_len(g.nref);
+    const int cb = blockIdx.x * Lc;
+    int ce = cb + Lc; if (ce > g.nref) ce = g.nref;
+    long long carry = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.P[0] = 0;
+    for (int t0 = cb; t0 < ce; t0 += 4 * kTestThreads) {
+      const int e = t0 + 4 * (int)threadIdx.x;
+      const int v0 = e < ce ? cand_value(J, g, b, e) : 0, v1 = e + 1 < ce ? cand_value(J, g, b, e + 1) : 0;
+      const int v2 = e + 2 < ce ? cand_value(J, g, b, e + 2) : 0, v3 = e + 3 < ce ? cand_value(J, g, b, e + 3) : 0;
+      const long long a1 = v0, a2 = a1 + v1, a3 = a2 + v2, a4 = a3 + v3;
+      long long total;
+      const long long base = carry + block_exscan_i64(a4, s_l, &total);
+      if (e < ce) b.P[e + 1] = base + a1;
+      if (e + 1 < ce) b.P[e + 2] = base + a2;
+      if (e + 2 < ce) b.P[e + 3] = base + a3;
+      if (e + 3 < ce) b.P[e + 4] = base + a4;
+      carry += total;
+    }
+    if (threadIdx.x == 0) M.totals[blockIdx.x] = carry;
+    return;
+  }
+  // ---- candidate statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
+  const int width = g.width;
+  auto body_at = [&](int q) -> int {
+    return g.thin ? A[J.start + (int)((double)q / (double)g.nbody_eff * (double)g.nbody)] : A[J.start + q];
+  };
+  int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
+  for (int q = threadIdx.x; q < width; q += kTestThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
+  lo = block_reduce(lo, [](int a, int b2) { return a < b2 ? a : b2; }, s_i2);
+  hi = block_reduce(hi, [](int a, int b2) { return a > b2 ? a : b2; }, s_i2);
+  s1 = block_reduce(s1, [](long long a, long long b2) { return a + b2; }, s_l);
+  s2 = block_reduce(s2, [](long long a, long long b2) { return a + b2; }, s_l);
+  double q0 = lo, q1 = (double)s1 / (double)width, q2 = hi;
+  unsigned flags = 0;
+  if ((double)hi - (double)lo >= 1.0) {
+    const unsigned nbk = (unsigned)(hi - lo) + 2;
+    if (nbk > kCandHistBins) flags = 2;
+    else {
+      for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
+      __syncthreads();
+      for (int q = threadIdx.x; q < width; q += kTestThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
+      __syncthreads();
+      int qb[3];
+      hist_ranks(s_hist, nbk, (size_t)width, s_scan, s_q, qb);
+      if (qb[0] >= 0) q0 = (double)lo + qb[0] * 1.0;
+      if (qb[1] >= 0) q1 = (double)lo + qb[1] * 1.0;
+      if (qb[2] >= 0) q2 = (double)lo + qb[2] * 1.0;
+    }
+  }
+  if (threadIdx.x == 0) {
+    M.body_flags = flags; M.body_min = lo; M.body_max = hi; M.body_s1 = (double)s1; M.body_s2 = (double)s2;
+    M.body_q[0] = q0; M.body_q[1] = q1; M.body_q[2] = q2;
+  }
+}
+
+// launch 3: grid (kCandChunks, njobs) -- float window means of a chunk of windows, their extremes and moments
+__global__ __launch_bounds__(kTestThreads) void k_cand_means(const CandJob* __restrict__ jobs, int32_t* __restrict__ iscratch,
+                                                         long long* __restrict__ lscratch, CandMid* __restrict__ mid) {
+  __shared__ long long s_off[kCandChunks];
+  __shared__ double s_d[kMaxWaves];
+  __shared__ float s_f[kMaxWaves];
+  const CandJob J = jobs[blockIdx.y];
+  CandMid& M = mid[blockIdx.y];
+  const CandGeom g = cand_geometry(J, M);
+  const CandBufs b = cand_buffers(J, iscratch, lscratch);
+  if (g.nwin <= 0 || g.width <= 0) return;
+  if (threadIdx.x == 0) { long long o = 0; for (int c = 0; c < kCandChunks; ++c) { s_off[c] = o; o += M.totals[c]; } }
+  __syncthreads();
+  const int Lc = cand_chunk_len(g.nref);
+  auto P_at = [&](int x) -> long long { return x == 0 ? 0ll : s_off[(x - 1) / Lc] + b.P[x]; };
+  const int Wc = cand_chunk_len(g.nwin);
+  const int wb = blockIdx.x * Wc;
+  int we = wb + Wc; if (we > g.nwin) we = g.nwin;
+  float* Wm = reinterpret_cast<float*>(b.ref);
+  const double dw = (double)g.width;
+  float flo = 3.0e38f, fhi = -3.0e38f; double m1 = 0, m2 = 0;
+  for (int q = wb + (int)threadIdx.x; q < we; q += kTestThreads) {
+    const float w = (float)((double)(P_at(q + g.width) - P_at(q)) / dw);
+    Wm[q] = w;
+    flo = w < flo ? w : flo; fhi = w > fhi ? w : fhi; m1 += (double)w; m2 += (double)w * (double)w;
+  }
+  flo = block_reduce(flo, [](float a, float b2) { return a < b2 ? a : b2; }, s_f);
+  fhi = block_reduce(fhi, [](float a, float b2) { return a > b2 ? a : b2; }, s_f);
+  m1 = block_reduce(m1, [](double a, double b2) { return a + b2; }, s_d);
+  m2 = block_reduce(m2, [](double a, double b2) { return a + b2; }, s_d);
+  if (threadIdx.x == 0) { M.flo[blockIdx.x] = flo; M.fhi[blockIdx.x] = fhi; M.m1[blockIdx.x] = m1; M.m2[blockIdx.x] = m2; }
+}
+
+// launch 4: grid (kCandChunks, njobs) -- 0.01-grid histogram of the means; the last workgroup of a job walks it and
+// writes the result.  ghist and the ticket are left zero.
+__global__ __launch_bounds__(kTestThreads) void k_cand_hist(const CandJob* __restrict__ jobs, int32_t* __restrict__ iscratch,
+                                                        long long* __restrict__ lscratch, CandMid* __restrict__ mid,
+                                                        uint32_t* __restrict__ ghist_all, CandOut* __restrict__ outs) {
+  extern __shared__ unsigned int s_hist[];   // kCandHistBins counters
+  __shared__ int s_scan[kMaxWaves];
+  __shared__ int s_q[3];
+  __shared__ int s_last;
+  const CandJob J = jobs[blockIdx.y];
+  CandMid& M = mid[blockIdx.y];
+  const CandGeom g = cand_geometry(J, M);
+  const CandBufs b = cand_buffers(J, iscratch, lscratch);
+  uint32_t* ghist = ghist_all + (size_t)blockIdx.y * kCandHistBins;
+  CandOut O;
+  O.flags = M.body_flags;
+  if (((J.cut & 1) && M.lused >= J.nleft) || ((J.cut & 2) && M.rused >= J.nright)) O.flags |= 8;
+  O.nref = g.nref; O.nbody = g.nbody_eff; O.nwin = g.nwin; O.left_reach = M.lreach; O.right_reach = M.rreach;
+  if (g.nwin <= 0 || g.width <= 0) {
+    O.flags = (O.flags & 8) | 1;
+    O.body_min = O.body_max = 0; O.body_s1 = O.body_s2 = O.ref_s1 = O.ref_s2 = 0;
+    for (int k = 0; k < 3; ++k) { O.body_q[k] = 0; O.ref_q[k] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) outs[blockIdx.y] = O;
+    return;
+  }
+  O.body_min = M.body_min; O.body_max = M.body_max; O.body_s1 = M.body_s1; O.body_s2 = M.body_s2;
+  O.body_q[0] = M.body_q[0]; O.body_q[1] = M.body_q[1]; O.body_q[2] = M.body_q[2];
+  float flo = 3.0e38f, fhi = -3.0e38f; double m1 = 0, m2 = 0;
+  for (int c = 0; c < kCandChunks; ++c) {   // chunks without windows left their neutral elements
+    flo = M.flo[c] < flo ? M.flo[c] : flo; fhi = M.fhi[c] > fhi ? M.fhi[c] : fhi; m1 += M.m1[c]; m2 += M.m2[c];
+  }
+  const double lo = flo, hi = fhi;
+  O.ref_s1 = m1; O.ref_s2 = m2;
+  O.ref_q[0] = lo; O.ref_q[1] = m1 / (double)g.nwin; O.ref_q[2] = hi;
+  const bool spread = (hi - lo) >= 0.01;
+  const size_t nbk = spread ? (size_t)((hi - lo) / 0.01 + 2) : 0;
+  if (!spread || nbk > kCandHistBins) {
+    if (spread) O.flags |= 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) outs[blockIdx.y] = O;
+    return;
+  }
+  const float* Wm = reinterpret_cast<const float*>(b.ref);
+  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
+  __syncthreads();
+  const int Wc = cand_chunk_len(g.nwin);
+  const int wb = blockIdx.x * Wc;
+  int we = wb + Wc; if (we > g.nwin) we = g.nwin;
+  // neighbouring windows mostly share a bucket: eight consecutive means per thread, equal buckets merged before the atomic
+  for (int i0 = wb + 8 * (int)threadIdx.x; i0 < we; i0 += 8 * kTestThreads) {
+    unsigned pend_b = 0xffffffffu, pend_c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (i0 + k < we) {
+        const double idx = ((double)Wm[i0 + k] - lo) / 0.01 + 0.5;   // wufunctions.cpp:396
+        const unsigned bkt = (unsigned)(unsigned long long)idx;
+        if (bkt != pend_b) { if (pend_c) atomicAdd(&s_hist[pend_b], pend_c); pend_b = bkt; pend_c = 0; }
+        ++pend_c;
+      }
+    }
+    if (pend_c) atomicAdd(&s_hist[pend_b], pend_c);
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) { const unsigned c = s_hist[e]; if (c) atomicAdd(&ghist[e], c); }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&M.done, 1u) == kCandChunks - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = atomicAdd(&ghist[e], 0u);   // the folded histogram, read past the caches
+  __syncthreads();
+  int qb[3];
+  hist_ranks(s_hist, (unsigned)nbk, (size_t)g.nwin, s_scan, s_q, qb);
+  if (qb[0] >= 0) O.ref_q[0] = lo + qb[0] * 0.01;
+  if (qb[1] >= 0) O.ref_q[1] = lo + qb[1] * 0.01;
+  if (qb[2] >= 0) O.ref_q[2] = lo + qb[2] * 0.01;
+  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) ghist[e] = 0;
+  if (threadIdx.x == 0) { M.done = 0; outs[blockIdx.y] = O; }
+}
+
 // Sums of depth over inclusive ranges (mean_tp of mergesegments, rsi.cpp:775-779): exact integers.
 __global__ __launch_bounds__(kThreads) void k_range_sums(const int32_t* __restrict__ A, const int2* __restrict__ ranges,
                                                          long long* __restrict__ sums) {
@@ -573,6 +828,19 @@ void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long
 void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream) {
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, njobs, ws);
+}
+void launch_candidate_test_split(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+                                 int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,
+                                 CandOut* outs, hipStream_t stream) {
+  if (njobs <= 0) return;
+  const size_t lds = (size_t)kCandHistBins * 4;
+  RSI_ALLOW_FULL_LDS(k_cand_prefix);
+  RSI_ALLOW_FULL_LDS(k_cand_hist);
+  const int2* ch = static_cast<const int2*>(chains);
+  hipLaunchKernelGGL(k_cand_gather, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid);
+  hipLaunchKernelGGL(k_cand_prefix, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid);
+  hipLaunchKernelGGL(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid);
+  hipLaunchKernelGGL(k_cand_hist, dim3(kCandChunks, njobs), dim3(kTestThreads), lds, stream, jobs, iscratch, lscratch, mid, ghist, outs);
 }
 size_t sharpen_workspace_bytes(int njobs) { return sharpen_zero_bytes(njobs) + (size_t)njobs * 2 * kEdgeChunks * (8 + 8 + 4); }
 size_t sharpen_workspace_zero_bytes(int njobs) { return sharpen_zero_bytes(njobs); }

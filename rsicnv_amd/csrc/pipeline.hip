@@ -187,6 +187,12 @@ class DeviceTester : public rsih::NeighbourTester {
     stats.assign(n, rsih::TestStats{});
     left_reach.assign(n, 0);
     okv.assign(n, 0);
+    // One workgroup per test (k_candidate_test) or the four-launch form that spreads a test over 17 workgroups.  A lone
+    // chromosome gets its tests back 40 % sooner from the second; in a pool the first is better (35.3 against 38.1 ms per
+    // genome): a few long-lived workgroups cost the per-base kernels of the other chromosomes next to nothing, hundreds of
+    // full ones take their CUs.  RSI_HOT_CAND_SPLIT=0 / 1 overrides.
+    static const int split_env = getenv("RSI_HOT_CAND_SPLIT") ? atoi(getenv("RSI_HOT_CAND_SPLIT")) : -1;
+    const bool split = split_env >= 0 ? split_env != 0 : ctx->gate == nullptr;
     size_t first = 0;
     while (first < n) {
       std::vector<CandJob> jobs;
@@ -196,7 +202,8 @@ class DeviceTester : public rsih::NeighbourTester {
         const rsih::TestPlan& T = plans[last];
         if (T.capacity <= 0 || T.end < T.start || T.start < 0 || T.end >= N) break;   // left to the host path (ok stays 0)
         auto up4 = [](size_t x) { return (x + 3) & ~(size_t)3; };   // the kernel wants every piece on a 16-byte boundary
-        const size_t iw = up4((size_t)std::max(T.top + 1, 0)) + up4((size_t)T.capacity) + up4((size_t)std::min(T.capacity, T.budget));
+        const size_t iw = up4((size_t)std::max(T.top + 1, 0)) + up4((size_t)T.capacity) + up4((size_t)std::min(T.capacity, T.budget)) +
+                          (split ? up4((size_t)T.capacity) : 0);   // the split form's right walk has its own slots
         const size_t lw = up4((size_t)T.capacity + 1);
         if (!jobs.empty() && (iwords + iw) * 4 + (lwords + lw) * 8 > kCandScratchBytes) break;
         CandJob J{};
@@ -220,6 +227,12 @@ class DeviceTester : public rsih::NeighbourTester {
             !ok(ctx->cand_outs.ensure(outs.size() * sizeof(CandOut))) || !ok(ctx->cand_i32.ensure(iwords * 4)) ||
             !ok(ctx->cand_i64.ensure(lwords * 8)))
           return false;
+        if (split) {   // per-job records and folded histograms of the split form: zero when (re)allocated, left zero by every launch
+          const void* m0 = ctx->cand_mid.p; const void* h0 = ctx->cand_hist.p;
+          if (!ok(ctx->cand_mid.ensure(jobs.size() * sizeof(CandMid))) || !ok(ctx->cand_hist.ensure(jobs.size() * (size_t)kCandHistBins * 4))) return false;
+          if (ctx->cand_mid.p != m0 && !ok(hipMemsetAsync(ctx->cand_mid.p, 0, ctx->cand_mid.cap, ctx->stream))) return false;
+          if (ctx->cand_hist.p != h0 && !ok(hipMemsetAsync(ctx->cand_hist.p, 0, ctx->cand_hist.cap, ctx->stream))) return false;
+        }
       }
       GateShared gs(ctx);
       Phase ph(ctx, "cand.test");
@@ -227,8 +240,13 @@ class DeviceTester : public rsih::NeighbourTester {
       if (!ok(copy_h2d(ctx, ctx->cand_chains.p, chains.data(), chains.size() * 4))) return false;
       {
         Timer t(ctx, "candidate_test");
-        launch_candidate_test(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
-                              ctx->cand_i64.as<long long>(), median, ctx->cand_outs.as<CandOut>(), ctx->stream);
+        if (split)
+          launch_candidate_test_split(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
+                                      ctx->cand_i64.as<long long>(), median, ctx->cand_mid.as<CandMid>(), ctx->cand_hist.as<uint32_t>(),
+                                      ctx->cand_outs.as<CandOut>(), ctx->stream);
+        else
+          launch_candidate_test(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
+                                ctx->cand_i64.as<long long>(), median, ctx->cand_outs.as<CandOut>(), ctx->stream);
       }
       if (!ok(copy_d2h(ctx, outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut)))) return false;
       if (!wait()) return false;
