@@ -48,7 +48,15 @@ __global__ __launch_bounds__(kThreads) void k_nb_raw(const int64_t* __restrict__
     kmin = k < kmin ? k : kmin;
   }
   for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(kmin, d); kmin = o < kmin ? o : kmin; }
-  if (lane_id() == 0 && kmin != 0xffffffffu) atomicMax(rawmin_key, ~kmin);   // complement: all zero = nothing seen
+  // one atomic per workgroup of a bounded grid: one per wave of one-bin threads was 19 000 atomics on the same word per
+  // chromosome, and those serialise (the kernel took 100 us for 1.2 M bins, 80 of them in that queue)
+  __shared__ uint32_t s_min[kThreads / 64];
+  if (lane_id() == 0) s_min[threadIdx.x >> 6] = kmin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) kmin = s_min[w] < kmin ? s_min[w] : kmin;
+    if (kmin != 0xffffffffu) atomicMax(rawmin_key, ~kmin);   // complement: all zero = nothing seen
+  }
 }
 
 // rsi.cpp:1176-1185: subtract the minimum, rescale to the depth scale, overwrite bins 0..2
@@ -723,7 +731,9 @@ __global__ __launch_bounds__(kThreads) void k_best_subsegment(const SegItem* __r
 
 void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, double r, float* raw, uint32_t* rawmin_bits,
                    hipStream_t stream) {
-  hipLaunchKernelGGL(k_nb_raw, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, binsum, nb, m, ncompact, r, raw, rawmin_bits);
+  int grid = grid_for(nb, kThreads * 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_nb_raw, dim3(grid), dim3(kThreads), 0, stream, binsum, nb, m, ncompact, r, raw, rawmin_bits);
 }
 void launch_nb_scale(float* x, int64_t nb, double tmin, double med_nbt, double med, float lev0, float lev1, float lev2,
                      hipStream_t stream) {
