@@ -851,7 +851,17 @@ __global__ __launch_bounds__(1024) void k_value_median(const uint32_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long local = 0;
   int lo = 0x7fffffff, hi = -1;
-  for (int v = v0; v < v0 + kPer; ++v) { const uint32_t c = hist[v]; local += c; if (c) { lo = v < lo ? v : lo; hi = v; } }
+  // sixteen 16-byte loads per walk instead of 64 four-byte ones: a wave's load instruction touches 64 cache lines either way
+#pragma unroll 4
+  for (int i = 0; i < kPer / 4; ++i) {
+    const uint4 c4 = *reinterpret_cast<const uint4*>(hist + v0 + 4 * i);
+    const int v = v0 + 4 * i;
+    local += (unsigned long long)c4.x + c4.y + c4.z + c4.w;
+    if (c4.x) { lo = v < lo ? v : lo; hi = v; }
+    if (c4.y) { lo = v + 1 < lo ? v + 1 : lo; hi = v + 1; }
+    if (c4.z) { lo = v + 2 < lo ? v + 2 : lo; hi = v + 2; }
+    if (c4.w) { lo = v + 3 < lo ? v + 3 : lo; hi = v + 3; }
+  }
   unsigned long long incl = local;
   for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
   int wlo = lo, whi = hi;
@@ -865,10 +875,16 @@ __global__ __launch_bounds__(1024) void k_value_median(const uint32_t* __restric
   for (int w = 0; w < 16; ++w) { if (w < wave) base += s_w[w]; all += s_w[w]; glo = s_lo[w] < glo ? s_lo[w] : glo; ghi = s_hi[w] > ghi ? s_hi[w] : ghi; }
   const unsigned long long r2 = total / 2;
   unsigned long long seen = base + incl - local;
-  for (int v = v0; v < v0 + kPer; ++v) {
-    const unsigned long long upto = seen + hist[v];
-    if (seen < r2 && upto >= r2) s_med = v;
-    seen = upto;
+#pragma unroll 4
+  for (int i = 0; i < kPer / 4; ++i) {
+    const uint4 c4 = *reinterpret_cast<const uint4*>(hist + v0 + 4 * i);
+    const uint32_t q[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long upto = seen + q[k];
+      if (seen < r2 && upto >= r2) s_med = v0 + 4 * i + k;
+      seen = upto;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) { out->inrange = all; out->lo = glo; out->hi = ghi; out->med = s_med; out->pad = 0; }
