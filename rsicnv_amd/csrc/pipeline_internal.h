@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <sys/prctl.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
@@ -181,18 +183,25 @@ namespace rsip {
     }                                                                                         \
   } while (0)
 
-// Wait for the context's stream without burning a core: poll briefly (most waits are a few
-// microseconds), then sleep on a blocking-sync event.  With one busy-spinning thread per worker a
-// 16-CPU quota is exhausted by the waits alone and the whole process gets throttled.
+// Wait for the context's stream without burning a core: poll briefly (most waits are a few microseconds), then nap
+// between polls.  With one busy-spinning thread per worker a 16-CPU quota is exhausted by the waits alone and the whole
+// process gets throttled; a blocking hipEventSynchronize sleeps until the completion interrupt, and when nothing else
+// is running on the GPU (one chromosome alone in a pool) that wake-up now and then came 30 ms late on some boxes.
 inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
   hipError_t e = hipEventRecord(ev, stream);
   if (e != hipSuccess) return e;
   for (int spin = 0; spin < 2000; ++spin) {
     e = hipEventQuery(ev);
-    if (e == hipSuccess) return hipSuccess;
     if (e != hipErrorNotReady) return e;
   }
-  return hipEventSynchronize(ev);
+  static thread_local bool slack_set = false;
+  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL); slack_set = true; }   // naps of 10 us, not 10 + 50
+  for (;;) {
+    struct timespec nap = {0, 10000};   // 10 us
+    nanosleep(&nap, nullptr);
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+  }
 }
 
 // Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
