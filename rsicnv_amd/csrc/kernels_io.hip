@@ -86,12 +86,18 @@ __global__ __launch_bounds__(kThreads) void k_parse_depth_text(const unsigned ch
   __syncthreads();
   // ---- totals ----
   for (int d = 32; d >= 1; d >>= 1) { lines += __shfl_xor(lines, d); stored += __shfl_xor(stored, d); beyond += __shfl_xor(beyond, d); }
-  if ((threadIdx.x & 63) == 0) {
-    if (lines) atomicAdd(&stats->lines, (unsigned long long)lines);
-    if (stored) atomicAdd(&stats->stored, (unsigned long long)stored);
-    if (beyond) atomicAdd(&stats->beyond, (unsigned long long)beyond);
+  // one set of atomics per workgroup (they all land on the same three words and serialise there)
+  __shared__ int s_tot[kThreads / 64][3];
+  if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6][0] = (int)lines; s_tot[threadIdx.x >> 6][1] = (int)stored; s_tot[threadIdx.x >> 6][2] = (int)beyond; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t0 = 0, t1 = 0, t2 = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { t0 += s_tot[w][0]; t1 += s_tot[w][1]; t2 += s_tot[w][2]; }
+    if (t0) atomicAdd(&stats->lines, (unsigned long long)t0);
+    if (t1) atomicAdd(&stats->stored, (unsigned long long)t1);
+    if (t2) atomicAdd(&stats->beyond, (unsigned long long)t2);
+    if (s_bad) atomicOr(&stats->unsorted, 1u);
   }
-  if (threadIdx.x == 0 && s_bad) atomicOr(&stats->unsorted, 1u);
 }
 
 }  // namespace
