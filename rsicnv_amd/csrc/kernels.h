@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include "device_util.h"
 
 namespace rsik {
 
@@ -16,8 +17,13 @@ constexpr int kTileBases = 4096;      // bases per workgroup tile in the streami
 
 // ---- K1: FASTA bytes -> GC bitmask + N bitmask (loaddata.cpp:481-483; readref.cpp:95) ----
 // gcbits/nbits hold nwords = n/64 + 1 words, bit j of word w <-> base 64*w + j, zero beyond n.
+// `fill`: ranges cleared for the kernels that follow in the stream (K1 is the first kernel of a chromosome's chain)
 void launch_fasta_classify(const uint8_t* fasta, int64_t n, uint64_t* gcbits, uint64_t* nbits, int64_t nwords,
-                           hipStream_t stream);
+                           const FillList& fill, hipStream_t stream);
+void launch_fill(const FillList& fill, hipStream_t stream);   // the same clearing as a launch of its own (rare paths)
+// Scratch for the in-kernel folds of the per-workgroup slabs (device_util.h, fold_slabs): group sums of the widest slab.
+// counters: kFoldGroups + 1 arrival counters per kernel, zero before the launch (every launch leaves them zero).
+size_t fold_scratch_bytes();
 // ---- K1b: run boundaries of the N bitmask -> unordered list of (pos << 1 | is_end) ----
 void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
                           hipStream_t stream);
@@ -33,11 +39,11 @@ struct GcAccum {
 // packed = 1: one LDS atomic per base (count and sum in one 64-bit word), valid for depths < 2^21;
 // when the result carries flag bit 1 the caller zeroes acc and launches again with packed = 0.
 // slabs: scratch of gc_hist_slab_bytes(n) bytes (per-workgroup partial results, folded by a second tiny kernel).
+// The last workgroup to finish folds the slabs into acc, adds the last n % 4 bases and builds table[kGcLevels + 1]
+// (level means, then the mean of the positive depths): gccontent.cpp:109-112, 141-145.
 size_t gc_hist_slab_bytes(int64_t n);
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, void* slabs,
-                    hipStream_t stream);
-// folds the slabs into acc and adds the last n % 4 bases; must follow launch_gc_hist
-void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, const void* slabs, hipStream_t stream);
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, int packed, void* slabs,
+                    void* gsum, unsigned int* counters, hipStream_t stream);
 
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
@@ -48,17 +54,15 @@ struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int ne
 // inrange = sum of the counters, lo / hi = smallest / largest value present (lo > hi: none), med = the bucket where the
 // cumulated count first reaches total/2 (-1: never).
 struct ValueMedian { unsigned long long inrange; int32_t lo, hi, med, pad; };
-void launch_value_median(const uint32_t* hist, uint64_t total, ValueMedian* out, hipStream_t stream);
 size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
-// table: kGcLevels level means followed by the mean of the positive depths (launch_gc_table builds it on the device)
-void launch_gc_table(const GcAccum* acc, double* table, hipStream_t stream);
+// table: kGcLevels level means followed by the mean of the positive depths (K2's last workgroup builds it).
+// The last workgroup to finish folds the slabs into hist, fixes the tail quirks of the 20-slice write-back (SURVEY App. A
+// Q2/Q3) in out[] and hist[], adds the last n % 4 bases (which the streaming loop leaves out), walks hist to *vm and
+// copies head_bytes from head_src (device) to head_dst (mapped host memory; NULL: no copy).
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream);
-void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream);   // must follow launch_gc_rescale
-// Must follow launch_gc_rescale: tail quirks of the 20-slice write-back fixed
-// in out[] and hist[], plus the last n % 4 bases, which the streaming kernel leaves out.
-void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                          int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream);
+                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
+                       unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
+                       hipStream_t stream);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
 // (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;
@@ -73,11 +77,18 @@ struct BinAccum {
 // class (compacted index mod 31, or 31 for the tail beyond 31*floor(n'/31)); the chromosome's sum,
 // sum of squares and median all derive from it.
 // slabs: scratch of cap_compact_slab_bytes(...) bytes for the per-workgroup histograms.
+// The last workgroup to finish folds the slabs into res_hist and copies exp_bytes from exp_src (device) to exp_dst
+// (mapped host memory).  cap_compact_overwrites(): every value is below the LDS range (the cap is), res_hist is
+// overwritten and needs no clearing; otherwise it must be zero before the launch.  Region lists of up to kRegInline
+// entries travel in `inl` with the kernel arguments (cbreak / cum may then be NULL).
+constexpr int kRegInline = 48;
+struct K4Regions { long long brk[kRegInline]; long long cum[kRegInline + 1]; };
 size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact);
-void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
+int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact);
+void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
-                            uint32_t* res_hist, BinAccum* acc, void* slabs, hipStream_t stream);
-void launch_cap_compact_fold(int m, int32_t capval, int64_t ncompact, uint32_t* res_hist, const void* slabs, hipStream_t stream);
+                            uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
+                            const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =

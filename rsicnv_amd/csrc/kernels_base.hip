@@ -6,6 +6,7 @@
 // Built with -ffp-contract=off: the only floating-point here is the GC rescale, which must round
 // exactly like the reference's x86-64 SSE2 build.
 #include "kernels.h"
+#include "device_util.h"
 
 namespace rsik {
 
@@ -24,7 +25,8 @@ __device__ inline int lane_id() { return threadIdx.x & 63; }
 // K1  fasta_classify: one thread per 16 bytes; 4 neighbouring lanes assemble one 64-bit word.
 __global__ __launch_bounds__(kThreads) void k_fasta_classify(const uint8_t* __restrict__ fasta, int64_t n,
                                                              uint64_t* __restrict__ gcbits,
-                                                             uint64_t* __restrict__ nbits, int64_t nwords) {
+                                                             uint64_t* __restrict__ nbits, int64_t nwords, FillList fill) {
+  fill_ranges(fill);   // accumulators of the kernels that follow in the stream (first kernel of a chromosome's chain)
   const int64_t nthreads16 = nwords * 4;   // 16-byte groups to cover all words
   for (int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x; g < nthreads16;
        g += (int64_t)gridDim.x * kThreads) {
@@ -260,7 +262,9 @@ constexpr int kGcSlab = 2 * kGcLevels + 4;
 template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict__ depth,
                                                       const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
-                                                      unsigned long long* __restrict__ slabs) {
+                                                      unsigned long long* __restrict__ slabs, unsigned long long* __restrict__ gsum,
+                                                      int per_group, unsigned int* __restrict__ counters,
+                                                      GcAccum* __restrict__ acc, double* __restrict__ table) {
   __shared__ WaveGc s_gc[kThreads / 64];
   __shared__ unsigned long long s_tail[3 * (kThreads / 64)];
   __shared__ unsigned long long s_sum[kGcLevels * kGcRep];
@@ -370,30 +374,131 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
   if (threadIdx.x == 0) {
     unsigned long long ps = 0, pc = 0, fl = 0;
     for (int w = 0; w < kThreads / 64; ++w) { ps += s_tail[3 * w]; pc += s_tail[3 * w + 1]; fl |= s_tail[3 * w + 2]; }
-    slab[2 * kGcLevels] = ps; slab[2 * kGcLevels + 1] = pc; slab[2 * kGcLevels + 2] = fl; slab[2 * kGcLevels + 3] = 0;
+    // the two flags as additive fields (number of workgroups that raised them), so that the fold can sum the slab
+    slab[2 * kGcLevels] = ps; slab[2 * kGcLevels + 1] = pc; slab[2 * kGcLevels + 2] = (fl & 1ull) | ((fl >> 1) << 32); slab[2 * kGcLevels + 3] = 0;
+  }
+  // ---- the last workgroup to finish folds the slabs (device_util.h), adds the ragged last n % 4 bases, which lie in the
+  // stale-window zone i >= n-101 whose count is that of [n-202, n-2] (App. A Q1), and builds the GC table
+  // (gccontent.cpp:109-112, 141-145): level means, the mean of the positive depths where a level is empty or below 1;
+  // table[kGcLevels] = that mean.  No fold launch, no table launch, no host round trip between K2 and K3. ----
+  unsigned long long* total = s_sum;
+  if (!fold_slabs(slabs, gsum, total, kGcSlab, per_group, counters)) return;
+  if (threadIdx.x == 0 && (n & 3) != 0) {
+    int g = 0;
+    for (int64_t i = n - 202; i <= n - 2; ++i) g += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
+    for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
+      const int v = depth[i];
+      total[g] += (unsigned long long)(long long)v;
+      total[kGcLevels + g] += 1ull;
+      if (v > 0) { total[2 * kGcLevels] += (unsigned long long)v; total[2 * kGcLevels + 1] += 1ull; }
+      if (v < 0) total[2 * kGcLevels + 2] |= 1ull;
+    }
+  }
+  __syncthreads();
+  const unsigned long long ps = total[2 * kGcLevels], pc = total[2 * kGcLevels + 1], fl = total[2 * kGcLevels + 2];
+  double rdmean = (double)ps;
+  if (pc > 0) rdmean /= (double)pc;
+  for (int g = threadIdx.x; g < kGcLevels; g += kThreads) {
+    const unsigned long long sg = total[g], cg = total[kGcLevels + g];
+    acc->sum[g] = sg; acc->cnt[g] = cg;
+    double t = cg > 0 ? (double)sg / (double)cg : rdmean;
+    if (t < 1) t = rdmean;
+    table[g] = t;
+  }
+  if (threadIdx.x == 0) {
+    acc->possum = ps; acc->poscnt = pc;
+    acc->negatives = ((fl & 0xffffffffull) ? 1u : 0u) | ((fl >> 32) ? 2u : 0u);
+    acc->pad = 0;
+    table[kGcLevels] = rdmean;
   }
 }
 
-// Fold the per-workgroup slabs into GcAccum.  grid.y splits the slabs into groups of kFoldGroup;
-// each thread sums one word over its group (coalesced across threads) and adds the partial sum with
-// one atomic: a few dozen atomics per word instead of thousands.
-constexpr int kFoldGroup = 32;
+// Tail of the 20-slice write-back (gccontent.cpp:156-175; App. A Q2/Q3) and the ragged last quad
+// that the streaming kernel leaves out.  One wave (the last workgroup of K3).  adjust = 0: only the ragged quad's values are
+// added to the histogram (the -NOGC path has no slices).
+__device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                                     const double* __restrict__ table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
+                                     uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
+  // called by wave 0 of one workgroup; lane k handles tail cell k (r <= 19)
+  const double rdmean = adjust ? table[kGcLevels] : 0.0;
+  const int lane = threadIdx.x;
+  const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
+  auto hist_add = [&](int to) {
+    if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
+    else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
+    else atomicOr(&aux->negatives, 1u);
+  };
+  auto hist_sub = [&](int from) {
+    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
+    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
+  };
+  if (!adjust) {
+    if (ragged + lane < n) hist_add(depth[ragged + lane]);
+    return;
+  }
+  const int64_t S = n / 20, r = n - 20 * S;   // r >= n % 4, so the ragged bases are among the last r
+  if (r == 0) return;
+  // fresh edge window [n-201, n-1]: 201 mask bits counted with four ballots
+  int gtail = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int64_t i = n - 201 + 64 * c + lane;
+    const bool bit = i < n && ((gcbits[i >> 6] >> (i & 63)) & 1);
+    gtail += __popcll(__ballot(bit));
+  }
+  // the two groups of cells are disjoint (n-201+k < 20S), and each lane owns one cell of each
+  if (r >= 2 && lane < r) {
+    const int nv = (int)((double)depth[20 * S + lane] * rdmean / table[gtail] + 0.5);
+    const int64_t idx = n - 201 + lane;
+    hist_sub(out[idx]); hist_add(nv);
+    out[idx] = nv;
+  }
+  if (lane < r) {   // the last r bases keep their unadjusted depth
+    const int64_t idx = 20 * S + lane;
+    if (idx < ragged) hist_sub(out[idx]);
+    hist_add(depth[idx]);
+    out[idx] = depth[idx];
+  }
+}
 
-__global__ __launch_bounds__(kThreads) void k_gc_hist_reduce(const unsigned long long* __restrict__ slabs, int nslabs,
-                                                             GcAccum* __restrict__ acc) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= kGcSlab) return;
-  const int k0 = blockIdx.y * kFoldGroup, k1 = k0 + kFoldGroup < nslabs ? k0 + kFoldGroup : nslabs;
-  unsigned long long t = 0;
-  const bool is_flag = e == 2 * kGcLevels + 2;
+// Median walk of partition_stat_tp (wufunctions.cpp:398-420, dy = 1) over hist[kHistValues] for `total` values by one
+// workgroup of NT threads (kHistValues / NT consecutive counters each); the counters were written by other workgroups.
+template <int NT>
+__device__ inline void value_median_block(const uint32_t* __restrict__ hist, unsigned long long total, ValueMedian* __restrict__ out) {
+  __shared__ unsigned long long s_w[NT / 64];
+  __shared__ int s_lo[NT / 64], s_hi[NT / 64], s_med;
+  constexpr int kPer = kHistValues / NT;
+  const int v0 = threadIdx.x * kPer;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long local = 0;
+  int lo = 0x7fffffff, hi = -1;
 #pragma unroll 8
-  for (int k = k0; k < k1; ++k) { const unsigned long long v = slabs[(size_t)k * kGcSlab + e]; t = is_flag ? (t | v) : (t + v); }
-  if (!t) return;
-  if (e < kGcLevels) atomicAdd(&acc->sum[e], t);
-  else if (e < 2 * kGcLevels) atomicAdd(&acc->cnt[e - kGcLevels], t);
-  else if (e == 2 * kGcLevels) atomicAdd(&acc->possum, t);
-  else if (e == 2 * kGcLevels + 1) atomicAdd(&acc->poscnt, t);
-  else if (is_flag) atomicOr(&acc->negatives, (unsigned int)t);
+  for (int i = 0; i < kPer; ++i) {
+    const uint32_t c = ld_cg(hist + v0 + i);
+    local += c;
+    if (c) { lo = v0 + i < lo ? v0 + i : lo; hi = v0 + i; }
+  }
+  unsigned long long incl = local;
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+  int wlo = lo, whi = hi;
+  for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(wlo, d), b = __shfl_xor(whi, d); wlo = a < wlo ? a : wlo; whi = b > whi ? b : whi; }
+  if (lane == 63) s_w[wave] = incl;
+  if (lane == 0) { s_lo[wave] = wlo; s_hi[wave] = whi; }
+  if (threadIdx.x == 0) s_med = -1;
+  __syncthreads();
+  unsigned long long base = 0, all = 0;
+  int glo = 0x7fffffff, ghi = -1;
+  for (int w = 0; w < NT / 64; ++w) { if (w < wave) base += s_w[w]; all += s_w[w]; glo = s_lo[w] < glo ? s_lo[w] : glo; ghi = s_hi[w] > ghi ? s_hi[w] : ghi; }
+  const unsigned long long r2 = total / 2;
+  unsigned long long seen = base + incl - local;
+  if (local != 0 && seen < r2 && seen + local >= r2) {   // the walk's bucket lies in this thread's stretch
+    for (int i = 0; i < kPer; ++i) {
+      const unsigned long long upto = seen + ld_cg(hist + v0 + i);
+      if (seen < r2 && upto >= r2) s_med = v0 + i;
+      seen = upto;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { out->inrange = all; out->lo = glo; out->hi = ghi; out->med = s_med; out->pad = 0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,7 +520,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          int64_t nwords, const double* __restrict__ table /* [kGcLevels] + rdmean */,
                                                          int32_t* __restrict__ out,
                                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
-                                                         unsigned int* __restrict__ hist_slabs) {
+                                                         unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
+                                                         int per_group, unsigned int* __restrict__ counters,
+                                                         ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
+                                                         unsigned int head_bytes) {
   __shared__ GcTile gt;
   __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
   __shared__ double s_table[kGcLevels];
@@ -485,69 +593,22 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
     for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
     hist_slabs[(size_t)blockIdx.x * kValLds + v] = c;
   }
-}
-
-// The last n % 4 bases for K2 (one thread): they lie in the stale-window zone i >= n-101, whose
-// count is that of [n-202, n-2] (App. A Q1).
-__global__ void k_gc_hist_tail(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
-                               GcAccum* __restrict__ acc) {
-  if (blockIdx.x != 0 || threadIdx.x != 0 || (n & 3) == 0) return;
-  int g = 0;
-  for (int64_t i = n - 202; i <= n - 2; ++i) g += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
-  for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
-    const int v = depth[i];
-    atomicAdd(&acc->sum[g], (unsigned long long)(long long)v);
-    atomicAdd(&acc->cnt[g], 1ull);
-    if (v > 0) { atomicAdd(&acc->possum, (unsigned long long)v); atomicAdd(&acc->poscnt, 1ull); }
-    if (v < 0) atomicOr(&acc->negatives, 1u);
-  }
-}
-
-// Tail of the 20-slice write-back (gccontent.cpp:156-175; App. A Q2/Q3) and the ragged last quad
-// that the streaming kernel leaves out.  One thread.  adjust = 0: only the ragged quad's values are
-// added to the histogram (the -NOGC path has no slices).
-__global__ void k_gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
-                                const double* __restrict__ table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
-                                uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
-  if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave; lane k handles tail cell k (r <= 19)
-  const double rdmean = adjust ? table[kGcLevels] : 0.0;
-  const int lane = threadIdx.x;
-  const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
-  auto hist_add = [&](int to) {
-    if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
-    else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
-    else atomicOr(&aux->negatives, 1u);
-  };
-  auto hist_sub = [&](int from) {
-    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
-    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
-  };
-  if (!adjust) {
-    if (ragged + lane < n) hist_add(depth[ragged + lane]);
-    return;
-  }
-  const int64_t S = n / 20, r = n - 20 * S;   // r >= n % 4, so the ragged bases are among the last r
-  if (r == 0) return;
-  // fresh edge window [n-201, n-1]: 201 mask bits counted with four ballots
-  int gtail = 0;
-  for (int c = 0; c < 4; ++c) {
-    const int64_t i = n - 201 + 64 * c + lane;
-    const bool bit = i < n && ((gcbits[i >> 6] >> (i & 63)) & 1);
-    gtail += __popcll(__ballot(bit));
-  }
-  // the two groups of cells are disjoint (n-201+k < 20S), and each lane owns one cell of each
-  if (r >= 2 && lane < r) {
-    const int nv = (int)((double)depth[20 * S + lane] * rdmean / table[gtail] + 0.5);
-    const int64_t idx = n - 201 + lane;
-    hist_sub(out[idx]); hist_add(nv);
-    out[idx] = nv;
-  }
-  if (lane < r) {   // the last r bases keep their unadjusted depth
-    const int64_t idx = 20 * S + lane;
-    if (idx < ragged) hist_sub(out[idx]);
-    hist_add(depth[idx]);
-    out[idx] = depth[idx];
-  }
+  // ---- the last workgroup to finish: folds the slabs into the value histogram, applies the tail quirks of the 20-slice
+  // write-back, walks the histogram to the median apply_cap needs (loaddata.cpp:233) and hands the chromosome's header
+  // (GC accumulators, counters, median, the first N-run entries) to the host through mapped memory: what used to be
+  // three launches and a device -> host copy behind this kernel ----
+  unsigned int* total = s_hist;
+  if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
+  for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
+  __threadfence();
+  __syncthreads();
+  value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
+  __threadfence();
+  __syncthreads();
+  export_words(head_dst, head_src, head_bytes);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -586,7 +647,9 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     const int32_t* __restrict__ src, int64_t n, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
     int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr /* LDS histogram value range, power of two */,
     int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
-    uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc, unsigned int* __restrict__ hist_slabs) {
+    uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc, unsigned int* __restrict__ hist_slabs,
+    unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters, int overwrite,
+    const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t* s_val = reinterpret_cast<int32_t*>(smem);                       // TB*m values (padded to 4)
   const int tile_elems = TB * m;
@@ -594,8 +657,13 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)tile_pad * 4);   // [vr][32]
   __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
-  for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
-  for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  if (nreg <= kRegInline) {   // the short list travels with the kernel arguments: no upload in front of the launch
+    for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
+    for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
+  } else {
+    for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
+    for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  }
   __syncthreads();
   const RegionTable R{cbreak, cum, nreg, s_break, s_cum};
 
@@ -748,19 +816,17 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   // would serialise on them. ----
   unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) slab[e] = s_hist[e];
-}
-
-// out[e] += sum over slabs of slab[e], e < width: grid.y splits the slabs into groups of kFoldGroup,
-// one atomic per (entry, group) with a non-zero partial sum.
-__global__ __launch_bounds__(kThreads) void k_hist_slab_reduce(const unsigned int* __restrict__ slabs, int nslabs, int width,
-                                                               uint32_t* __restrict__ out) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= width) return;
-  const int k0 = blockIdx.y * kFoldGroup, k1 = k0 + kFoldGroup < nslabs ? k0 + kFoldGroup : nslabs;
-  unsigned int t = 0;
-#pragma unroll 8
-  for (int k = k0; k < k1; ++k) t += slabs[(size_t)k * width + e];
-  if (t) atomicAdd(&out[e], t);
+  // ---- the last workgroup to finish folds the slabs into res_hist (device_util.h) and hands the histogram, with the
+  // BinAccum record in front of it, to the host through mapped memory: no fold launch, no device -> host copy.
+  // overwrite: every value is below vr (the cap is), so res_hist needs no clearing beforehand ----
+  if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
+    const unsigned int c = s_hist[e];
+    if (overwrite) res_hist[e] = c; else if (c) atomicAdd(&res_hist[e], c);
+  }
+  __threadfence();
+  __syncthreads();
+  export_words(exp_dst, exp_src, exp_bytes);
 }
 
 inline int grid_for(int64_t items, int per_block) {
@@ -773,124 +839,54 @@ inline int grid_for(int64_t items, int per_block) {
 }  // namespace
 
 void launch_fasta_classify(const uint8_t* fasta, int64_t n, uint64_t* gcbits, uint64_t* nbits, int64_t nwords,
-                           hipStream_t stream) {
+                           const FillList& fill, hipStream_t stream) {
   hipLaunchKernelGGL(k_fasta_classify, dim3(grid_for(nwords * 4, kThreads)), dim3(kThreads), 0, stream, fasta, n, gcbits,
-                     nbits, nwords);
+                     nbits, nwords, fill);
+}
+__global__ __launch_bounds__(kThreads) void k_fill(FillList fill) { fill_ranges(fill); }
+void launch_fill(const FillList& fill, hipStream_t stream) {
+  unsigned long long units = 0;
+  for (int k = 0; k < fill.n; ++k) units += fill.units[k];
+  if (units == 0) return;
+  hipLaunchKernelGGL(k_fill, dim3(grid_for((int64_t)units, kThreads)), dim3(kThreads), 0, stream, fill);
 }
 void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
                           hipStream_t stream) {
   hipLaunchKernelGGL(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
                      count, cap);
 }
-size_t gc_hist_slab_bytes(int64_t n) {
+static int gc_hist_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   int64_t grid = (nsub + 3) / 4;
   if (grid > kMaxGrid) grid = kMaxGrid;
   const int64_t need = (nsub + kGcMaxSubPerWg - 1) / kGcMaxSubPerWg;
   if (grid < need) grid = need;
-  return (size_t)(grid < 1 ? 1 : grid) * kGcSlab * 8;
+  return (int)(grid < 1 ? 1 : grid);
 }
-void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, int packed, void* slabs,
-                    hipStream_t stream) {
-  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
-  const int grid = (int)(gc_hist_slab_bytes(n) / (kGcSlab * 8));
+size_t gc_hist_slab_bytes(int64_t n) { return (size_t)gc_hist_grid(n) * kGcSlab * 8; }
+size_t fold_scratch_bytes() { return (size_t)kFoldGroups * 256 * kResClasses * 4; }   // the widest slab (K4 at vr = 256)
+void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, int packed, void* slabs,
+                    void* gsum, unsigned int* counters, hipStream_t stream) {
+  const int grid = gc_hist_grid(n);
   unsigned long long* sl = static_cast<unsigned long long*>(slabs);
-  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
-  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl);
-  (void)nsub;
-}
-void launch_gc_hist_fold(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, const void* slabs, hipStream_t stream) {
-  const int grid = (int)(gc_hist_slab_bytes(n) / (kGcSlab * 8));
-  hipLaunchKernelGGL(k_gc_hist_reduce, dim3((kGcSlab + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
-                     static_cast<const unsigned long long*>(slabs), grid, acc);
-  if (n & 3) hipLaunchKernelGGL(k_gc_hist_tail, dim3(1), dim3(64), 0, stream, depth, gcbits, n, acc);
+  unsigned long long* gs = static_cast<unsigned long long*>(gsum);
+  const int pg = fold_per_group(grid);
+  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table);
+  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
-// GC table on the device (gccontent.cpp:109-112, 141-145): level means, the mean of the positive depths where a
-// level is empty or below 1; table[kGcLevels] = that mean.  Saves the host round trip between K2 and K3.
-__global__ void k_gc_table(const GcAccum* __restrict__ acc, double* __restrict__ table) {
-  double rdmean = (double)acc->possum;
-  if (acc->poscnt > 0) rdmean /= (double)acc->poscnt;
-  for (int g = threadIdx.x; g < kGcLevels; g += blockDim.x) {
-    double t = acc->cnt[g] > 0 ? (double)acc->sum[g] / (double)acc->cnt[g] : rdmean;
-    if (t < 1) t = rdmean;
-    table[g] = t;
-  }
-  if (threadIdx.x == 0) table[kGcLevels] = rdmean;
-}
-void launch_gc_table(const GcAccum* acc, double* table, hipStream_t stream) {
-  hipLaunchKernelGGL(k_gc_table, dim3(1), dim3(256), 0, stream, acc, table);
-}
 
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, hipStream_t stream) {
+                       int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
+                       unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
+                       hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   const dim3 g(grid), b(kThreads);
   unsigned int* sl = static_cast<unsigned int*>(slabs);
-  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl);
-  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl);
-}
-void launch_gc_rescale_fold(int64_t n, uint32_t* hist, const void* slabs, hipStream_t stream) {
-  const int grid = grid_for(n, kTileBases);
-  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((kValLds + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
-                     static_cast<const unsigned int*>(slabs), grid, kValLds, hist);
-}
-void launch_gc_tail_fixup(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                          int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, hipStream_t stream) {
-  if (!adjust && (n & 3) == 0) return;
-  hipLaunchKernelGGL(k_gc_tail_fixup, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, adjust, out, hist, aux);
-}
-
-// one workgroup of 1024 threads, 64 consecutive counters each
-__global__ __launch_bounds__(1024) void k_value_median(const uint32_t* __restrict__ hist, unsigned long long total,
-                                                       ValueMedian* __restrict__ out) {
-  __shared__ unsigned long long s_w[16];
-  __shared__ int s_lo[16], s_hi[16], s_med;
-  constexpr int kPer = kHistValues / 1024;
-  const int v0 = threadIdx.x * kPer;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long local = 0;
-  int lo = 0x7fffffff, hi = -1;
-  // sixteen 16-byte loads per walk instead of 64 four-byte ones: a wave's load instruction touches 64 cache lines either way
-#pragma unroll 4
-  for (int i = 0; i < kPer / 4; ++i) {
-    const uint4 c4 = *reinterpret_cast<const uint4*>(hist + v0 + 4 * i);
-    const int v = v0 + 4 * i;
-    local += (unsigned long long)c4.x + c4.y + c4.z + c4.w;
-    if (c4.x) { lo = v < lo ? v : lo; hi = v; }
-    if (c4.y) { lo = v + 1 < lo ? v + 1 : lo; hi = v + 1; }
-    if (c4.z) { lo = v + 2 < lo ? v + 2 : lo; hi = v + 2; }
-    if (c4.w) { lo = v + 3 < lo ? v + 3 : lo; hi = v + 3; }
-  }
-  unsigned long long incl = local;
-  for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-  int wlo = lo, whi = hi;
-  for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(wlo, d), b = __shfl_xor(whi, d); wlo = a < wlo ? a : wlo; whi = b > whi ? b : whi; }
-  if (lane == 63) s_w[wave] = incl;
-  if (lane == 0) { s_lo[wave] = wlo; s_hi[wave] = whi; }
-  if (threadIdx.x == 0) s_med = -1;
-  __syncthreads();
-  unsigned long long base = 0, all = 0;
-  int glo = 0x7fffffff, ghi = -1;
-  for (int w = 0; w < 16; ++w) { if (w < wave) base += s_w[w]; all += s_w[w]; glo = s_lo[w] < glo ? s_lo[w] : glo; ghi = s_hi[w] > ghi ? s_hi[w] : ghi; }
-  const unsigned long long r2 = total / 2;
-  unsigned long long seen = base + incl - local;
-#pragma unroll 4
-  for (int i = 0; i < kPer / 4; ++i) {
-    const uint4 c4 = *reinterpret_cast<const uint4*>(hist + v0 + 4 * i);
-    const uint32_t q[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned long long upto = seen + q[k];
-      if (seen < r2 && upto >= r2) s_med = v0 + 4 * i + k;
-      seen = upto;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) { out->inrange = all; out->lo = glo; out->hi = ghi; out->med = s_med; out->pad = 0; }
-}
-void launch_value_median(const uint32_t* hist, uint64_t total, ValueMedian* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_value_median, dim3(1), dim3(1024), 0, stream, hist, (unsigned long long)total, out);
+  unsigned int* gs = static_cast<unsigned int*>(gsum);
+  const int pg = fold_per_group(grid);
+  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes);
+  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes);
 }
 
 static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {
@@ -906,9 +902,15 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact) {
   k4_geometry(m, capval, ncompact, TB, vr, grid);
   return (size_t)grid * vr * kResClasses * 4;
 }
-void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, int nreg,
+int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact) {
+  int TB, vr, grid;
+  k4_geometry(m, capval, ncompact, TB, vr, grid);
+  return capval < vr ? 1 : 0;
+}
+void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
-                            uint32_t* res_hist, BinAccum* acc, void* slabs, hipStream_t stream) {
+                            uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
+                            const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
   int TB, vr, grid;
   k4_geometry(m, capval, ncompact, TB, vr, grid);
   const size_t tile_pad = ((size_t)TB * m + 3) & ~(size_t)3;
@@ -917,21 +919,18 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   const int maxv = (quads + kThreads - 1) / kThreads;          // 16-byte loads per thread and tile
   const int parts = kThreads / TB, ept = (m + parts - 1) / parts;   // values per thread in the median phase
   unsigned int* sl = static_cast<unsigned int*>(slabs);
+  unsigned int* gs = static_cast<unsigned int*>(gsum);
+  const int pg = fold_per_group(grid);
+  const int overwrite = capval < vr ? 1 : 0;
 #define RSI_K4(MV, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin<MV, EP>));                                                            \
     hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
-                       ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl); } while (0)
+                       ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl, gs, pg, counters, overwrite,              \
+                       exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
   else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)
   else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile
   else RSI_K4(13, 0);
 #undef RSI_K4
-}
-void launch_cap_compact_fold(int m, int32_t capval, int64_t ncompact, uint32_t* res_hist, const void* slabs, hipStream_t stream) {
-  int TB, vr, grid;
-  k4_geometry(m, capval, ncompact, TB, vr, grid);
-  const int width = vr * kResClasses;
-  hipLaunchKernelGGL(k_hist_slab_reduce, dim3((width + kThreads - 1) / kThreads, (grid + kFoldGroup - 1) / kFoldGroup), dim3(kThreads), 0, stream,
-                     static_cast<const unsigned int*>(slabs), grid, width, res_hist);
 }
 
 }  // namespace rsik

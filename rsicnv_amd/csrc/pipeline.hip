@@ -587,27 +587,39 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   HIPCHK(ctx->gcbits.ensure((size_t)nwords * 8));
   HIPCHK(ctx->nbits.ensure((size_t)nwords * 8));
   HIPCHK(ctx->hist_val.ensure((size_t)kHistValues * 4));
+  HIPCHK(ctx->gsum.ensure(fold_scratch_bytes()));
+  static_assert(sizeof(BinAccum) <= kResHead, "BinAccum outgrew its header");
+  HIPCHK(ctx->hist_res.ensure(kResHead + (size_t)kHistValues * kResClasses * 4));
   uint8_t* small = ctx->small.as<uint8_t>();
+  unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone);   // arrival counters: K2, K3, K4
   ph_a1a.stop();
   Phase ph_a1b(ctx, "a1b.launch K1-K3");
-  HIPCHK(hipMemsetAsync(small, 0, kHeaderBytes, st));
+  const bool want_cap = P.cap > 1;
 
   // ---- A1-A4 are issued back to back: GC mask and N runs (K1, K1b), GC table and rescale (K2, K3), the cap
-  // median walk.  The GC table is built on the device, so nothing in this chain needs the host; the N-run list,
-  // the GC accumulators (for the checks and the log) and the median come back in ONE round trip. ----
+  // median walk.  K1 clears the accumulators of everything behind it, K2's last workgroup builds the GC table, K3's
+  // last workgroup walks the value histogram to the median and writes the header (N-run list, GC accumulators for the
+  // checks and the log, median) into the pinned mailbox: four launches, no memset, no copy, ONE round trip. ----
   uint32_t* d_ncount = reinterpret_cast<uint32_t*>(small + kOffCounters) + 5;
-  { Timer t(ctx, "fasta_classify", true); launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, st); }
+  {
+    FillList fl{};
+    fill_add(fl, small, kHeaderBytes, 0u);
+    if (P.gcadjust || want_cap) fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
+    fill_add(fl, ctx->hist_res.p, kResHead, 0u);   // BinAccum of K4
+    Timer t(ctx, "fasta_classify", true);
+    launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, fl, st);
+  }
   uint64_t* d_ntrans = reinterpret_cast<uint64_t*>(small + kOffNtrans);
   { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, st); }
   constexpr uint32_t kEagerRuns = 1024;
   uint32_t n_trans = 0;
   std::vector<uint64_t> trans_raw(kEagerRuns);
-  // the header (accumulators, counters, median) and the first entries of the N-run list: one transfer at the end of the chain
-  std::vector<unsigned char> head(kHeaderBytes + (size_t)kEagerRuns * 8);
+  // the header (accumulators, counters, median) and the first entries of the N-run list: one block, written by the last kernel of the chain
+  const size_t head_bytes = kHeaderBytes + (size_t)kEagerRuns * 8;
+  unsigned char* head = static_cast<unsigned char*>(mb_alloc(ctx, head_bytes));
+  if (!head) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
 
   const int32_t* d_src = d_depth;
-  const bool want_cap = P.cap > 1;
-  if (P.gcadjust || want_cap) HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
   ValueHistAux* d_aux = reinterpret_cast<ValueHistAux*>(small + kOffValAux);
   GcAccum* d_acc = reinterpret_cast<GcAccum*>(small + kOffGcAcc);
   double* d_table = reinterpret_cast<double*>(small + kOffTable);
@@ -620,32 +632,23 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // then issued once more with the two-atomic form
   auto issue_gc_chain = [&](int packed) -> int {
     if (P.gcadjust) {
-      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, packed, ctx->slabs.p, st); }
-      { Timer t(ctx, "gc_hist_fold"); launch_gc_hist_fold(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, ctx->slabs.p, st); }
-      { Timer t(ctx, "gc_table"); launch_gc_table(d_acc, d_table, st); }
+      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, st); }
       HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-      { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
-      { Timer t(ctx, "gc_rescale_fold"); launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st); }
-      { Timer t(ctx, "gc_tail_fixup"); launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, st); }
+      { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
     } else if (want_cap) {
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, st); }
-      launch_gc_rescale_fold(n, ctx->hist_val.as<uint32_t>(), ctx->slabs.p, st);
-      launch_gc_tail_fixup(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, st);
+      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+    } else {
+      HIPCHK(copy_d2h(ctx, head, small, head_bytes));   // no kernel behind K1b to hand the header over: a plain copy
     }
-    if (want_cap) {
-      // the median walk runs on the device (one small workgroup): 24 bytes come back instead of the 256 KB histogram
-      { Timer t(ctx, "value_median"); launch_value_median(ctx->hist_val.as<uint32_t>(), (uint64_t)n, d_vm, st); }
-    }
-    HIPCHK(copy_d2h(ctx, head.data(), small, head.size()));
     return RSI_OK;
   };
   auto unpack_head = [&]() {
-    memcpy(&acc, head.data() + kOffGcAcc, sizeof(acc));
-    memcpy(&aux, head.data() + kOffValAux, sizeof(aux));
-    memcpy(&vm, head.data() + kOffValMedian, sizeof(vm));
-    memcpy(&n_trans, head.data() + kOffCounters + 5 * 4, 4);
-    memcpy(trans_raw.data(), head.data() + kOffNtrans, (size_t)kEagerRuns * 8);
+    memcpy(&acc, head + kOffGcAcc, sizeof(acc));
+    memcpy(&aux, head + kOffValAux, sizeof(aux));
+    memcpy(&vm, head + kOffValMedian, sizeof(vm));
+    memcpy(&n_trans, head + kOffCounters + 5 * 4, 4);
+    memcpy(trans_raw.data(), head + kOffNtrans, (size_t)kEagerRuns * 8);
   };
   // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
   if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), gc_rescale_slab_bytes(n))));
@@ -656,9 +659,11 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   unpack_head();
   if (P.gcadjust && (acc.negatives & 2u)) {
     Phase ph_w(ctx, "a2-3.gc wide redo");
-    HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(GcAccum), st));
-    HIPCHK(hipMemsetAsync(ctx->hist_val.p, 0, (size_t)kHistValues * 4, st));
-    HIPCHK(hipMemsetAsync(d_aux, 0, sizeof(ValueHistAux), st));
+    FillList fl{};
+    fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
+    fill_add(fl, d_aux, 16, 0u);
+    static_assert(sizeof(ValueHistAux) == 16, "ValueHistAux is cleared as one 16-byte unit");
+    launch_fill(fl, st);
     if ((rc = issue_gc_chain(0)) != RSI_OK) return rc;
     HIPCHK(CTX_SYNC());
     unpack_head();
@@ -731,7 +736,12 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   if (ncompact <= 0 || nb < 8) return fail(ctx, RSI_ERR_TOO_SMALL, "nothing left after removing N regions");
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  {   // cbreak[4100] | cum: one upload
+  K4Regions inl;
+  memset(&inl, 0, sizeof(inl));
+  if ((int)noncode.size() <= kRegInline) {   // the usual case: the list rides with the kernel arguments
+    for (size_t k = 0; k < cbreak.size(); ++k) inl.brk[k] = cbreak[k];
+    for (size_t k = 0; k < cum.size(); ++k) inl.cum[k] = cum[k];
+  } else {   // cbreak[4100] | cum: one upload
     std::vector<int64_t> both((size_t)4100 + cum.size(), 0);
     std::copy(cbreak.begin(), cbreak.end(), both.begin());
     std::copy(cum.begin(), cum.end(), both.begin() + 4100);
@@ -740,19 +750,23 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   HIPCHK(ctx->rdc.ensure((size_t)(ncompact + 4) * 4));
   HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
   HIPCHK(ctx->binsum.ensure((size_t)nb * 8));
-  static_assert(sizeof(BinAccum) <= kResHead, "BinAccum outgrew its header");
-  HIPCHK(ctx->hist_res.ensure(kResHead + (size_t)kHistValues * kResClasses * 4));
   const size_t res_vals = want_cap && capval < kHistValues - 1 ? (size_t)std::max(capval, 0) + 1 : (size_t)kHistValues;
-  HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, kResHead + res_vals * kResClasses * 4, st));
   BinAccum* d_bacc = reinterpret_cast<BinAccum*>(ctx->hist_res.p);
   uint32_t* d_res = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead);
+  // K4's last workgroup folds the per-workgroup histograms and writes [BinAccum | histogram] into the mailbox.  With the
+  // cap below the kernel's LDS value range the fold overwrites res_hist (nothing to clear); otherwise (no cap, or a cap
+  // of 256 and more) stray values reach res_hist through global atomics and it is cleared first.
+  const size_t exp_bytes = kResHead + res_vals * kResClasses * 4;
+  const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact) != 0;
+  if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
+  uint32_t* exp_slot = exp_bytes <= kMailboxMaxCopy ? static_cast<uint32_t*>(mb_alloc(ctx, exp_bytes)) : nullptr;
   HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
-  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, st); }
-  { Timer t(ctx, "cap_compact_fold"); launch_cap_compact_fold(P.m, capval, ncompact, d_res, ctx->slabs.p, st); }
+  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st); }
   BinAccum bacc;
   std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);
-  HIPCHK(copy_d2h(ctx, hres_all.data(), ctx->hist_res.p, hres_all.size() * 4));
+  if (!exp_slot) HIPCHK(copy_d2h(ctx, hres_all.data(), ctx->hist_res.p, hres_all.size() * 4));
   HIPCHK(CTX_SYNC());
+  if (exp_slot) memcpy(hres_all.data(), exp_slot, exp_bytes);
   memcpy(&bacc, hres_all.data(), sizeof(bacc));
   const uint32_t* hres = hres_all.data() + kResHead / 4;
   if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");

@@ -148,6 +148,7 @@ struct rsi_ctx {
   int64_t n_in = 0;                          // length of the depth currently in in_depth
   DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
+  DevBuf gsum;    // group sums of the in-kernel slab folds (device_util.h)
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64, cand_mid, cand_hist;   // candidate tests on the device (kernels_cand.hip)
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
@@ -214,7 +215,13 @@ inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
 constexpr size_t kMailboxBytes = size_t(8) << 20, kMailboxMaxCopy = size_t(512) << 10;
 inline void* mb_alloc(rsi_ctx* ctx, size_t bytes) {
   if (!ctx->mailbox) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), kMailboxBytes, hipHostMallocDefault) != hipSuccess) { ctx->mailbox = nullptr; return nullptr; }
+    // mapped + coherent: kernels write small results straight into it (device_util.h, export_words), visible to the host
+    // once the stream has passed the kernel
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), kMailboxBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { ctx->mailbox = nullptr; return nullptr; }
+    void* dev_view = nullptr;
+    if (hipHostGetDevicePointer(&dev_view, ctx->mailbox, 0) != hipSuccess || dev_view != (void*)ctx->mailbox) {   // unified addressing: same pointer
+      (void)hipHostFree(ctx->mailbox); ctx->mailbox = nullptr; return nullptr;
+    }
     ctx->mb_cap = kMailboxBytes;
   }
   const size_t need = (bytes + 63) & ~size_t(63);
@@ -259,7 +266,9 @@ constexpr size_t kOffMinMax = 4608;                               // MinMaxF
 constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
 constexpr size_t kOffRawMin = 5120;                               // uint32
 constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
-constexpr size_t kHeaderBytes = 5376;                             // everything above: zeroed at the start of a run, fetched in one copy
+constexpr size_t kOffDone = 5376;                                 // arrival counters of the in-kernel folds: kDoneStride uint32 per kernel
+constexpr size_t kDoneStride = 48;                                // >= kFoldGroups + 1
+constexpr size_t kHeaderBytes = 6400;                             // everything above: cleared by the first kernel of a run (K1), handed to the host as one block
 constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:
                                                                   // the header and the first entries travel as one transfer
