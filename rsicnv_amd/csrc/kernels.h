@@ -95,28 +95,42 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
 // complement of the smallest order key over the bins (atomicMax; zero on entry = nothing seen).
 void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, double r, float* raw,
                    uint32_t* rawmin_bits, hipStream_t stream);
-// x = (float)(raw - tmin); x = (float)(x / med_nbt * med); bins 0..2 <- lev[0..2]
-void launch_nb_scale(float* x, int64_t nb, double tmin, double med_nbt, double med, float lev0, float lev1, float lev2,
-                     hipStream_t stream);
-void launch_i32_to_f32(const int32_t* in, float* out, int64_t nb, hipStream_t stream);
-
 // ---- K6: 0.01-grid histogram quantiles of float arrays (partition_stat_tp, wufunctions.cpp:364) ----
 // min_inv = complement of the smallest order key seen, max_bits = largest key; all zero = nothing seen yet
 struct MinMaxF { uint32_t min_inv, max_bits; unsigned int nonfinite; unsigned int pad; };
+// The whole median as a chain of two launches (min/max + grid plan by the last workgroup -> histogram + walk by the last
+// workgroup); `out` receives the result, or the flag of the first test that failed.
+struct GridMedian { double med, ymin; unsigned long long count; uint32_t np, flags; };
+enum { kGridEmpty = 1, kGridNonFinite = 2, kGridDegenerate = 4, kGridTooWide = 8 };
+// Shared state of a context's chains: mm holds "nothing seen" (all zero) before a chain and again after it; hist has cap
+// entries; counters: two arrival counters (plan, walk), zero before and after.
+struct GridChain { MinMaxF* mm; uint32_t* hist; uint32_t cap; unsigned int* counters; };
+// what the last workgroup of launch_hist_walk copies to mapped host memory (NULL dst: nothing)
+struct GridExport { const void* src[2]; void* dst[2]; size_t bytes[2]; };
+
+// x = (float)(raw - tmin); x = (float)(x / med_nbt * med); bins 0..2 <- the three reference levels (rsi.cpp:1176-1185), where
+// tmin is the minimum launch_nb_raw left in *rawmin_bits and med_raw / del_raw / dup_raw are the transform of the median,
+// half and one-and-a-half times the median depth computed by the host (the kernel and the host derive the scaled levels
+// with the same IEEE operations).  The values' min/max are taken on the way and the last workgroup plans the median's grid
+// into *out: first link of a chain, continue with launch_hist_walk.
+void launch_nb_scale_minmax(float* x, int64_t nb, const uint32_t* rawmin_bits, double med_raw, double del_raw, double dup_raw,
+                            double RDmedian, const GridChain& c, GridMedian* out, hipStream_t stream);
+// -MED: out_f = (float)in, min/max of |out_f - center| taken on the way (first link of the MAD chain)
+void launch_i32_to_f32_minmax(const int32_t* in, float* out_f, int64_t nb, double center, const GridChain& c, GridMedian* out,
+                              hipStream_t stream);
 // min/max over x[i] (or |x[i]-center| rounded to float when use_abs), restricted to mask[i]==0 when mask != NULL
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
                        hipStream_t stream);
 // hist[(size_t)((v - ymin)/0.01 + 0.5)] += 1, same selection as above; hist has np entries
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin,
                      uint32_t* hist, uint32_t np, hipStream_t stream);
-
-// The whole median as one chain of launches (min/max -> plan -> histogram -> walk); `out` receives the result, or the
-// flag of the first test that failed.  d_center != NULL: the centre is read from device memory (an earlier chain's `med`).
-// `mm` must hold the "nothing seen" record on entry (all zero) and does again on exit; hist has cap entries.
-struct GridMedian { double med, ymin; unsigned long long count; uint32_t np, flags; };
-enum { kGridEmpty = 1, kGridNonFinite = 2, kGridDegenerate = 4, kGridTooWide = 8 };
-void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
-                        MinMaxF* mm, uint32_t* hist, uint32_t cap, GridMedian* out, hipStream_t stream);
+// first link: min/max of the selection, grid planned into *out.  d_center != NULL: the centre is read from device memory
+// (an earlier chain's `med`).
+void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                        const GridChain& c, GridMedian* out, hipStream_t stream);
+// second link: histogram on the planned grid, median into *out; then the export, and `fill` for the kernels behind it
+void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                      const GridChain& c, GridMedian* out, const GridExport* ex, const FillList* fill, hipStream_t stream);
 
 // ---- K7: RSI scan (rsistatus, rsi.cpp:1191-1259; runmeantp wufunctions.cpp:573-647) ----
 struct ScanParams {
@@ -133,35 +147,45 @@ constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable e
 // sum <= thr_del[L], a DUP hit iff sum >= thr_dup[L] (host-derived, see scan_thresholds()).
 // first_del / first_dup: smallest L that marks the bin, 0xffffffff when none.  counters[0] = trim
 // escapes, counters[1] = values breaking the exact-sum precondition.
+constexpr int kThrInline = 232;   // thresholds that fit the kernel arguments: Lmax + 1 + kScanPad <= kThrInline
+struct ScanThr { double del[kThrInline]; double dup[kThrInline]; };
+// inl != NULL: thresholds in the kernel arguments (thr_del / thr_dup unused)
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del,
-                     const double* thr_dup, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
+                     const double* thr_dup, const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
                      hipStream_t stream);
-// histogram of first_del over L (hist[L], L <= Lmax); bins with exclude[j] <= *exclude_max are left out
-void launch_level_hist(const uint32_t* first, const uint32_t* exclude, const uint32_t* exclude_max, int64_t nb, int32_t Lmax,
-                       uint32_t* hist, hipStream_t stream);
-// *level = the L a sweep stops at (first L with more than a fifth of the bins marked, else Lmax)
-void launch_stop_level(const uint32_t* hist, int32_t Lmax, int64_t nb, uint32_t* level, hipStream_t stream);
-// status[j] = -first_del[j] if first_del[j] <= levels[0]; else +first_dup[j] if <= levels[1]; else 0
-void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels,
-                           int64_t nb, int32_t* status, hipStream_t stream);
+// Stop levels of the two sweeps (rsi.cpp:1225, 1255; DEL marks win, App. A Q14) in one launch.
+// work: [16 uint32: escapes, inexact (the scan's), ldel, ldup, both-count, ...][hist_del kMaxLevels][hist_dup kMaxLevels], zero
+// before the scan; both: scratch for kBothCap (first_del, first_dup) pairs.  The last workgroup copies host_bytes of work to
+// host_copy (mapped host memory).
+constexpr int kMaxLevels = 2064;
+constexpr size_t kScanWorkBytes = 64 + 2 * (size_t)kMaxLevels * 4;
+void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
+                       unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream);
+// status[j] = -first_del[j] if first_del[j] <= levels[0]; else +first_dup[j] if <= levels[1]; else 0; copy (may be NULL)
+// receives the same.  Run boundaries appended unordered to runs as (pos << 1 | is_end), *count entries (zero before);
+// host_copy (may be NULL): [count, 0][first host_entries entries] written by the last workgroup.
+void launch_resolve_runs(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb, int32_t* status,
+                         int32_t* copy, uint64_t* runs, uint32_t* count, uint32_t cap, unsigned int* counter, void* host_copy,
+                         uint32_t host_entries, hipStream_t stream);
 
 // ---- K9/K10: marked runs and max-score sub-segment (get_continuous_segments rsi.cpp:291;
 //      get_rsi_segments rsi.cpp:1060) ----
-// run starts/ends appended unordered: list entries (start << 32 | end), count
-void launch_find_runs(const int32_t* status, int64_t nb, uint64_t* runs, uint32_t* count, uint32_t cap,
-                      hipStream_t stream);
 struct BestSeg { double score; int32_t start; int32_t len; };
 struct SegItem { int32_t run; int32_t len; int32_t Lbeg; int32_t Lend; };   // lengths [Lbeg, Lend) of one run
+// Short run / item lists ride in the kernel arguments (the pointer forms are for longer ones).
+constexpr int kRunsInline = 200, kItemsInline = 150;
+struct RunsInline { int32_t se[2 * kRunsInline]; int32_t off[kRunsInline]; };     // (start, end) pairs; prefix offsets
+struct ItemsInline { SegItem it[kItemsInline]; int32_t off[kRunsInline]; };
 // exact double prefix of every run into scratch + poff[run] (len+1 entries), one workgroup per run
-void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, int nruns, const int64_t* poff,
-                       double* scratch, hipStream_t stream);
+void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns,
+                       const int64_t* poff, double* scratch, hipStream_t stream);
 // one workgroup per work item; out[item] = best (score, offset, L) of that item under the
-// reference's visiting order (larger score, then smaller L, then smaller offset)
-void launch_best_items(const void* items, int nitems, const int64_t* poff, const double* scratch, double tmedian, BestSeg* out,
-                       hipStream_t stream);
+// reference's visiting order (larger score, then smaller L, then smaller offset); out may be mapped host memory
+void launch_best_items(const void* items, const ItemsInline* inl, int nitems, const int64_t* poff, const double* scratch,
+                       double tmedian, BestSeg* out, hipStream_t stream);
 // edge trimming of filterstatus (rsi.cpp:1023-1044): one thread per run
-void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, int nruns,
-                      double delthr, double addthr, hipStream_t stream);
+void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl,
+                      int nruns, double delthr, double addthr, hipStream_t stream);
 
 // Dynamic LDS beyond 48 KB has to be allowed per kernel.  Done once per kernel and for all the CU has left next to the
 // kernel's static use: a per-launch setting from several host threads (a pool) would race with the other threads' launches.

@@ -6,6 +6,7 @@
 // Built with -ffp-contract=off and IEEE division/sqrt: every double expression below has to round
 // like the reference's x86-64 build.
 #include "kernels.h"
+#include "device_util.h"
 
 namespace rsik {
 
@@ -59,25 +60,6 @@ __global__ __launch_bounds__(kThreads) void k_nb_raw(const int64_t* __restrict__
   }
 }
 
-// rsi.cpp:1176-1185: subtract the minimum, rescale to the depth scale, overwrite bins 0..2
-__global__ __launch_bounds__(kThreads) void k_nb_scale(float* __restrict__ x, int64_t nb, double tmin, double med_nbt,
-                                                       double med, float lev0, float lev1, float lev2) {
-  for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < nb; b += (int64_t)gridDim.x * kThreads) {
-    float v = x[b];
-    v = (float)((double)v - tmin);
-    v = (float)((double)v / med_nbt * med);
-    if (b == 0) v = lev0;
-    if (b == 1) v = lev1;
-    if (b == 2) v = lev2;
-    x[b] = v;
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void k_i32_to_f32(const int32_t* __restrict__ in, float* __restrict__ out, int64_t nb) {
-  for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < nb; b += (int64_t)gridDim.x * kThreads)
-    out[b] = (float)in[b];
-}
-
 // ------------------------------------------------------------------------------------------
 // K6  quantile histograms of float arrays on the 0.01 grid (partition_stat_tp, wufunctions.cpp:364-424)
 __device__ inline float sel_value(const float* __restrict__ x, int64_t i, int use_abs, double center) {
@@ -116,13 +98,6 @@ __global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict
                                                          int64_t nb, int use_abs, double center, MinMaxF* __restrict__ mm) {
   minmax_body(x, mask, nb, use_abs, center, mm);
 }
-// the same with the centre taken from an earlier link of a device-side chain (the median just found)
-__global__ __launch_bounds__(kThreads) void k_minmax_f32_at(const float* __restrict__ x, const int32_t* __restrict__ mask,
-                                                            int64_t nb, int use_abs, const double* __restrict__ center,
-                                                            MinMaxF* __restrict__ mm) {
-  minmax_body(x, mask, nb, use_abs, *center, mm);
-}
-
 constexpr uint32_t kLdsBins = 32768;   // 128 KB of LDS counters (one workgroup per CU): covers a value range of 327
 
 // Each thread takes kHistRun consecutive elements and merges equal neighbouring buckets before the
@@ -165,19 +140,20 @@ __global__ __launch_bounds__(kThreads) void k_hist_f32(const float* __restrict__
   hist_body(x, mask, nb, use_abs, center, ymin, hist, np, use_lds, s_h);
 }
 
-// ---- the same median as one device-side chain: min/max -> plan -> histogram -> walk, nothing returns to the
-// host in between; a second chain can take its centre from the first one's result (median, then MAD) ----
+// ---- the same median as a device-side chain of TWO launches: (min/max, and the last workgroup to finish derives the
+// grid and clears its buckets) -> (histogram, and the last workgroup walks it to the median).  Nothing returns to the
+// host in between; a second chain takes its centre from the first one's result (median, then MAD).  The tests and
+// their order are grid_median()'s (pipeline.hip). ----
 __device__ inline float f32_unkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// Every workgroup derives the grid (anchor, number of buckets) from the min/max record and clears its share of the
-// buckets; the first one publishes the plan.  The tests and their order are grid_median()'s (pipeline.hip).
-__global__ __launch_bounds__(kThreads) void k_grid_plan(const MinMaxF* __restrict__ mm, uint32_t cap, uint32_t* __restrict__ hist,
-                                                        GridMedian* __restrict__ g) {
-  const uint32_t kmin = ~mm->min_inv, kmax = mm->max_bits;
+// one workgroup, after every min/max atomic of the launch has landed: anchor and bucket count -> *g, buckets cleared,
+// the min/max record back to "nothing seen"
+__device__ inline void grid_plan_block(MinMaxF* __restrict__ mm, uint32_t cap, uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
+  const uint32_t kmin = ~ld_cg(&mm->min_inv), kmax = ld_cg(&mm->max_bits), bad = ld_cg(&mm->nonfinite);
   uint32_t flags = 0, np = 0;
   double ymin = 0.0;
   if (kmin == 0xffffffffu) flags = kGridEmpty;
-  else if (mm->nonfinite) flags = kGridNonFinite;
+  else if (bad) flags = kGridNonFinite;
   else {
     ymin = (double)f32_unkey(kmin);
     const double ymax = (double)f32_unkey(kmax);
@@ -187,45 +163,146 @@ __global__ __launch_bounds__(kThreads) void k_grid_plan(const MinMaxF* __restric
       if (n > cap) flags = kGridTooWide; else np = (uint32_t)n;
     }
   }
-  for (uint32_t e = blockIdx.x * kThreads + threadIdx.x; e < np; e += gridDim.x * kThreads) hist[e] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { g->med = 0.0; g->ymin = ymin; g->count = 0; g->np = np; g->flags = flags; }
+  for (uint32_t e = threadIdx.x; e < np; e += kThreads) hist[e] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g->med = 0.0; g->ymin = ymin; g->count = 0; g->np = np; g->flags = flags;
+    mm->min_inv = 0; mm->max_bits = 0; mm->nonfinite = 0;
+  }
 }
 
-__global__ __launch_bounds__(kThreads) void k_hist_f32_planned(const float* __restrict__ x, const int32_t* __restrict__ mask,
-                                                               int64_t nb, int use_abs, double center,
-                                                               const double* __restrict__ center_ptr,
-                                                               const GridMedian* __restrict__ g, uint32_t* __restrict__ hist) {
-  extern __shared__ unsigned int s_h[];
-  if (g->flags) return;
-  const uint32_t np = g->np;
-  hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, np <= kLdsBins, s_h);
+// min/max of a workgroup's values -> the record (one set of atomics per workgroup)
+__device__ inline void minmax_commit(uint32_t kmin, uint32_t kmax, unsigned int bad, MinMaxF* __restrict__ mm) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; bad |= __shfl_xor(bad, d);
+  }
+  __shared__ uint32_t s_min[kThreads / 64], s_max[kThreads / 64], s_bad[kThreads / 64];
+  if (lane_id() == 0) { s_min[threadIdx.x >> 6] = kmin; s_max[threadIdx.x >> 6] = kmax; s_bad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) { kmin = s_min[w] < kmin ? s_min[w] : kmin; kmax = s_max[w] > kmax ? s_max[w] : kmax; bad |= s_bad[w]; }
+    if (kmin != 0xffffffffu) atomicMax(&mm->min_inv, ~kmin);
+    if (kmax != 0) atomicMax(&mm->max_bits, kmax);
+    if (bad) atomicOr(&mm->nonfinite, 1u);
+  }
 }
 
-// hist_median_grid (hostmath.h) by one workgroup: the bucket in which the running count first reaches total/2.
-// Leaves the min/max record ready for the next chain.
-__global__ __launch_bounds__(kThreads) void k_grid_walk(const uint32_t* __restrict__ hist, GridMedian* __restrict__ g,
-                                                        MinMaxF* __restrict__ mm) {
+__global__ __launch_bounds__(kThreads) void k_minmax_plan(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                          int64_t nb, int use_abs, double center, const double* __restrict__ center_ptr,
+                                                          MinMaxF* __restrict__ mm, unsigned int* __restrict__ counter, uint32_t cap,
+                                                          uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
+  const double c = center_ptr ? *center_ptr : center;
+  uint32_t kmin = 0xffffffffu, kmax = 0;
+  unsigned int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
+    if (mask && mask[i] != 0) continue;
+    const float v = sel_value(x, i, use_abs, c);
+    if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+    const uint32_t k = f32_key(v);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  }
+  minmax_commit(kmin, kmax, bad, mm);
+  if (last_block_done(counter)) grid_plan_block(mm, cap, hist, g);
+}
+
+// What the host picks up after a chain: results and scalars that sit in one block of device memory, copied to mapped host
+// memory by the chain's last workgroup.
+struct ExportPair { const void* src[2]; void* dst[2]; unsigned int bytes[2]; };
+
+// hist_median_grid (hostmath.h) by one workgroup: the bucket in which the running count first reaches total/2
+__device__ inline void grid_walk_block(const uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
   __shared__ unsigned long long s_sum[kThreads];
-  if (threadIdx.x == 0) { mm->min_inv = 0; mm->max_bits = 0; mm->nonfinite = 0; }
-  if (g->flags) return;
   const uint32_t np = g->np;
   const uint32_t chunk = (np + kThreads - 1) / kThreads;
   const uint32_t b0 = threadIdx.x * chunk < np ? threadIdx.x * chunk : np;
   const uint32_t b1 = b0 + chunk < np ? b0 + chunk : np;
   unsigned long long mine = 0;
-  for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
+  for (uint32_t b = b0; b < b1; ++b) mine += ld_cg(hist + b);
   s_sum[threadIdx.x] = mine;
   __syncthreads();
   unsigned long long seen = 0, total = 0;
   for (int t = 0; t < kThreads; ++t) { const unsigned long long v = s_sum[t]; if (t < (int)threadIdx.x) seen += v; total += v; }
   const unsigned long long r2 = total / 2;
   if (threadIdx.x == 0) { g->count = total; if (r2 == 0) g->med = g->ymin; }
-  if (r2 == 0) return;
-  for (uint32_t b = b0; b < b1; ++b) {
-    const unsigned long long upto = seen + hist[b];
-    if (seen < r2 && upto >= r2) g->med = g->ymin + (double)b * 0.01;
-    seen = upto;
+  if (r2 != 0 && mine != 0 && seen < r2 && seen + mine >= r2) {
+    for (uint32_t b = b0; b < b1; ++b) {
+      const unsigned long long upto = seen + ld_cg(hist + b);
+      if (seen < r2 && upto >= r2) g->med = g->ymin + (double)b * 0.01;
+      seen = upto;
+    }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                        int64_t nb, int use_abs, double center,
+                                                        const double* __restrict__ center_ptr,
+                                                        GridMedian* __restrict__ g, uint32_t* __restrict__ hist,
+                                                        unsigned int* __restrict__ counter, ExportPair ex, FillList fill) {
+  extern __shared__ unsigned int s_h[];
+  fill_ranges(fill);   // for the kernels behind this one (the scan's first-L arrays, its counters)
+  if (!g->flags) {
+    const uint32_t np = g->np;
+    hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, np <= kLdsBins, s_h);
+  }
+  if (!last_block_done(counter)) return;
+  if (!g->flags) grid_walk_block(hist, g);
+  __threadfence();
+  __syncthreads();
+  for (int k = 0; k < 2; ++k) export_words(ex.dst[k], ex.src[k], ex.bytes[k]);
+}
+
+// rsi.cpp:1176-1185: subtract the minimum, rescale to the depth scale, overwrite bins 0..2 -- and, while the values
+// pass through, their min/max for the median that follows (the last workgroup derives that median's grid).
+// The scalars come from the raw minimum found by k_nb_raw and the three reference levels the host computed with its
+// own libm (no device log in them); the host repeats the same IEEE operations on the minimum it gets back.
+struct NbLevels { double med_raw, del_raw, dup_raw, RDmedian; };
+__global__ __launch_bounds__(kThreads) void k_nb_scale_mm(float* __restrict__ x, int64_t nb, const uint32_t* __restrict__ rawmin_inv,
+                                                          NbLevels lv, MinMaxF* __restrict__ mm, unsigned int* __restrict__ counter,
+                                                          uint32_t cap, uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
+  const uint32_t key = ~(*rawmin_inv);
+  const double tmin = (double)__uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+  const double med_nbt = lv.med_raw - tmin;
+  const double del_s = (lv.del_raw - tmin) / med_nbt * lv.RDmedian, dup_s = (lv.dup_raw - tmin) / med_nbt * lv.RDmedian;
+  const double med_s = med_nbt / med_nbt * lv.RDmedian;
+  const float lev0 = (float)del_s, lev1 = (float)dup_s, lev2 = (float)med_s;
+  uint32_t kmin = 0xffffffffu, kmax = 0;
+  unsigned int bad = 0;
+  for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < nb; b += (int64_t)gridDim.x * kThreads) {
+    float v = x[b];
+    v = (float)((double)v - tmin);
+    v = (float)((double)v / med_nbt * lv.RDmedian);
+    if (b == 0) v = lev0;
+    if (b == 1) v = lev1;
+    if (b == 2) v = lev2;
+    x[b] = v;
+    if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+    const uint32_t k = f32_key(v);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  }
+  minmax_commit(kmin, kmax, bad, mm);
+  if (last_block_done(counter)) grid_plan_block(mm, cap, hist, g);
+}
+
+// -MED: the bin medians as floats, and the min/max of their absolute deviations from `center` for the MAD that follows
+__global__ __launch_bounds__(kThreads) void k_i32_to_f32_mm(const int32_t* __restrict__ in, float* __restrict__ out, int64_t nb,
+                                                            double center, MinMaxF* __restrict__ mm, unsigned int* __restrict__ counter,
+                                                            uint32_t cap, uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
+  uint32_t kmin = 0xffffffffu, kmax = 0;
+  unsigned int bad = 0;
+  for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < nb; b += (int64_t)gridDim.x * kThreads) {
+    const float f = (float)in[b];
+    out[b] = f;
+    const float v = (float)fabs((double)f - center);
+    if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+    const uint32_t k = f32_key(v);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  }
+  minmax_commit(kmin, kmax, bad, mm);
+  if (last_block_done(counter)) grid_plan_block(mm, cap, hist, g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -437,12 +514,17 @@ __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const dou
   }
 }
 
+// INL: the thresholds ride in the kernel arguments (Lmax <= kThrInline - kScanPad - 1: every configuration BASELINE names);
+// otherwise they are read from device memory the host uploaded.
+template <bool INL>
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
-                                                       ScanParams sp, const double* __restrict__ thr_del,
-                                                       const double* __restrict__ thr_dup,
+                                                       ScanParams sp, const double* __restrict__ thr_del_mem,
+                                                       const double* __restrict__ thr_dup_mem,
                                                        uint32_t* __restrict__ first_del, uint32_t* __restrict__ first_dup,
-                                                       uint32_t* __restrict__ counters) {
+                                                       uint32_t* __restrict__ counters, ScanThr inl) {
   extern __shared__ __align__(16) double sm[];
+  const double* __restrict__ thr_del = INL ? inl.del : thr_del_mem;
+  const double* __restrict__ thr_dup = INL ? inl.dup : thr_dup_mem;
   const int Lmax = sp.Lmax, kcap = sp.kcap;
   const int halo = Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;          // staged bins
@@ -575,80 +657,119 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   }
 }
 
-// histogram over L of first[] (bins whose exclude[] <= exclude_max are skipped: DEL marks win)
-__global__ __launch_bounds__(kThreads) void k_level_hist(const uint32_t* __restrict__ first,
-                                                         const uint32_t* __restrict__ exclude,
-                                                         const uint32_t* __restrict__ exclude_max_ptr,
-                                                         int64_t nb, int32_t Lmax, uint32_t* __restrict__ hist) {
-  extern __shared__ unsigned int s_l[];
-  const uint32_t exclude_max = exclude ? *exclude_max_ptr : 0u;   // the DEL sweep's stop level, found by k_stop_level
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_l[e] = 0;
-  __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
-    const uint32_t f = first[i];
-    if (f > (uint32_t)Lmax) continue;
-    if (exclude && exclude[i] <= exclude_max) continue;
-    atomicAdd(&s_l[f], 1u);
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { const unsigned int c = s_l[e]; if (c) atomicAdd(&hist[e], c); }
-}
-
-// Which L does a sweep stop at?  The first L after whose marks more than a fifth of the bins are
-// marked (rsi.cpp:1225, 1255), Lmax when that never happens.  One workgroup; the walk is sequential.
-__global__ __launch_bounds__(kThreads) void k_stop_level(const uint32_t* __restrict__ hist, int32_t Lmax, int64_t nb,
-                                                         uint32_t* __restrict__ level) {
-  extern __shared__ unsigned int s_l[];
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_l[e] = hist[e];
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+// After a sweep pair: at which L did each sweep stop?  The DEL sweep stops after the first L with more than a fifth of
+// the bins marked (rsi.cpp:1225), the DUP sweep likewise (rsi.cpp:1255) but it cannot mark bins the DEL sweep marked
+// (App. A Q14).  One launch: every workgroup histograms first_del and first_dup over L in LDS and appends the (rare) bins
+// marked by both sweeps to a list; the last workgroup to finish walks the DEL histogram to its stop level, takes the
+// listed bins the DEL sweep really marked out of the DUP histogram (or, if the list overflowed, recounts them itself),
+// walks that one, and leaves the levels, the per-L counts (what the reference logs per L, rsi.cpp:1221-1224, 1251-1254)
+// and the pass counters in `work`, a copy of which goes to mapped host memory.
+// work: [ScanPassHead (64 bytes)] [hist_del: kMaxLevels uint32] [hist_dup: kMaxLevels uint32]
+constexpr int kBothCap = 16384;
+__device__ inline uint32_t stop_level_walk(const unsigned int* s_l, int32_t Lmax, int64_t nb) {
   unsigned long long cum = 0;
-  uint32_t lv = (uint32_t)Lmax;
   for (int L = 1; L <= Lmax; ++L) {
     cum += s_l[L];
-    if ((double)(int)cum / (double)(int)nb > 0.2) { lv = (uint32_t)L; break; }
+    if ((double)(int)cum / (double)(int)nb > 0.2) return (uint32_t)L;
   }
-  *level = lv;
+  return (uint32_t)Lmax;
 }
-
-__global__ __launch_bounds__(kThreads) void k_resolve_status(const uint32_t* __restrict__ first_del,
-                                                             const uint32_t* __restrict__ first_dup,
-                                                             const uint32_t* __restrict__ levels, int64_t nb,
-                                                             int32_t* __restrict__ status) {
-  const uint32_t ldel = levels[0], ldup = levels[1];
+__global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restrict__ first_del, const uint32_t* __restrict__ first_dup,
+                                                         int64_t nb, int32_t Lmax, uint32_t* __restrict__ work,
+                                                         uint2* __restrict__ both, unsigned int* __restrict__ counter,
+                                                         void* host_copy, unsigned int host_bytes) {
+  extern __shared__ unsigned int s_l[];   // [2][Lmax + 1]
+  unsigned int* s_d = s_l;
+  unsigned int* s_u = s_l + (Lmax + 1);
+  uint32_t* head = work;                  // [0] escapes [1] inexact (the scan) [2] ldel [3] ldup [4] both-count [5] last run start + 1
+  uint32_t* hist_d = work + 16;
+  uint32_t* hist_u = hist_d + kMaxLevels;
+  for (int e = threadIdx.x; e < 2 * (Lmax + 1); e += kThreads) s_l[e] = 0;
+  __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
     const uint32_t fd = first_del[i], fu = first_dup[i];
-    int s = 0;
-    if (fd <= ldel) s = -(int)fd;
-    else if (fu <= ldup) s = (int)fu;
-    status[i] = s;
+    const bool hd = fd <= (uint32_t)Lmax, hu = fu <= (uint32_t)Lmax;
+    if (hd) atomicAdd(&s_d[fd], 1u);
+    if (hu) atomicAdd(&s_u[fu], 1u);
+    if (hd && hu) { const uint32_t k = atomicAdd(&head[4], 1u); if (k < (uint32_t)kBothCap) both[k] = make_uint2(fd, fu); }
   }
+  __syncthreads();
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) {
+    const unsigned int c = s_d[e], u = s_u[e];
+    if (c) atomicAdd(&hist_d[e], c);
+    if (u) atomicAdd(&hist_u[e], u);
+  }
+  if (!last_block_done(counter)) return;
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { s_d[e] = ld_cg(hist_d + e); s_u[e] = ld_cg(hist_u + e); }
+  __syncthreads();
+  __shared__ uint32_t s_ldel;
+  if (threadIdx.x == 0) s_ldel = stop_level_walk(s_d, Lmax, nb);
+  __syncthreads();
+  const uint32_t ldel = s_ldel;
+  const uint32_t nboth = ld_cg(&head[4]);
+  if (nboth <= (uint32_t)kBothCap) {
+    for (uint32_t k = threadIdx.x; k < nboth; k += kThreads) {
+      const uint32_t fd = ld_cg(&both[k].x), fu = ld_cg(&both[k].y);
+      if (fd <= ldel) atomicSub(&s_u[fu], 1u);
+    }
+  } else {   // the list overflowed: this workgroup recounts the DUP histogram with the exclusion
+    for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_u[e] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < nb; i += kThreads) {
+      const uint32_t fu = first_dup[i];
+      if (fu <= (uint32_t)Lmax && !(first_del[i] <= ldel)) atomicAdd(&s_u[fu], 1u);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) hist_u[e] = s_u[e];
+  if (threadIdx.x == 0) { head[2] = ldel; head[3] = stop_level_walk(s_u, Lmax, nb); }
+  __threadfence();
+  __syncthreads();
+  export_words(host_copy, work, host_bytes);
 }
 
-// ------------------------------------------------------------------------------------------
-// K9  marked runs (get_continuous_segments with d = 1, rsi.cpp:291-327): boundaries only
-__global__ __launch_bounds__(kThreads) void k_find_runs(const int32_t* __restrict__ status, int64_t nb,
-                                                        uint64_t* __restrict__ runs, uint32_t* __restrict__ count,
-                                                        uint32_t cap) {
+// status[j] = -first_del[j] if first_del[j] <= ldel; else +first_dup[j] if <= ldup; else 0 (copy: a second array that
+// receives the same values, for filterstatus to trim).  While the values pass through: the boundaries of the marked runs
+// (get_continuous_segments with d = 1, rsi.cpp:291-327: a run is a maximal stretch of adjacent bins of one sign), appended
+// unordered as (pos << 1 | is_end); the last workgroup hands the count and the first entries to the host.
+__device__ inline int resolved_status(uint32_t fd, uint32_t fu, uint32_t ldel, uint32_t ldup) {
+  return fd <= ldel ? -(int)fd : (fu <= ldup ? (int)fu : 0);
+}
+__global__ __launch_bounds__(kThreads) void k_resolve_runs(const uint32_t* __restrict__ first_del, const uint32_t* __restrict__ first_dup,
+                                                           const uint32_t* __restrict__ levels, int64_t nb,
+                                                           int32_t* __restrict__ status, int32_t* __restrict__ copy,
+                                                           uint64_t* __restrict__ runs, uint32_t* __restrict__ count, uint32_t cap,
+                                                           unsigned int* __restrict__ counter, void* host_copy, unsigned int host_entries) {
+  const uint32_t ldel = levels[0], ldup = levels[1];
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
-    const int s = status[i];
+    const int s = resolved_status(first_del[i], first_dup[i], ldel, ldup);
+    status[i] = s;
+    if (copy) copy[i] = s;
     if (s == 0) continue;
-    const int p = i > 0 ? status[i - 1] : 0, q = i + 1 < nb ? status[i + 1] : 0;
+    const int p = i > 0 ? resolved_status(first_del[i - 1], first_dup[i - 1], ldel, ldup) : 0;
+    const int q = i + 1 < nb ? resolved_status(first_del[i + 1], first_dup[i + 1], ldel, ldup) : 0;
     const bool is_start = p == 0 || ((p > 0) != (s > 0));
     const bool is_end = q == 0 || ((q > 0) != (s > 0));
     if (is_start) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) runs[k] = ((uint64_t)i << 1); }
     if (is_end) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) runs[k] = ((uint64_t)i << 1) | 1u; }
   }
+  if (!host_copy || !last_block_done(counter)) return;
+  // [count, pad][entries ...]
+  unsigned int* d = static_cast<unsigned int*>(host_copy);
+  const uint32_t n = ld_cg(count);
+  if (threadIdx.x == 0) { d[0] = n; d[1] = 0; }
+  const uint32_t k = n < host_entries ? n : host_entries;
+  export_words(d + 2, runs, (size_t)k * 8);
 }
 
 // edge trimming of filterstatus (rsi.cpp:1023-1044): one thread per run, runs are disjoint
 __global__ __launch_bounds__(kThreads) void k_trim_runs(const float* __restrict__ T, int32_t* __restrict__ status,
                                                         const int32_t* __restrict__ run_start,
                                                         const int32_t* __restrict__ run_end, int nruns, double delthr,
-                                                        double addthr) {
+                                                        double addthr, RunsInline inl) {
   const int r = blockIdx.x * kThreads + threadIdx.x;
   if (r >= nruns) return;
-  int i1 = run_start[r], i2 = run_end[r];
+  int i1 = run_start ? run_start[r] : inl.se[2 * r], i2 = run_start ? run_end[r] : inl.se[2 * r + 1];
   while (((double)T[i1] > delthr && status[i1] < 0) || ((double)T[i1] < addthr && status[i1] > 0)) {
     status[i1] = 0; ++i1; if (i1 >= i2) break;
   }
@@ -662,11 +783,12 @@ __global__ __launch_bounds__(kThreads) void k_trim_runs(const float* __restrict_
 // Step 1: exact double prefix of the run's values into scratch (one workgroup per run).
 __global__ __launch_bounds__(kThreads) void k_run_prefix(const float* __restrict__ T, const int32_t* __restrict__ run_start,
                                                          const int32_t* __restrict__ run_end,
-                                                         const int64_t* __restrict__ poff, double* __restrict__ scratch) {
+                                                         const int64_t* __restrict__ poff, double* __restrict__ scratch, RunsInline inl) {
   __shared__ double s_tot[kThreads];
   const int r = blockIdx.x;
-  const int s = run_start[r], len = run_end[r] - run_start[r] + 1;
-  double* P = scratch + poff[r];
+  const int s = run_start ? run_start[r] : inl.se[2 * r];
+  const int len = (run_start ? run_end[r] : inl.se[2 * r + 1]) - s + 1;
+  double* P = scratch + (poff ? poff[r] : (int64_t)inl.off[r]);
   const int chunk = (len + kThreads - 1) / kThreads;
   const int c0 = threadIdx.x * chunk;
   double run = 0.0;
@@ -700,11 +822,11 @@ __device__ inline bool seg_better(double s, int L, int j, double bs, int bL, int
 __global__ __launch_bounds__(kThreads) void k_best_subsegment(const SegItem* __restrict__ items,
                                                               const int64_t* __restrict__ poff,
                                                               const double* __restrict__ scratch, double tmedian,
-                                                              BestSeg* __restrict__ out) {
+                                                              BestSeg* __restrict__ out, ItemsInline inl) {
   __shared__ double s_s[kThreads];
   __shared__ int s_L[kThreads], s_j[kThreads];
-  const SegItem it = items[blockIdx.x];
-  const double* P = scratch + poff[it.run];
+  const SegItem it = items ? items[blockIdx.x] : inl.it[blockIdx.x];
+  const double* P = scratch + (poff ? poff[it.run] : (int64_t)inl.off[it.run]);
   double bs = -1.0; int bL = 0x7fffffff, bj = 0x7fffffff;
   for (int L = it.Lbeg; L < it.Lend; ++L) {
     const double dL = (double)L, sq = sqrt(dL);
@@ -735,12 +857,16 @@ void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, d
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(k_nb_raw, dim3(grid), dim3(kThreads), 0, stream, binsum, nb, m, ncompact, r, raw, rawmin_bits);
 }
-void launch_nb_scale(float* x, int64_t nb, double tmin, double med_nbt, double med, float lev0, float lev1, float lev2,
-                     hipStream_t stream) {
-  hipLaunchKernelGGL(k_nb_scale, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, x, nb, tmin, med_nbt, med, lev0, lev1, lev2);
+void launch_nb_scale_minmax(float* x, int64_t nb, const uint32_t* rawmin_bits, double med_raw, double del_raw, double dup_raw,
+                            double RDmedian, const GridChain& c, GridMedian* out, hipStream_t stream) {
+  NbLevels lv{med_raw, del_raw, dup_raw, RDmedian};
+  hipLaunchKernelGGL(k_nb_scale_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, x, nb, rawmin_bits, lv, c.mm, c.counters, c.cap,
+                     c.hist, out);
 }
-void launch_i32_to_f32(const int32_t* in, float* out, int64_t nb, hipStream_t stream) {
-  hipLaunchKernelGGL(k_i32_to_f32, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, in, out, nb);
+void launch_i32_to_f32_minmax(const int32_t* in, float* out_f, int64_t nb, double center, const GridChain& c, GridMedian* out,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(k_i32_to_f32_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, in, out_f, nb, center, c.mm, c.counters, c.cap,
+                     c.hist, out);
 }
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
                        hipStream_t stream) {
@@ -756,21 +882,25 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
   if (grid > 128) grid = 128;
   hipLaunchKernelGGL(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
 }
-void launch_grid_median(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
-                        MinMaxF* mm, uint32_t* hist, uint32_t cap, GridMedian* out, hipStream_t stream) {
-  const int g = grid_for(nb, kThreads * 16);
-  if (d_center) hipLaunchKernelGGL(k_minmax_f32_at, dim3(g), dim3(kThreads), 0, stream, x, mask, nb, use_abs, d_center, mm);
-  else hipLaunchKernelGGL(k_minmax_f32, dim3(g), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
-  hipLaunchKernelGGL(k_grid_plan, dim3(64), dim3(kThreads), 0, stream, mm, cap, hist, out);
+void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                        const GridChain& c, GridMedian* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_minmax_plan, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, d_center, c.mm,
+                     c.counters, c.cap, c.hist, out);
+}
+void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
+                      const GridChain& c, GridMedian* out, const GridExport* ex, const FillList* fill, hipStream_t stream) {
   const size_t lds = (size_t)kLdsBins * 4;
-  RSI_ALLOW_FULL_LDS(k_hist_f32_planned);
+  RSI_ALLOW_FULL_LDS(k_hist_walk);
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
-  hipLaunchKernelGGL(k_hist_f32_planned, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, hist);
-  hipLaunchKernelGGL(k_grid_walk, dim3(1), dim3(kThreads), 0, stream, hist, out, mm);
+  ExportPair e{};
+  if (ex) for (int k = 0; k < 2; ++k) { e.src[k] = ex->src[k]; e.dst[k] = ex->dst[k]; e.bytes[k] = (unsigned int)ex->bytes[k]; }
+  FillList f{};
+  if (fill) f = *fill;
+  hipLaunchKernelGGL(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
-                     uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
+                     const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
   ScanParams sp = sp_in;
   const int halo = sp.Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;
@@ -781,42 +911,47 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   sp.kcap = kcap;
   const size_t lds = scan_lds_bytes(count, kcap);
   const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
-  RSI_ALLOW_FULL_LDS(k_rsi_scan);
-  hipLaunchKernelGGL(k_rsi_scan, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters);
+  if (inl) {
+    RSI_ALLOW_FULL_LDS(k_rsi_scan<true>);
+    hipLaunchKernelGGL(k_rsi_scan<true>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, *inl);
+  } else {
+    RSI_ALLOW_FULL_LDS(k_rsi_scan<false>);
+    static const ScanThr none{};
+    hipLaunchKernelGGL(k_rsi_scan<false>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, none);
+  }
 }
-void launch_level_hist(const uint32_t* first, const uint32_t* exclude, const uint32_t* exclude_max, int64_t nb, int32_t Lmax,
-                       uint32_t* hist, hipStream_t stream) {
-  hipLaunchKernelGGL(k_level_hist, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 4, stream, first, exclude,
-                     exclude_max, nb, Lmax, hist);
+void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
+                       unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_level_stop, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 8, stream, first_del, first_dup, nb,
+                     Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
 }
-void launch_stop_level(const uint32_t* hist, int32_t Lmax, int64_t nb, uint32_t* level, hipStream_t stream) {
-  hipLaunchKernelGGL(k_stop_level, dim3(1), dim3(kThreads), (size_t)(Lmax + 1) * 4, stream, hist, Lmax, nb, level);
+void launch_resolve_runs(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb, int32_t* status,
+                         int32_t* copy, uint64_t* runs, uint32_t* count, uint32_t cap, unsigned int* counter, void* host_copy,
+                         uint32_t host_entries, hipStream_t stream) {
+  hipLaunchKernelGGL(k_resolve_runs, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, first_del, first_dup, levels, nb, status, copy,
+                     runs, count, cap, counter, host_copy, host_entries);
 }
-void launch_resolve_status(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb,
-                           int32_t* status, hipStream_t stream) {
-  hipLaunchKernelGGL(k_resolve_status, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, first_del, first_dup, levels, nb, status);
-}
-void launch_find_runs(const int32_t* status, int64_t nb, uint64_t* runs, uint32_t* count, uint32_t cap, hipStream_t stream) {
-  hipLaunchKernelGGL(k_find_runs, dim3(grid_for(nb, kThreads)), dim3(kThreads), 0, stream, status, nb, runs, count, cap);
-}
-void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, int nruns,
+void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns,
                       double delthr, double addthr, hipStream_t stream) {
   if (nruns <= 0) return;
+  static const RunsInline none{};
   hipLaunchKernelGGL(k_trim_runs, dim3((nruns + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, T, status, run_start, run_end,
-                     nruns, delthr, addthr);
+                     nruns, delthr, addthr, inl ? *inl : none);
 }
 
 // best_subsegment is driven from the host side in two launches (see pipeline.hip)
-void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, int nruns, const int64_t* poff,
+void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns, const int64_t* poff,
                        double* scratch, hipStream_t stream) {
   if (nruns <= 0) return;
-  hipLaunchKernelGGL(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch);
+  static const RunsInline none{};
+  hipLaunchKernelGGL(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch, inl ? *inl : none);
 }
-void launch_best_items(const void* items, int nitems, const int64_t* poff, const double* scratch, double tmedian, BestSeg* out,
-                       hipStream_t stream) {
+void launch_best_items(const void* items, const ItemsInline* inl, int nitems, const int64_t* poff, const double* scratch, double tmedian,
+                       BestSeg* out, hipStream_t stream) {
   if (nitems <= 0) return;
+  static const ItemsInline none{};
   hipLaunchKernelGGL(k_best_subsegment, dim3(nitems), dim3(kThreads), 0, stream, reinterpret_cast<const SegItem*>(items), poff,
-                     scratch, tmedian, out);
+                     scratch, tmedian, out, inl ? *inl : none);
 }
 
 }  // namespace rsik

@@ -21,6 +21,10 @@ struct ScanOut {
   std::vector<int> status2;
   std::vector<Candidate> segs;
   uint32_t escapes = 0, inexact = 0;
+  // per-L counts of newly marked bins of the four sweeps (pass 1 DEL, DUP, pass 2 DEL, DUP) and the L each stopped at:
+  // what the reference logs per L (rsi.cpp:1221-1224, 1251-1254)
+  std::vector<uint32_t> level_log[4];
+  uint32_t stop_levels[4] = {0, 0, 0, 0};
 };
 
 // 0.01-grid median of the selected values of a device float array (partition_stat_tp semantics)
@@ -53,25 +57,52 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   return RSI_OK;
 }
 
-// The device-side form (kernels_bin.hip, launch_grid_median): median of the selection into slot 0 and, chained to it,
-// the median of the absolute deviations from it (or from `center` when `first` is false) into slot 1 -- one round trip
-// for the pair instead of four.  A range wider than the resident histogram falls back to grid_median().
+// The device-side form (kernels_bin.hip): a median is a chain of two launches (min/max + plan, histogram + walk), a
+// (median, MAD) pair four, the MAD taking its centre from the median through device memory; the pair's results come back
+// in the pinned mailbox with the last launch, which also clears what the scan pass behind it accumulates into.
+// A range wider than the resident histogram falls back to grid_median().
 constexpr uint32_t kGridCap = 1u << 20;
-int grid_pair_issue(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, bool first, double center, GridMedian out[2]) {
+struct ChainOut { GridMedian g[2]; uint32_t rawmin_inv; uint32_t pad[15]; };   // what a chain leaves in the mailbox
+GridChain grid_chain(rsi_ctx* ctx) {
   uint8_t* small = ctx->small.as<uint8_t>();
-  MinMaxF* d_mm = reinterpret_cast<MinMaxF*>(small + kOffMinMax);
+  return GridChain{reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->hist_f.as<uint32_t>(), kGridCap,
+                   reinterpret_cast<unsigned int*>(small + kOffDone) + 3 * kDoneStride};
+}
+// what the scan pass `pass` needs cleared: the first-L arrays, its work block, the run-boundary counter
+void scan_fill_list(rsi_ctx* ctx, int pass, int64_t nb, FillList& fl) {
+  uint8_t* small = ctx->small.as<uint8_t>();
+  uint32_t* d_first_del = ctx->first_del.as<uint32_t>();
+  const int64_t nbpad = (nb + 3) & ~int64_t(3);
+  fill_add(fl, d_first_del, (size_t)(nbpad + nb) * 4, 0xffffffffu);
+  fill_add(fl, small + kOffScanPass + (size_t)pass * kScanPassBytes, kScanPassBytes, 0u);
+  fill_add(fl, small + kOffCounters, 32, 0u);
+}
+// Issues the (median, MAD) pair of the selection (mask == 0 where given).  planned: the first link's min/max + plan has been
+// done by the kernel that produced x (launch_nb_scale_minmax).  with_median = false: only the MAD around `center`
+// (planned then refers to the MAD's first link).  Returns the mailbox record the last launch fills.
+int grid_pair_issue(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, bool with_median, double center, bool planned,
+                    int fill_pass, ChainOut** out) {
+  uint8_t* small = ctx->small.as<uint8_t>();
   GridMedian* d_g = reinterpret_cast<GridMedian*>(small + kOffGrid);
-  HIPCHK(ctx->hist_f.ensure((size_t)kGridCap * 4));
-  // d_mm holds "nothing seen" (all zero) here: the run's first memset covers it and every user leaves it that way
-  if (first) {
-    Timer t(ctx, "grid_median");
-    launch_grid_median(d_x, d_mask, nb, 0, 0.0, nullptr, d_mm, ctx->hist_f.as<uint32_t>(), kGridCap, d_g, ctx->stream);
+  const GridChain gc = grid_chain(ctx);
+  ChainOut* slot = static_cast<ChainOut*>(mb_alloc(ctx, sizeof(ChainOut)));
+  if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+  memset(slot, 0, sizeof(*slot));
+  GateShared gs(ctx);
+  if (with_median) {
+    if (!planned) { Timer t(ctx, "minmax_plan"); launch_minmax_plan(d_x, d_mask, nb, 0, 0.0, nullptr, gc, d_g, ctx->stream); }
+    { Timer t(ctx, "hist_walk"); launch_hist_walk(d_x, d_mask, nb, 0, 0.0, nullptr, gc, d_g, nullptr, nullptr, ctx->stream); }
+    planned = false;
   }
-  {
-    Timer t(ctx, "grid_median");
-    launch_grid_median(d_x, d_mask, nb, 1, center, first ? &d_g->med : nullptr, d_mm, ctx->hist_f.as<uint32_t>(), kGridCap, d_g + 1, ctx->stream);
-  }
-  HIPCHK(copy_d2h(ctx, out + (first ? 0 : 1), d_g + (first ? 0 : 1), (first ? 2 : 1) * sizeof(GridMedian)));
+  const double* d_center = with_median ? &d_g->med : nullptr;
+  if (!planned) { Timer t(ctx, "minmax_plan"); launch_minmax_plan(d_x, d_mask, nb, 1, center, d_center, gc, d_g + 1, ctx->stream); }
+  GridExport ex{};
+  ex.src[0] = d_g; ex.dst[0] = slot->g; ex.bytes[0] = 2 * sizeof(GridMedian);
+  ex.src[1] = small + kOffRawMin; ex.dst[1] = &slot->rawmin_inv; ex.bytes[1] = 4;
+  FillList fl{};
+  if (fill_pass >= 0) scan_fill_list(ctx, fill_pass, nb, fl);
+  { Timer t(ctx, "hist_walk"); launch_hist_walk(d_x, d_mask, nb, 1, center, d_center, gc, d_g + 1, &ex, &fl, ctx->stream); }
+  *out = slot;
   return RSI_OK;
 }
 // what grid_median() would have returned for this record (same tests, same order, same messages)
@@ -126,27 +157,47 @@ int fetch_pairs(rsi_ctx* ctx, const uint64_t* d_list, const uint32_t* d_count, u
   return RSI_OK;
 }
 
-// Marked runs of a device status array in the reference's sense (last run not emitted, Q11).
-int marked_runs_device(rsi_ctx* ctx, const int32_t* d_status, int64_t nb, std::vector<Region>& runs) {
-  uint8_t* small = ctx->small.as<uint8_t>();
-  uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
-  HIPCHK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
-  { Timer t(ctx, "find_runs"); launch_find_runs(d_status, nb, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, ctx->stream); }
-  int rc = fetch_pairs(ctx, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, runs, false);
-  if (rc != RSI_OK) return rc;
-  if (!runs.empty()) runs.pop_back();
+// Marked runs in the reference's sense (last run not emitted, Q11) from what k_resolve_runs left in the mailbox
+// ([count, 0][first kEagerBounds boundary entries]) and, for longer lists, in the device list.
+constexpr uint32_t kEagerBounds = 1024;
+int runs_from_export(rsi_ctx* ctx, const uint32_t* slot, const uint64_t* d_list, std::vector<Region>& runs) {
+  const uint32_t cnt = slot[0];
+  runs.clear();
+  if (cnt == 0) return RSI_OK;
+  if (cnt > kMaxRunEntries) return fail(ctx, RSI_ERR_UNSUPPORTED, "boundary list overflow");
+  std::vector<uint64_t> raw(cnt);
+  memcpy(raw.data(), slot + 2, (size_t)std::min(cnt, kEagerBounds) * 8);
+  if (cnt > kEagerBounds) {
+    HIPCHK(copy_d2h(ctx, raw.data() + kEagerBounds, d_list + kEagerBounds, (size_t)(cnt - kEagerBounds) * 8));
+    HIPCHK(CTX_SYNC());
+  }
+  std::vector<int64_t> s, e;
+  for (uint64_t v : raw) ((v & 1) ? e : s).push_back((int64_t)(v >> 1));
+  if (s.size() != e.size()) return fail(ctx, RSI_ERR_INTERNAL, "unbalanced run boundaries");
+  std::sort(s.begin(), s.end());
+  std::sort(e.begin(), e.end());
+  for (size_t i = 0; i < s.size(); ++i) runs.push_back({(int)s[i], (int)e[i]});
+  runs.pop_back();
   return RSI_OK;
 }
 
-int upload_runs(rsi_ctx* ctx, const std::vector<Region>& runs, int32_t** d_start, int32_t** d_end) {
+// The run list for the kernels: in the kernel arguments when short, else uploaded (start[k] | end[k]).
+struct RunArgs { RunsInline inl; bool use_inl = false; int32_t* d_start = nullptr; int32_t* d_end = nullptr; };
+int prepare_runs(rsi_ctx* ctx, const std::vector<Region>& runs, RunArgs& ra) {
   const size_t k = runs.size();
+  if (k <= (size_t)kRunsInline) {
+    memset(&ra.inl, 0, sizeof(ra.inl));
+    for (size_t i = 0; i < k; ++i) { ra.inl.se[2 * i] = runs[i].start; ra.inl.se[2 * i + 1] = runs[i].end; }
+    ra.use_inl = true;
+    return RSI_OK;
+  }
   HIPCHK(ctx->run_se.ensure(k * 8 + 64));
   std::vector<int32_t> se(2 * k);
   for (size_t i = 0; i < k; ++i) { se[i] = runs[i].start; se[k + i] = runs[i].end; }
-  HIPCHK(copy_h2d(ctx, ctx->run_se.p, se.data(), k * 8));
-  HIPCHK(CTX_SYNC());   // se goes out of scope
-  *d_start = ctx->run_se.as<int32_t>();
-  *d_end = ctx->run_se.as<int32_t>() + k;
+  HIPCHK(copy_h2d(ctx, ctx->run_se.p, se.data(), k * 8));   // parked in the mailbox: se may go out of scope
+  ra.use_inl = false;
+  ra.d_start = ctx->run_se.as<int32_t>();
+  ra.d_end = ctx->run_se.as<int32_t>() + k;
   return RSI_OK;
 }
 
@@ -309,54 +360,64 @@ class DeviceTester : public rsih::NeighbourTester {
   bool failed = false;
 };
 
-// One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status.  Nothing in it needs the host: the levels at which the
-// two sweeps stop are found on the device (k_stop_level), so the pass is one chain of launches without a round trip;
-// its counters (ScanPassOut slot `pass`) travel with the caller's next transfer.
+// One rsistatus pass on the device (rsi.cpp:1191-1259) -> d_status (and d_copy).  Three launches and no round trip: the scan
+// (thresholds in the kernel arguments), the stop levels of the two sweeps, the status values with the run boundaries.  The
+// first-L arrays, the work block and the boundary counter were cleared by the last launch of the quantile chain in front.
+// What the host wants from the pass lands in the pinned mailbox: *work_slot = [ScanPassOut | per-L counts], *runs_slot =
+// [count | first boundaries].
 int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
-              double tlamda, int Lmax, int32_t* d_status) {
+              double tlamda, int Lmax, int32_t* d_status, int32_t* d_copy, const uint32_t** work_slot, const uint32_t** runs_slot) {
   uint8_t* small = ctx->small.as<uint8_t>();
   std::vector<double> del, dup;
   scan_thresholds(tmedian, tlamda, Lmax, del, dup);
   const size_t nthr = (size_t)Lmax + 1 + kScanPad;
-  HIPCHK(ctx->thr.ensure(nthr * 16));
-  double* d_del = ctx->thr.as<double>();
-  double* d_dup = d_del + nthr;
-  del.insert(del.end(), dup.begin(), dup.end());
-  HIPCHK(copy_h2d(ctx, d_del, del.data(), 2 * nthr * 8));
-  uint8_t* work = small + kOffScanPass + (size_t)pass * kScanPassBytes;
-  ScanPassOut* d_out = reinterpret_cast<ScanPassOut*>(work);
-  uint32_t* d_lh_del = reinterpret_cast<uint32_t*>(work + 64);
-  uint32_t* d_lh_dup = reinterpret_cast<uint32_t*>(work + 64 + 8256);
+  ScanThr inl;
+  const bool use_inl = nthr <= (size_t)kThrInline;
+  double* d_del = nullptr;
+  double* d_dup = nullptr;
+  if (use_inl) {
+    for (size_t k = 0; k < (size_t)kThrInline; ++k) { inl.del[k] = k < nthr ? del[k] : -INFINITY; inl.dup[k] = k < nthr ? dup[k] : INFINITY; }
+  } else {
+    HIPCHK(ctx->thr.ensure(nthr * 16));
+    d_del = ctx->thr.as<double>();
+    d_dup = d_del + nthr;
+    del.insert(del.end(), dup.begin(), dup.end());
+    HIPCHK(copy_h2d(ctx, d_del, del.data(), 2 * nthr * 8));
+  }
+  uint32_t* work = reinterpret_cast<uint32_t*>(small + kOffScanPass + (size_t)pass * kScanPassBytes);
   uint32_t* d_first_del = ctx->first_del.as<uint32_t>();
   uint32_t* d_first_dup = d_first_del + ((nb + 3) & ~int64_t(3));
-  HIPCHK(hipMemsetAsync(work, 0, kScanPassBytes, ctx->stream));
-  HIPCHK(hipMemsetAsync(d_first_del, 0xff, (size_t)(d_first_dup - d_first_del + nb) * 4, ctx->stream));
+  unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone) + 3 * kDoneStride;
+  uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
+  const size_t work_bytes = 64 + ((size_t)kMaxLevels + (size_t)Lmax + 1) * 4;
+  uint32_t* wslot = static_cast<uint32_t*>(mb_alloc(ctx, work_bytes));
+  uint32_t* rslot = static_cast<uint32_t*>(mb_alloc(ctx, 8 + (size_t)kEagerBounds * 8));
+  if (!wslot || !rslot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
   ScanParams sp;
   sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
   sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
-  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, d_first_del, d_first_dup, &d_out->escapes, ctx->stream); }
-  { Timer t(ctx, "level_hist"); launch_level_hist(d_first_del, nullptr, nullptr, nb, Lmax, d_lh_del, ctx->stream); }
-  launch_stop_level(d_lh_del, Lmax, nb, &d_out->ldel, ctx->stream);
-  { Timer t(ctx, "level_hist"); launch_level_hist(d_first_dup, d_first_del, &d_out->ldel, nb, Lmax, d_lh_dup, ctx->stream); }
-  launch_stop_level(d_lh_dup, Lmax, nb, &d_out->ldup, ctx->stream);
-  { Timer t(ctx, "resolve_status"); launch_resolve_status(d_first_del, d_first_dup, &d_out->ldel, nb, d_status, ctx->stream); }
+  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->stream); }
+  { Timer t(ctx, "level_stop"); launch_level_stop(d_first_del, d_first_dup, nb, Lmax, work, ctx->runs.p, d_done + 2, wslot, work_bytes, ctx->stream); }
+  { Timer t(ctx, "resolve_runs"); launch_resolve_runs(d_first_del, d_first_dup, work + 2, nb, d_status, d_copy, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, d_done + 3, rslot, kEagerBounds, ctx->stream); }
+  *work_slot = wslot; *runs_slot = rslot;
   return RSI_OK;
 }
 
-// rsicnvnbn (rsi.cpp:1262-1360) / rsicnvmed (rsi.cpp:1402-1501) around the device scan
+// rsicnvnbn (rsi.cpp:1262-1360) / rsicnvmed (rsi.cpp:1402-1501) around the device scan.  `first` = the record the quantile
+// chain in front of the first pass leaves in the mailbox (issued by the caller, behind the transform).
 int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, int64_t nb, double RDmedian,
-             double factor, int LmaxBase, float t0, float t2, ScanOut& out) {
+             double factor, int LmaxBase, ChainOut* first, double nb_med_raw, double nb_del_raw, double nb_dup_raw, ScanOut& out) {
   const int32_t* d_medint = ctx->binmed.as<int32_t>();
   double tmedian, tsigma, tlamda, target, dev, absmed;
   uint64_t cnt;
   int rc, cal_max;
+  float t0 = 0, t2 = 0;
   {
     Phase ph(ctx, "scan.quantiles");
-    GateShared gs(ctx);
-    GridMedian g[2];
-    if ((rc = grid_pair_issue(ctx, d_T, nullptr, nb, !use_med, RDmedian, g)) != RSI_OK) return rc;
     HIPCHK(CTX_SYNC());
+    const GridMedian* g = first->g;
     if ((!use_med && (g[0].flags & kGridTooWide)) || (g[1].flags & kGridTooWide)) {   // host-driven path, any range
+      GateShared gs(ctx);
       if (!use_med) {
         if ((rc = grid_median(ctx, d_T, nullptr, nb, 0, 0.0, &tmedian, &cnt)) != RSI_OK) return rc;
       } else {
@@ -367,6 +428,16 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       tmedian = RDmedian;
       if (!use_med && (rc = grid_result(ctx, g[0], &tmedian, &cnt)) != RSI_OK) return rc;
       if ((rc = grid_result(ctx, g[1], &absmed, &cnt)) != RSI_OK) return rc;
+    }
+    if (!use_med) {   // the scaled reference levels (bins 0 and 2), as k_nb_scale_mm derived them from the raw minimum
+      const uint32_t key = ~first->rawmin_inv;
+      float tminf;
+      { const uint32_t b = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; memcpy(&tminf, &b, 4); }
+      const double tmin = tminf;
+      const double med_nbt = nb_med_raw - tmin;
+      t0 = (float)((nb_del_raw - tmin) / med_nbt * RDmedian);
+      t2 = (float)(med_nbt / med_nbt * RDmedian);
+      (void)nb_dup_raw;
     }
   }
   tsigma = absmed / 0.6745;
@@ -395,7 +466,9 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int32_t* d_st1 = ctx->status1.as<int32_t>();
   int32_t* d_st1f = ctx->status1f.as<int32_t>();
   int32_t* d_st2 = ctx->status2.as<int32_t>();
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1)) != RSI_OK) return rc; }
+  const uint32_t* wslot = nullptr;
+  const uint32_t* rslot = nullptr;
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, d_st1f, &wslot, &rslot)) != RSI_OK) return rc; }
 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
@@ -406,11 +479,11 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   const int* hst = ctx->h_status.as<int>();
   HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_st1f, d_st1, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  ScanPassOut pass_out[2];
-  HIPCHK(copy_d2h(ctx, &pass_out[0], ctx->small.as<uint8_t>() + kOffScanPass, sizeof(ScanPassOut)));
   { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
-  out.escapes += pass_out[0].escapes; out.inexact = pass_out[0].inexact;
+  out.escapes += wslot[0]; out.inexact = wslot[1];
+  out.level_log[0].assign(wslot + 16, wslot + 16 + Lmax + 1);
+  out.level_log[1].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
+  out.stop_levels[0] = wslot[2]; out.stop_levels[1] = wslot[3];
   {
     Phase phs(ctx, "fs.sums");
     // status values lie in [-Lmax, Lmax]; the unmarked level (almost every bin) is summed in a register.
@@ -445,12 +518,12 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       if (!(leveldel > 0 || leveladd < 0 || leveldel > leveladd)) {
         std::vector<Region> runs;
         GateShared gs(ctx);
-        if ((rc = marked_runs_device(ctx, d_st1, nb, runs)) != RSI_OK) return rc;
+        if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
         if (!runs.empty()) {
-          int32_t *d_rs, *d_re;
-          if ((rc = upload_runs(ctx, runs, &d_rs, &d_re)) != RSI_OK) return rc;
+          RunArgs ra;
+          if ((rc = prepare_runs(ctx, runs, ra)) != RSI_OK) return rc;
           Timer t(ctx, "trim_runs");
-          launch_trim_runs(d_T, d_st1f, d_rs, d_re, (int)runs.size(), (double)m0 - dev, (double)m0 + dev, ctx->stream);
+          launch_trim_runs(d_T, d_st1f, ra.d_start, ra.d_end, ra.use_inl ? &ra.inl : nullptr, (int)runs.size(), (double)m0 - dev, (double)m0 + dev, ctx->stream);
         }
       }
     }
@@ -458,41 +531,44 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   ph_filter.stop();
   // ---- second-pass parameters on the unmarked bins (rsi.cpp:1307-1319 / 1457-1469) ----
   Phase ph_q2(ctx, "scan.quantiles");
-  GateShared gs_q2(ctx);
   double tmed2;
   uint64_t k = 0;
-  GridMedian g2[2];
-  if ((rc = grid_pair_issue(ctx, d_T, d_st1f, nb, true, 0.0, g2)) != RSI_OK) return rc;
+  ChainOut* second = nullptr;
+  if ((rc = grid_pair_issue(ctx, d_T, d_st1f, nb, true, 0.0, false, 1, &second)) != RSI_OK) return rc;
   HIPCHK(CTX_SYNC());
-  const bool wide2 = (g2[0].flags & kGridTooWide) != 0;
-  if ((rc = wide2 ? grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k) : grid_result(ctx, g2[0], &tmed2, &k)) != RSI_OK) return rc;
-  if (k > (uint64_t)(nb / 2)) {
-    tmedian = tmed2;
-    if ((rc = (wide2 || (g2[1].flags & kGridTooWide)) ? grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)
-                                                      : grid_result(ctx, g2[1], &absmed, &cnt)) != RSI_OK) return rc;
-    tsigma = absmed / 0.6745;
-    tlamda = factor * tsigma;
-    tlamda = std::max(tlamda, target);
+  const GridMedian* g2 = second->g;
+  {
+    GateShared gs_q2(ctx);
+    const bool wide2 = (g2[0].flags & kGridTooWide) != 0;
+    if ((rc = wide2 ? grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k) : grid_result(ctx, g2[0], &tmed2, &k)) != RSI_OK) return rc;
+    if (k > (uint64_t)(nb / 2)) {
+      tmedian = tmed2;
+      if ((rc = (wide2 || (g2[1].flags & kGridTooWide)) ? grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)
+                                                        : grid_result(ctx, g2[1], &absmed, &cnt)) != RSI_OK) return rc;
+      tsigma = absmed / 0.6745;
+      tlamda = factor * tsigma;
+      tlamda = std::max(tlamda, target);
+    }
   }
   out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
   ph_q2.stop();
-  gs_q2.release();
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 1, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 1, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, nullptr, &wslot, &rslot)) != RSI_OK) return rc; }
   Phase ph_seg(ctx, "scan.segments");
   GateShared gs_seg(ctx);
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
   HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
   HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));   // into out.status2 after the next sync
+  HIPCHK(CTX_SYNC());
   std::vector<Region> runs;
-  HIPCHK(copy_d2h(ctx, &pass_out[1], ctx->small.as<uint8_t>() + kOffScanPass + kScanPassBytes, sizeof(ScanPassOut)));
-  if ((rc = marked_runs_device(ctx, d_st2, nb, runs)) != RSI_OK) return rc;   // synchronises
-  out.escapes += pass_out[1].escapes; out.inexact = pass_out[1].inexact;
+  if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
+  out.escapes += wslot[0]; out.inexact = wslot[1];
+  out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
+  out.level_log[3].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
+  out.stop_levels[2] = wslot[2]; out.stop_levels[3] = wslot[3];
   out.status2.assign(ctx->h_status2.as<int>(), ctx->h_status2.as<int>() + nb);
   out.segs.clear();
   if (runs.empty()) return RSI_OK;
-  int32_t *d_rs, *d_re;
-  if ((rc = upload_runs(ctx, runs, &d_rs, &d_re)) != RSI_OK) return rc;
   std::vector<int64_t> poff(runs.size() + 1, 0);
   std::vector<SegItem> items;
   const int64_t kPairsPerItem = 1 << 16;   // about 256 pairs per thread: enough workgroups to cover the chip
@@ -509,16 +585,39 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   HIPCHK(ctx->scratch.ensure((size_t)poff.back() * 8 + (runs.size() + 1) * 8));
   double* d_scratch = ctx->scratch.as<double>();
-  int64_t* d_poff = reinterpret_cast<int64_t*>(d_scratch + poff.back());
-  HIPCHK(ctx->items.ensure(items.size() * sizeof(SegItem)));
-  HIPCHK(ctx->best.ensure(items.size() * sizeof(BestSeg)));
-  HIPCHK(copy_h2d(ctx, d_poff, poff.data(), poff.size() * 8));
-  HIPCHK(copy_h2d(ctx, ctx->items.p, items.data(), items.size() * sizeof(SegItem)));
-  { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, d_rs, d_re, (int)runs.size(), d_poff, d_scratch, ctx->stream); }
-  { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
+  // short lists ride in the kernel arguments and the per-item results land in the pinned mailbox: two launches, no copy
+  const bool inl = runs.size() <= (size_t)kRunsInline && items.size() <= (size_t)kItemsInline && poff.back() < (int64_t)1 << 31;
   std::vector<BestSeg> best(items.size());
-  HIPCHK(copy_d2h(ctx, best.data(), ctx->best.p, items.size() * sizeof(BestSeg)));
-  HIPCHK(CTX_SYNC());
+  if (inl) {
+    RunArgs ra;
+    if ((rc = prepare_runs(ctx, runs, ra)) != RSI_OK) return rc;
+    ItemsInline ii;
+    memset(&ii, 0, sizeof(ii));
+    for (size_t r = 0; r < runs.size(); ++r) { ra.inl.off[r] = (int32_t)poff[r]; ii.off[r] = (int32_t)poff[r]; }
+    for (size_t i = 0; i < items.size(); ++i) ii.it[i] = items[i];
+    BestSeg* slot = static_cast<BestSeg*>(mb_alloc(ctx, items.size() * sizeof(BestSeg)));
+    if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, nullptr, nullptr, &ra.inl, (int)runs.size(), nullptr, d_scratch, ctx->stream); }
+    { Timer t(ctx, "best_subsegment"); launch_best_items(nullptr, &ii, (int)items.size(), nullptr, d_scratch, tmedian, slot, ctx->stream); }
+    HIPCHK(CTX_SYNC());
+    memcpy(best.data(), slot, items.size() * sizeof(BestSeg));
+  } else {
+    RunArgs ra;
+    const size_t kr = runs.size();
+    HIPCHK(ctx->run_se.ensure(kr * 8 + 64));
+    std::vector<int32_t> se(2 * kr);
+    for (size_t i = 0; i < kr; ++i) { se[i] = runs[i].start; se[kr + i] = runs[i].end; }
+    HIPCHK(copy_h2d(ctx, ctx->run_se.p, se.data(), kr * 8));
+    int64_t* d_poff = reinterpret_cast<int64_t*>(d_scratch + poff.back());
+    HIPCHK(ctx->items.ensure(items.size() * sizeof(SegItem)));
+    HIPCHK(ctx->best.ensure(items.size() * sizeof(BestSeg)));
+    HIPCHK(copy_h2d(ctx, d_poff, poff.data(), poff.size() * 8));
+    HIPCHK(copy_h2d(ctx, ctx->items.p, items.data(), items.size() * sizeof(SegItem)));
+    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, ctx->run_se.as<int32_t>(), ctx->run_se.as<int32_t>() + kr, nullptr, (int)kr, d_poff, d_scratch, ctx->stream); }
+    { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, nullptr, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
+    HIPCHK(copy_d2h(ctx, best.data(), ctx->best.p, items.size() * sizeof(BestSeg)));
+    HIPCHK(CTX_SYNC());
+  }
   std::vector<BestSeg> per_run(runs.size(), BestSeg{-1.0, 0, 0});
   for (size_t i = 0; i < items.size(); ++i) {   // items of a run are in increasing L: strict > keeps the earliest
     BestSeg& b = per_run[(size_t)items[i].run];
@@ -834,30 +933,21 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     HIPCHK(ctx->status2.ensure((size_t)nb * 4));
     HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
 
-    // ---- A10: NB transform (K5), always computed as the reference does (Q10) ----
+    // ---- A10: NB transform (K5), always computed as the reference does (Q10).  The raw minimum stays on the device: the
+    // scaling kernel derives the scaled levels from it and from the three raw reference levels computed here (host libm, as
+    // the reference), and takes the min/max of the scaled values for the median that follows. ----
     HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
+    HIPCHK(ctx->hist_f.ensure((size_t)kGridCap * 4));
     uint32_t* d_rawmin = reinterpret_cast<uint32_t*>(small + kOffRawMin);
+    GridMedian* d_g = reinterpret_cast<GridMedian*>(small + kOffGrid);
     { Timer t(ctx, "nb_raw"); launch_nb_raw(ctx->binsum.as<int64_t>(), nb, P.m, ncompact, r, ctx->tnb.as<float>(), d_rawmin, st); }
-    uint32_t minkey;
-    HIPCHK(copy_d2h(ctx, &minkey, d_rawmin, 4));   // zeroed with the header at the start of the run, used once
-    HIPCHK(CTX_SYNC());
-    minkey = ~minkey;
-    float tminf;
-    { uint32_t b = (minkey & 0x80000000u) ? (minkey & 0x7fffffffu) : ~minkey; memcpy(&tminf, &b, 4); }
-    const double tmin = tminf;
     auto nbf = [&](double sum) {
       const double mm = (double)P.m;
       return 2.0 * sqrt(r) * log(sqrt((sum + 0.25) / (mm * r - 0.5)) + sqrt(1.0 + (sum + 0.25) / (mm * r - 0.5)));
     };
-    double med_nbt = nbf(RDmedian * P.m), del_nbt = nbf(RDmedian / 2.0 * (double)P.m), dup_nbt = nbf(RDmedian * 1.5 * (double)P.m);
-    med_nbt -= tmin;
-    del_nbt -= tmin; dup_nbt -= tmin;
-    del_nbt = del_nbt / med_nbt * RDmedian;
-    dup_nbt = dup_nbt / med_nbt * RDmedian;
-    const double med_scaled = med_nbt / med_nbt * RDmedian;
-    const float lev0 = (float)del_nbt, lev1 = (float)dup_nbt, lev2 = (float)med_scaled;
-    { Timer t(ctx, "nb_scale"); launch_nb_scale(ctx->tnb.as<float>(), nb, tmin, med_nbt, RDmedian, lev0, lev1, lev2, st); }
-    S.nb_tmin = tmin;
+    const double med_raw = nbf(RDmedian * P.m), del_raw = nbf(RDmedian / 2.0 * (double)P.m), dup_raw = nbf(RDmedian * 1.5 * (double)P.m);
+    { Timer t(ctx, "nb_scale"); launch_nb_scale_minmax(ctx->tnb.as<float>(), nb, d_rawmin, med_raw, del_raw, dup_raw, RDmedian, grid_chain(ctx), d_g, st); }
+    bool nb_planned = true;   // d_g[0] holds the grid of the NB values' median, its buckets are clear
     ctx->have_nb = true;
 
     ph_nb.stop();
@@ -865,24 +955,36 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     rsih::CallerInput in;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     HIPCHK(ctx->h_medint.ensure((size_t)nb * 4));
-    HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(CTX_SYNC());
-    std::vector<int> medint(ctx->h_medint.as<int>(), ctx->h_medint.as<int>() + nb);
+    HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));   // complete at the scan's first wait
+    std::vector<int> medint;
     in.binmedint = &medint;
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
       ScanOut so;
       const float* d_T;
+      ChainOut* first = nullptr;
+      int rc2;
       if (use_med) {
         HIPCHK(ctx->tmed.ensure((size_t)nb * 4));
-        { Timer t(ctx, "i32_to_f32"); launch_i32_to_f32(ctx->binmed.as<int32_t>(), ctx->tmed.as<float>(), nb, st); }
+        { Timer t(ctx, "i32_to_f32"); launch_i32_to_f32_minmax(ctx->binmed.as<int32_t>(), ctx->tmed.as<float>(), nb, RDmedian, grid_chain(ctx), d_g + 1, st); }
         d_T = ctx->tmed.as<float>();
         ctx->have_med = true;
+        nb_planned = false;   // the chains share the bucket array
+        if ((rc2 = grid_pair_issue(ctx, d_T, nullptr, nb, false, RDmedian, true, 0, &first)) != RSI_OK) return rc2;
       } else {
         d_T = ctx->tnb.as<float>();
+        if ((rc2 = grid_pair_issue(ctx, d_T, nullptr, nb, true, 0.0, nb_planned, 0, &first)) != RSI_OK) return rc2;
+        nb_planned = false;
       }
-      int rc2 = run_scan(ctx, P, use_med, d_T, nb, RDmedian, factor, LmaxBase, lev0, lev2, so);
+      rc2 = run_scan(ctx, P, use_med, d_T, nb, RDmedian, factor, LmaxBase, first, med_raw, del_raw, dup_raw, so);
       if (rc2 != RSI_OK) return rc2;
+      {
+        const uint32_t key = ~first->rawmin_inv;
+        float tminf;
+        { const uint32_t bb = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; memcpy(&tminf, &bb, 4); }
+        S.nb_tmin = tminf;
+      }
+      if (medint.empty()) medint.assign(ctx->h_medint.as<int>(), ctx->h_medint.as<int>() + nb);
       ctx->last_scan_med = use_med;
       S.tmedian1 = so.tmedian1; S.tsigma1 = so.tsigma1; S.tlamda1 = so.tlamda1;
       S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;
