@@ -34,7 +34,14 @@ __device__ inline void fill_ranges(const FillList& f) {
   }
 }
 
-// Loads that must see what OTHER workgroups of the same launch wrote (after last_block_done): served by the L2.
+// Hand-over between workgroups of ONE launch without fences.  An agent-scope fence (__threadfence) writes back the whole
+// L2 of the XCD on gfx942 / gfx950 (buffer_wbl2) -- with a streaming kernel's dirty output in it that costs microseconds
+// per workgroup, a millisecond per launch.  Instead: everything one workgroup hands to another is written with st_cg
+// (agent-scope store, write-through to the coherence point) or with atomics, the writer's __syncthreads() waits for those to
+// complete, only then does it bump the arrival counter; the reader uses ld_cg (agent-scope load).  Plain loads of data
+// other workgroups of the same launch wrote with plain stores are NOT safe and not used.
+__device__ inline void st_cg(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_cg(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline unsigned int ld_cg(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline unsigned long long ld_cg(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline int ld_cg(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -44,8 +51,7 @@ __device__ inline int ld_cg(const int* p) { return __hip_atomic_load(p, __ATOMIC
 // workgroup must call it (it synchronises the workgroup).
 __device__ inline bool last_block_done(unsigned int* counter) {
   __shared__ unsigned int s_last__;
-  __threadfence();
-  __syncthreads();
+  __syncthreads();   // this workgroup's st_cg stores and atomics have completed
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(counter, 1u);
     const bool last = t == gridDim.x * gridDim.y - 1;
@@ -53,12 +59,10 @@ __device__ inline bool last_block_done(unsigned int* counter) {
     s_last__ = last ? 1u : 0u;
   }
   __syncthreads();
-  const bool last = s_last__ != 0;
-  if (last) __threadfence();
-  return last;
+  return s_last__ != 0;
 }
 
-// Two-level hand-over of per-workgroup partial results.  Every workgroup has written its `slab` (width words, plain
+// Two-level hand-over of per-workgroup partial results.  Every workgroup has written its `slab` (width words, st_cg
 // stores) at slabs + blockIdx.x * width.  Workgroups form groups of `per_group` consecutive indices; the last one of a
 // group to arrive sums the group's slabs into gsum + group * width, and the last group to arrive sums the group sums
 // into total[] (global or LDS) and gets `true`: exactly one workgroup of the launch, after all others are done.  No
@@ -74,8 +78,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   const int g = (int)blockIdx.x / per_group;
   const int ngroups = (nblocks + per_group - 1) / per_group;
   const int members = (g + 1) * per_group <= nblocks ? per_group : nblocks - g * per_group;
-  __threadfence();
-  __syncthreads();
+  __syncthreads();   // the slab's st_cg stores have completed
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(&counters[1 + g], 1u);
     const bool last = t == (unsigned int)members - 1u;
@@ -84,15 +87,13 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  __threadfence();
   for (int e = threadIdx.x; e < width; e += blockDim.x) {
     T s = 0;
     const T* col = slabs + (size_t)g * per_group * width + e;
 #pragma unroll 8
     for (int k = 0; k < members; ++k) s += ld_cg(col + (size_t)k * width);
-    gsum[(size_t)g * width + e] = s;
+    st_cg(gsum + (size_t)g * width + e, s);
   }
-  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(&counters[0], 1u);
@@ -102,7 +103,6 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  __threadfence();
   for (int e = threadIdx.x; e < width; e += blockDim.x) {
     T s = 0;
 #pragma unroll 8

@@ -369,13 +369,13 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
       if (PACKED) { s2 += w & ((1ull << 40) - 1); c += w >> 40; }
       else { s2 += w; c += s_cnt[g * kGcRep + r]; }
     }
-    slab[g] = s2; slab[kGcLevels + g] = c;
+    st_cg(&slab[g], s2); st_cg(&slab[kGcLevels + g], c);
   }
   if (threadIdx.x == 0) {
     unsigned long long ps = 0, pc = 0, fl = 0;
     for (int w = 0; w < kThreads / 64; ++w) { ps += s_tail[3 * w]; pc += s_tail[3 * w + 1]; fl |= s_tail[3 * w + 2]; }
     // the two flags as additive fields (number of workgroups that raised them), so that the fold can sum the slab
-    slab[2 * kGcLevels] = ps; slab[2 * kGcLevels + 1] = pc; slab[2 * kGcLevels + 2] = (fl & 1ull) | ((fl >> 1) << 32); slab[2 * kGcLevels + 3] = 0;
+    st_cg(&slab[2 * kGcLevels], ps); st_cg(&slab[2 * kGcLevels + 1], pc); st_cg(&slab[2 * kGcLevels + 2], (fl & 1ull) | ((fl >> 1) << 32)); st_cg(&slab[2 * kGcLevels + 3], 0ull);
   }
   // ---- the last workgroup to finish folds the slabs (device_util.h), adds the ragged last n % 4 bases, which lie in the
   // stale-window zone i >= n-101 whose count is that of [n-202, n-2] (App. A Q1), and builds the GC table
@@ -432,6 +432,16 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
     if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
     else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
   };
+  // what the streaming loop wrote to out[i]: recomputed here, because a plain load of another workgroup's plain store
+  // of the same launch may be stale (device_util.h); window rule of App. A Q1
+  auto streamed = [&](int64_t i) {
+    int64_t lo = i - 100;
+    if (lo < 0) lo = 0;
+    if (lo > n - 202) lo = n - 202;
+    int g = 0;
+    for (int k = 0; k < 201; ++k) g += (int)((gcbits[(lo + k) >> 6] >> ((lo + k) & 63)) & 1);
+    return (int)((double)depth[i] * rdmean / table[g] + 0.5);
+  };
   if (!adjust) {
     if (ragged + lane < n) hist_add(depth[ragged + lane]);
     return;
@@ -449,12 +459,12 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
   if (r >= 2 && lane < r) {
     const int nv = (int)((double)depth[20 * S + lane] * rdmean / table[gtail] + 0.5);
     const int64_t idx = n - 201 + lane;
-    hist_sub(out[idx]); hist_add(nv);
+    hist_sub(streamed(idx)); hist_add(nv);
     out[idx] = nv;
   }
   if (lane < r) {   // the last r bases keep their unadjusted depth
     const int64_t idx = 20 * S + lane;
-    if (idx < ragged) hist_sub(out[idx]);
+    if (idx < ragged) hist_sub(streamed(idx));
     hist_add(depth[idx]);
     out[idx] = depth[idx];
   }
@@ -498,7 +508,11 @@ __device__ inline void value_median_block(const uint32_t* __restrict__ hist, uns
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) { out->inrange = all; out->lo = glo; out->hi = ghi; out->med = s_med; out->pad = 0; }
+  if (threadIdx.x == 0) {   // agent-scope stores: the same workgroup reads the record back through ld_cg for the export
+    st_cg(&out->inrange, all);
+    st_cg(reinterpret_cast<unsigned int*>(&out->lo), (unsigned int)glo); st_cg(reinterpret_cast<unsigned int*>(&out->hi), (unsigned int)ghi);
+    st_cg(reinterpret_cast<unsigned int*>(&out->med), (unsigned int)s_med); st_cg(reinterpret_cast<unsigned int*>(&out->pad), 0u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   for (int v = threadIdx.x; v < kValLds; v += kThreads) {
     unsigned int c = 0;
     for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
-    hist_slabs[(size_t)blockIdx.x * kValLds + v] = c;
+    st_cg(&hist_slabs[(size_t)blockIdx.x * kValLds + v], c);
   }
   // ---- the last workgroup to finish: folds the slabs into the value histogram, applies the tail quirks of the 20-slice
   // write-back, walks the histogram to the median apply_cap needs (loaddata.cpp:233) and hands the chromosome's header
@@ -600,13 +614,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   unsigned int* total = s_hist;
   if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
   for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
-  __threadfence();
   __syncthreads();
   if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
-  __threadfence();
   __syncthreads();
   value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
-  __threadfence();
   __syncthreads();
   export_words(head_dst, head_src, head_bytes);
 }
@@ -815,16 +826,15 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   // folds the slabs into res_hist.  Atomics from every workgroup into the same few thousand words
   // would serialise on them. ----
   unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) slab[e] = s_hist[e];
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
   // ---- the last workgroup to finish folds the slabs into res_hist (device_util.h) and hands the histogram, with the
   // BinAccum record in front of it, to the host through mapped memory: no fold launch, no device -> host copy.
   // overwrite: every value is below vr (the cap is), so res_hist needs no clearing beforehand ----
   if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
     const unsigned int c = s_hist[e];
-    if (overwrite) res_hist[e] = c; else if (c) atomicAdd(&res_hist[e], c);
+    if (overwrite) st_cg(&res_hist[e], c); else if (c) atomicAdd(&res_hist[e], c);
   }
-  __threadfence();
   __syncthreads();
   export_words(exp_dst, exp_src, exp_bytes);
 }

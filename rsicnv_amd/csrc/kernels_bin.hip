@@ -225,11 +225,13 @@ __device__ inline void grid_walk_block(const uint32_t* __restrict__ hist, GridMe
   unsigned long long seen = 0, total = 0;
   for (int t = 0; t < kThreads; ++t) { const unsigned long long v = s_sum[t]; if (t < (int)threadIdx.x) seen += v; total += v; }
   const unsigned long long r2 = total / 2;
-  if (threadIdx.x == 0) { g->count = total; if (r2 == 0) g->med = g->ymin; }
+  // agent-scope stores: the same workgroup reads the record back through ld_cg for the export
+  unsigned long long* med_bits = reinterpret_cast<unsigned long long*>(&g->med);
+  if (threadIdx.x == 0) { st_cg(&g->count, total); if (r2 == 0) st_cg(med_bits, (unsigned long long)__double_as_longlong(g->ymin)); }
   if (r2 != 0 && mine != 0 && seen < r2 && seen + mine >= r2) {
     for (uint32_t b = b0; b < b1; ++b) {
       const unsigned long long upto = seen + ld_cg(hist + b);
-      if (seen < r2 && upto >= r2) g->med = g->ymin + (double)b * 0.01;
+      if (seen < r2 && upto >= r2) st_cg(med_bits, (unsigned long long)__double_as_longlong(g->ymin + (double)b * 0.01));
       seen = upto;
     }
   }
@@ -248,7 +250,6 @@ __global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict_
   }
   if (!last_block_done(counter)) return;
   if (!g->flags) grid_walk_block(hist, g);
-  __threadfence();
   __syncthreads();
   for (int k = 0; k < 2; ++k) export_words(ex.dst[k], ex.src[k], ex.bytes[k]);
 }
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
     const bool hd = fd <= (uint32_t)Lmax, hu = fu <= (uint32_t)Lmax;
     if (hd) atomicAdd(&s_d[fd], 1u);
     if (hu) atomicAdd(&s_u[fu], 1u);
-    if (hd && hu) { const uint32_t k = atomicAdd(&head[4], 1u); if (k < (uint32_t)kBothCap) both[k] = make_uint2(fd, fu); }
+    if (hd && hu) { const uint32_t k = atomicAdd(&head[4], 1u); if (k < (uint32_t)kBothCap) { st_cg(&both[k].x, fd); st_cg(&both[k].y, fu); } }
   }
   __syncthreads();
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) {
@@ -721,9 +722,8 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) hist_u[e] = s_u[e];
-  if (threadIdx.x == 0) { head[2] = ldel; head[3] = stop_level_walk(s_u, Lmax, nb); }
-  __threadfence();
+  for (int e = threadIdx.x; e <= Lmax; e += kThreads) st_cg(&hist_u[e], s_u[e]);
+  if (threadIdx.x == 0) { st_cg(&head[2], ldel); st_cg(&head[3], stop_level_walk(s_u, Lmax, nb)); }
   __syncthreads();
   export_words(host_copy, work, host_bytes);
 }
@@ -750,8 +750,8 @@ __global__ __launch_bounds__(kThreads) void k_resolve_runs(const uint32_t* __res
     const int q = i + 1 < nb ? resolved_status(first_del[i + 1], first_dup[i + 1], ldel, ldup) : 0;
     const bool is_start = p == 0 || ((p > 0) != (s > 0));
     const bool is_end = q == 0 || ((q > 0) != (s > 0));
-    if (is_start) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) runs[k] = ((uint64_t)i << 1); }
-    if (is_end) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) runs[k] = ((uint64_t)i << 1) | 1u; }
+    if (is_start) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&runs[k]), (unsigned long long)i << 1); }
+    if (is_end) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&runs[k]), ((unsigned long long)i << 1) | 1ull); }
   }
   if (!host_copy || !last_block_done(counter)) return;
   // [count, pad][entries ...]
