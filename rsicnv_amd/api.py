@@ -16,7 +16,8 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsi_hot.so")
+# RSI_HOT_LIB: another build of the same ABI (A/B measurements of library versions, tools/ab_bench.py)
+LIB_PATH = os.environ.get("RSI_HOT_LIB") or os.path.join(_HERE, "librsi_hot.so")
 
 RSI_OK = 0
 STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3: "RSI_ERR_HIP",

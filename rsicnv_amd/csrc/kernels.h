@@ -226,9 +226,10 @@ struct CandOut {
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
 };
 void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
-// one launch = one call of optimize_with_derivative for every job; ws: sharpen_workspace_bytes(njobs) bytes whose first
-// sharpen_workspace_zero_bytes(njobs) are zero before the first launch (each launch leaves them zero again)
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream);
+// one launch = one call of optimize_with_derivative for every job; ws: sharpen_workspace_bytes(ws_jobs) bytes laid out for
+// ws_jobs >= njobs jobs, whose first sharpen_workspace_zero_bytes(ws_jobs) are zero before the first launch (each launch
+// leaves them zero again, so a workspace is cleared once, when it is allocated).  jobs may be mapped host memory.
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream);
 size_t sharpen_workspace_bytes(int njobs);
 size_t sharpen_workspace_zero_bytes(int njobs);
 // The same test spread over several workgroups (four launches: the two walks side by side; chunked prefix + the candidate's

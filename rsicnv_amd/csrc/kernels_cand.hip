@@ -124,7 +124,8 @@ __host__ __device__ inline SharpenWs sharpen_views(void* ws, int njobs) {
 }
 
 __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __restrict__ rdc, int64_t ncompact,
-                                                            EdgeJob* __restrict__ jobs, int njobs, void* __restrict__ ws) {
+                                                            EdgeJob* __restrict__ jobs, int njobs /* capacity the workspace is laid out for */,
+                                                            void* __restrict__ ws) {
   __shared__ long long s_l[kMaxWaves];
   __shared__ long long s_v[kThreads / 64];
   __shared__ int s_i[kThreads / 64];
@@ -237,13 +238,14 @@ __device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int 
   };
   int vnext[4];
   load4(pos, vnext);
+  // the neighbour the walk may meet next: read when it changes, not per trip (the list may sit in mapped host memory)
+  int2 cur = ci < nchain ? chain[ci] : make_int2(1, 0);   // empty interval when the chain is used up
   while (room > 0 && (dir < 0 ? pos > 2 : (int64_t)pos < N - 2)) {
     const int par = trip & 1;
     ++trip;
     // positions of this trip in walk order: p_t = pos + dir*(1+t)
     const int avail = dir < 0 ? pos - 2 : (int)(N - 2 - pos);     // how many positions the walk may still visit
     const int cnt = avail < kWalkBlock ? avail : kWalkBlock;
-    const int2 cur = ci < nchain ? chain[ci] : make_int2(1, 0);   // empty interval when the chain is used up
     int v[4]; bool acc[4]; int nacc = 0; int trig = kNone;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = vnext[j];
@@ -302,6 +304,7 @@ __device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int 
       last = pos + dir * (1 + tstar);
       pos = dir < 0 ? cur.x - 1 : cur.y + 1;
       ++ci;
+      cur = ci < nchain ? chain[ci] : make_int2(1, 0);
       load4(pos, vnext);       // the prefetch was for the straight continuation
     } else {
       pos += dir * cnt;
@@ -825,9 +828,9 @@ void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long
   hipLaunchKernelGGL(k_range_sums, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums);
 }
 
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, hipStream_t stream) {
+void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, njobs, ws);
+  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws);
 }
 void launch_candidate_test_split(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                                  int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,

@@ -210,25 +210,39 @@ class DeviceTester : public rsih::NeighbourTester {
   double kernel_wait_ms = 0;
   int launches = 0;
 
+  // Jobs, neighbour lists and results of the candidate kernels live in the pinned mailbox (mapped host memory): the kernels
+  // read a few dozen bytes per workgroup from it and write their records into it, so a call is its launches and one wait --
+  // no upload, no download.  Lists too long for the mailbox take the copying path.
   bool sharpen(std::vector<Candidate>& L) override {
     if (L.empty()) return true;
-    std::vector<EdgeJob> jobs(L.size());
-    for (size_t i = 0; i < L.size(); ++i) jobs[i] = {L[i].start, L[i].end, L[i].type, 0};
-    const int nj = (int)jobs.size();
-    { Phase ph(ctx, "cand.ensure"); if (!ok(ctx->cand_jobs.ensure(jobs.size() * sizeof(EdgeJob))) || !ok(ctx->cand_i64.ensure(sharpen_workspace_bytes(nj)))) return false; }
-    uint8_t* ws = ctx->cand_i64.as<uint8_t>();
+    const int nj = (int)L.size();
+    EdgeJob* slot = static_cast<EdgeJob*>(mb_alloc(ctx, (size_t)nj * sizeof(EdgeJob)));
+    std::vector<EdgeJob> spill;
+    EdgeJob* jobs = slot;
+    if (!slot) { spill.resize((size_t)nj); jobs = spill.data(); }
+    for (int i = 0; i < nj; ++i) jobs[i] = {L[(size_t)i].start, L[(size_t)i].end, L[(size_t)i].type, 0};
+    {
+      Phase ph(ctx, "cand.ensure");
+      if (nj > ctx->sharpen_ws_jobs) {
+        const int cap = std::max(256, 2 * nj);
+        if (!ok(ctx->sharpen_ws.ensure(sharpen_workspace_bytes(cap)))) return false;
+        if (!ok(hipMemsetAsync(ctx->sharpen_ws.p, 0, sharpen_workspace_zero_bytes(cap), ctx->stream))) return false;
+        ctx->sharpen_ws_jobs = cap;
+      }
+      if (!slot && !ok(ctx->cand_jobs.ensure((size_t)nj * sizeof(EdgeJob)))) return false;
+    }
     GateShared gs(ctx);
     Phase ph(ctx, "cand.sharpen");
-    if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(EdgeJob)))) return false;
-    if (!ok(hipMemsetAsync(ws, 0, sharpen_workspace_zero_bytes(nj), ctx->stream))) return false;
+    EdgeJob* d_jobs = slot ? slot : ctx->cand_jobs.as<EdgeJob>();
+    if (!slot && !ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs, (size_t)nj * sizeof(EdgeJob)))) return false;
     for (int pass = 0; pass < 2; ++pass) {   // rsi.cpp:1876-1877
       Timer t(ctx, "sharpen_edges");
-      launch_sharpen_edges(d_rdc, N, ctx->cand_jobs.as<EdgeJob>(), nj, ws, ctx->stream);
+      launch_sharpen_edges(d_rdc, N, d_jobs, nj, ctx->sharpen_ws.p, ctx->sharpen_ws_jobs, ctx->stream);
     }
-    if (!ok(copy_d2h(ctx, jobs.data(), ctx->cand_jobs.p, jobs.size() * sizeof(EdgeJob)))) return false;
+    if (!slot && !ok(copy_d2h(ctx, jobs, ctx->cand_jobs.p, (size_t)nj * sizeof(EdgeJob)))) return false;
     if (!wait()) return false;
     gs.release();
-    for (size_t i = 0; i < L.size(); ++i) { L[i].start = jobs[i].start; L[i].end = jobs[i].end; }
+    for (int i = 0; i < nj; ++i) { L[(size_t)i].start = jobs[i].start; L[(size_t)i].end = jobs[i].end; }
     return true;
   }
 
@@ -287,20 +301,34 @@ class DeviceTester : public rsih::NeighbourTester {
       }
       GateShared gs(ctx);
       Phase ph(ctx, "cand.test");
-      if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(CandJob)))) return false;
-      if (!ok(copy_h2d(ctx, ctx->cand_chains.p, chains.data(), chains.size() * 4))) return false;
+      // jobs + chains + results in one mailbox slot (the kernels read / write mapped host memory); copies when it is too long
+      const size_t jb = (jobs.size() * sizeof(CandJob) + 63) & ~size_t(63), cb = (chains.size() * 4 + 63) & ~size_t(63);
+      const size_t ob = outs.size() * sizeof(CandOut);
+      unsigned char* slot = jb + cb + ob <= kMailboxMaxCopy ? static_cast<unsigned char*>(mb_alloc(ctx, jb + cb + ob)) : nullptr;
+      const CandJob* d_jobs = ctx->cand_jobs.as<CandJob>();
+      const void* d_chains = ctx->cand_chains.p;
+      CandOut* d_outs = ctx->cand_outs.as<CandOut>();
+      if (slot) {
+        memcpy(slot, jobs.data(), jobs.size() * sizeof(CandJob));
+        memcpy(slot + jb, chains.data(), chains.size() * 4);
+        d_jobs = reinterpret_cast<const CandJob*>(slot); d_chains = slot + jb; d_outs = reinterpret_cast<CandOut*>(slot + jb + cb);
+      } else {
+        if (!ok(copy_h2d(ctx, ctx->cand_jobs.p, jobs.data(), jobs.size() * sizeof(CandJob)))) return false;
+        if (!ok(copy_h2d(ctx, ctx->cand_chains.p, chains.data(), chains.size() * 4))) return false;
+      }
       {
         Timer t(ctx, "candidate_test");
         if (split)
-          launch_candidate_test_split(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
+          launch_candidate_test_split(d_rdc, N, d_jobs, (int)jobs.size(), d_chains, ctx->cand_i32.as<int32_t>(),
                                       ctx->cand_i64.as<long long>(), median, ctx->cand_mid.as<CandMid>(), ctx->cand_hist.as<uint32_t>(),
-                                      ctx->cand_outs.as<CandOut>(), ctx->stream);
+                                      d_outs, ctx->stream);
         else
-          launch_candidate_test(d_rdc, N, ctx->cand_jobs.as<CandJob>(), (int)jobs.size(), ctx->cand_chains.p, ctx->cand_i32.as<int32_t>(),
-                                ctx->cand_i64.as<long long>(), median, ctx->cand_outs.as<CandOut>(), ctx->stream);
+          launch_candidate_test(d_rdc, N, d_jobs, (int)jobs.size(), d_chains, ctx->cand_i32.as<int32_t>(),
+                                ctx->cand_i64.as<long long>(), median, d_outs, ctx->stream);
       }
-      if (!ok(copy_d2h(ctx, outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut)))) return false;
+      if (!slot && !ok(copy_d2h(ctx, outs.data(), ctx->cand_outs.p, outs.size() * sizeof(CandOut)))) return false;
       if (!wait()) return false;
+      if (slot) memcpy(outs.data(), d_outs, ob);
       gs.release();
       ph.stop();
       for (size_t k = 0; k < jobs.size(); ++k) {
@@ -328,11 +356,21 @@ class DeviceTester : public rsih::NeighbourTester {
       if (r.first < 0 || r.second >= N || r.second < r.first) return false;
       flat.push_back(r.first); flat.push_back(r.second);
     }
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+    const size_t fb = (flat.size() * 4 + 63) & ~size_t(63);
+    unsigned char* slot = static_cast<unsigned char*>(mb_alloc(ctx, fb + ranges.size() * 8));
+    GateShared gs(ctx);
+    if (slot) {   // ranges and sums in the mailbox
+      memcpy(slot, flat.data(), flat.size() * 4);
+      long long* d_sums = reinterpret_cast<long long*>(slot + fb);
+      { Timer t(ctx, "range_sums"); launch_range_sums(d_rdc, slot, (int)ranges.size(), d_sums, ctx->stream); }
+      if (!wait()) return false;
+      memcpy(sums.data(), d_sums, ranges.size() * 8);
+      return true;
+    }
     if (!ok(ctx->cand_chains.ensure(flat.size() * 4)) || !ok(ctx->cand_outs.ensure(ranges.size() * 8))) return false;
     if (!ok(copy_h2d(ctx, ctx->cand_chains.p, flat.data(), flat.size() * 4))) return false;
-    GateShared gs(ctx);
     { Timer t(ctx, "range_sums"); launch_range_sums(d_rdc, ctx->cand_chains.p, (int)ranges.size(), ctx->cand_outs.as<long long>(), ctx->stream); }
-    static_assert(sizeof(long long) == sizeof(int64_t), "int64");
     if (!ok(copy_d2h(ctx, sums.data(), ctx->cand_outs.p, ranges.size() * 8))) return false;
     return wait();
   }

@@ -151,6 +151,8 @@ struct rsi_ctx {
   DevBuf gsum;    // group sums of the in-kernel slab folds (device_util.h)
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64, cand_mid, cand_hist;   // candidate tests on the device (kernels_cand.hip)
+  DevBuf sharpen_ws;          // workspace of k_sharpen_edges, cleared when (re)allocated
+  int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
   bool have_gc = false, have_nb = false, have_med = false;
