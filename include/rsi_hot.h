@@ -78,6 +78,7 @@ typedef struct rsi_chrom_stats {
   int32_t inexact_sums; /* bins whose value breaks the exact-window-sum precondition */
   double t_device_ms;   /* wall time of the call, inputs already on the device */
   double t_kernels_ms;  /* sum of HIP-event times around the per-base kernels */
+  int64_t byte_escapes; /* bases of depth >= 255: the per-base kernels fetch those from the int32 array instead of the byte copy */
 } rsi_chrom_stats;
 
 typedef struct rsi_ctx rsi_ctx;

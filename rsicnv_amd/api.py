@@ -51,7 +51,8 @@ class RsiChromStats(C.Structure):
                 ("RDsd", C.c_double), ("nb_mad", C.c_double), ("nb_r", C.c_double), ("nb_tmin", C.c_double),
                 ("tmedian1", C.c_double), ("tsigma1", C.c_double), ("tlamda1", C.c_double), ("tmedian2", C.c_double),
                 ("tsigma2", C.c_double), ("tlamda2", C.c_double), ("trim_escapes", C.c_int32),
-                ("inexact_sums", C.c_int32), ("t_device_ms", C.c_double), ("t_kernels_ms", C.c_double)]
+                ("inexact_sums", C.c_int32), ("t_device_ms", C.c_double), ("t_kernels_ms", C.c_double),
+                ("byte_escapes", C.c_int64)]
 
 
 RSI_MAX_TIMED = 64

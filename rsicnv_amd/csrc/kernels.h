@@ -34,8 +34,11 @@ struct GcAccum {
   unsigned long long cnt[kGcLevels];
   unsigned long long possum, poscnt;   // over depth > 0
   unsigned int negatives;              // bit 0: depth < 0 seen (unsupported); bit 1: depth >= 2^21, packed form invalid
-  unsigned int pad;
+  unsigned int escapes;                // bases of kByteEscape and more (saturating count): their byte copy is the escape code
 };
+// K2 leaves a byte copy of the depth behind (depth8[i] = min(depth[i], kByteEscape)): the later per-base passes stream one
+// byte per base instead of four and turn to the int32 array only where a byte says kByteEscape.
+constexpr int kByteEscape = 255;
 // packed = 1: one LDS atomic per base (count and sum in one 64-bit word), valid for depths < 2^21;
 // when the result carries flag bit 1 the caller zeroes acc and launches again with packed = 0.
 // slabs: scratch of gc_hist_slab_bytes(n) bytes (per-workgroup partial results, folded by a second tiny kernel).
@@ -43,7 +46,7 @@ struct GcAccum {
 // (level means, then the mean of the positive depths): gccontent.cpp:109-112, 141-145.
 size_t gc_hist_slab_bytes(int64_t n);
 void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, int packed, void* slabs,
-                    void* gsum, unsigned int* counters, hipStream_t stream);
+                    void* gsum, unsigned int* counters, uint8_t* depth8 /* n + 16 bytes, or NULL */, hipStream_t stream);
 
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
@@ -63,6 +66,16 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
                        hipStream_t stream);
+// Only the rescaled array: out[] as the launch above leaves it, nothing else touched (rsi_hot_fetch of "rd_gc" when the run
+// itself streamed the byte copy and never wrote the int32 array).
+void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,
+                           unsigned int* counter, hipStream_t stream);
+// The value histogram of the rescaled depth from the byte copy, nothing written per base (what apply_cap's median needs,
+// loaddata.cpp:233); same last-workgroup work as launch_gc_rescale.
+size_t value_hist8_slab_bytes(int64_t n);
+void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                        uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
+                        const void* head_src, void* head_dst, size_t head_bytes, hipStream_t stream);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
 // (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;

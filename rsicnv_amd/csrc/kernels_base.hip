@@ -260,13 +260,13 @@ __device__ inline void sub_request(SubRegs& r, const int32_t* __restrict__ depth
 constexpr int kGcSlab = 2 * kGcLevels + 4;
 
 template <bool PACKED>
-__global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict__ depth,
+__global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restrict__ depth,
                                                       const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
                                                       unsigned long long* __restrict__ slabs, unsigned long long* __restrict__ gsum,
                                                       int per_group, unsigned int* __restrict__ counters,
-                                                      GcAccum* __restrict__ acc, double* __restrict__ table) {
+                                                      GcAccum* __restrict__ acc, double* __restrict__ table, uint8_t* __restrict__ d8) {
   __shared__ WaveGc s_gc[kThreads / 64];
-  __shared__ unsigned long long s_tail[3 * (kThreads / 64)];
+  __shared__ unsigned long long s_tail[4 * (kThreads / 64)];
   __shared__ unsigned long long s_sum[kGcLevels * kGcRep];
   __shared__ unsigned int s_cnt[PACKED ? 1 : kGcLevels * kGcRep];
   for (int e = threadIdx.x; e < kGcLevels * kGcRep; e += kThreads) { s_sum[e] = 0; if (!PACKED) s_cnt[e] = 0; }
@@ -275,9 +275,12 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
   WaveGc& G = s_gc[wave];
   const int rep = lane & (kGcRep - 1);
   unsigned long long possum = 0, poscnt = 0;
+  unsigned int escapes = 0;   // per lane: far below 2^32
   int vmax = 0, vmin = 0;
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+  // the byte copy of the depth (kByteEscape = "255 or more: look at the int32 array"), what K3 and K4 stream instead
+  auto sat8 = [](int v) -> uint32_t { return v < 0 ? 0u : (v >= kByteEscape ? (uint32_t)kByteEscape : (uint32_t)v); };
 
   auto trip = [&](const SubRegs& cur, SubRegs& nxt, int64_t sub) {
     const int64_t base = sub * kSubBases;
@@ -327,6 +330,15 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
       };
 #pragma unroll
       for (int k = 0; k < 4; ++k) { one(cur.q[k].x, 4 * k); one(cur.q[k].y, 4 * k + 1); one(cur.q[k].z, 4 * k + 2); one(cur.q[k].w, 4 * k + 3); }
+      if (d8) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          w[k] = sat8(cur.q[k].x) | (sat8(cur.q[k].y) << 8) | (sat8(cur.q[k].z) << 16) | (sat8(cur.q[k].w) << 24);
+          escapes += (cur.q[k].x >= kByteEscape) + (cur.q[k].y >= kByteEscape) + (cur.q[k].z >= kByteEscape) + (cur.q[k].w >= kByteEscape);
+        }
+        *reinterpret_cast<uint4*>(d8 + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only
       for (int j = 0; j < 16; ++j) {
         const int64_t i = i0 + j;
@@ -335,7 +347,9 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
         if (lo < 0) lo = 0;
         if (lo > n - 202) lo = n - 202;
         const uint32_t rel = (uint32_t)(lo - first_bit);
-        add(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+        const int val = depth[i];
+        add(val, wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+        if (d8) { d8[i] = (uint8_t)sat8(val); escapes += val >= kByteEscape; }
       }
     }
     flush();
@@ -357,9 +371,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
   for (int d = 32; d >= 1; d >>= 1) {
     possum += __shfl_xor(possum, d);
     poscnt += __shfl_xor(poscnt, d);
+    escapes += __shfl_xor(escapes, d);
     neg |= __shfl_xor(neg, d);
   }
-  if (lane == 0) { s_tail[3 * wave] = possum; s_tail[3 * wave + 1] = poscnt; s_tail[3 * wave + 2] = neg; }
+  if (lane == 0) { s_tail[4 * wave] = possum; s_tail[4 * wave + 1] = poscnt; s_tail[4 * wave + 2] = neg; s_tail[4 * wave + 3] = escapes; }
   __syncthreads();
   unsigned long long* slab = slabs + (size_t)blockIdx.x * kGcSlab;
   for (int g = threadIdx.x; g < kGcLevels; g += kThreads) {
@@ -372,10 +387,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
     st_cg(&slab[g], s2); st_cg(&slab[kGcLevels + g], c);
   }
   if (threadIdx.x == 0) {
-    unsigned long long ps = 0, pc = 0, fl = 0;
-    for (int w = 0; w < kThreads / 64; ++w) { ps += s_tail[3 * w]; pc += s_tail[3 * w + 1]; fl |= s_tail[3 * w + 2]; }
+    unsigned long long ps = 0, pc = 0, fl = 0, esc = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { ps += s_tail[4 * w]; pc += s_tail[4 * w + 1]; fl |= s_tail[4 * w + 2]; esc += s_tail[4 * w + 3]; }
     // the two flags as additive fields (number of workgroups that raised them), so that the fold can sum the slab
-    st_cg(&slab[2 * kGcLevels], ps); st_cg(&slab[2 * kGcLevels + 1], pc); st_cg(&slab[2 * kGcLevels + 2], (fl & 1ull) | ((fl >> 1) << 32)); st_cg(&slab[2 * kGcLevels + 3], 0ull);
+    st_cg(&slab[2 * kGcLevels], ps); st_cg(&slab[2 * kGcLevels + 1], pc); st_cg(&slab[2 * kGcLevels + 2], (fl & 1ull) | ((fl >> 1) << 32)); st_cg(&slab[2 * kGcLevels + 3], esc);
   }
   // ---- the last workgroup to finish folds the slabs (device_util.h), adds the ragged last n % 4 bases, which lie in the
   // stale-window zone i >= n-101 whose count is that of [n-202, n-2] (App. A Q1), and builds the GC table
@@ -392,6 +407,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
       total[kGcLevels + g] += 1ull;
       if (v > 0) { total[2 * kGcLevels] += (unsigned long long)v; total[2 * kGcLevels + 1] += 1ull; }
       if (v < 0) total[2 * kGcLevels + 2] |= 1ull;
+      if (d8) { d8[i] = (uint8_t)sat8(v); total[2 * kGcLevels + 3] += v >= kByteEscape; }
     }
   }
   __syncthreads();
@@ -408,7 +424,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_hist(const int32_t* __restrict_
   if (threadIdx.x == 0) {
     acc->possum = ps; acc->poscnt = pc;
     acc->negatives = ((fl & 0xffffffffull) ? 1u : 0u) | ((fl >> 32) ? 2u : 0u);
-    acc->pad = 0;
+    const unsigned long long esc = total[2 * kGcLevels + 3];
+    acc->escapes = esc > 0xffffffffull ? 0xffffffffu : (unsigned int)esc;   // bases whose byte copy says "look at the int32 array"
     table[kGcLevels] = rdmean;
   }
 }
@@ -424,11 +441,13 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
   const int lane = threadIdx.x;
   const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
   auto hist_add = [&](int to) {
+    if (!ghist) return;
     if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
     else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
     else atomicOr(&aux->negatives, 1u);
   };
   auto hist_sub = [&](int from) {
+    if (!ghist) return;
     if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
     else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
   };
@@ -460,13 +479,13 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
     const int nv = (int)((double)depth[20 * S + lane] * rdmean / table[gtail] + 0.5);
     const int64_t idx = n - 201 + lane;
     hist_sub(streamed(idx)); hist_add(nv);
-    out[idx] = nv;
+    if (out) out[idx] = nv;
   }
   if (lane < r) {   // the last r bases keep their unadjusted depth
     const int64_t idx = 20 * S + lane;
     if (idx < ragged) hist_sub(streamed(idx));
     hist_add(depth[idx]);
-    out[idx] = depth[idx];
+    if (out) out[idx] = depth[idx];
   }
 }
 
@@ -515,8 +534,6 @@ __device__ inline void value_median_block(const uint32_t* __restrict__ hist, uns
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// K3  gc_rescale (+ value histogram for the cap median)
 constexpr int kValLds = 256;   // values below this are counted in LDS, [value][32 lane phases]
 
 // rare path (values outside the LDS range): kept out of line so the unrolled callers stay small
@@ -528,6 +545,36 @@ __device__ __attribute__((noinline)) void value_hist_add(unsigned int* s_hist, u
   else { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)v); }
 }
 
+// What the last workgroup of a value-histogram kernel (K3, K3') does once every workgroup's LDS histogram s_hist
+// ([kValLds][32 lane phases]) is complete: per-workgroup slab, fold (device_util.h), tail quirks of the 20-slice
+// write-back, the walk to the median apply_cap needs (loaddata.cpp:233), and the chromosome's header (GC accumulators,
+// counters, median, the first N-run entries) into mapped host memory: what used to be three launches and a device -> host
+// copy behind the kernel.  All threads of every workgroup call it.
+template <bool ADJUST>
+__device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
+                                         int64_t n, const double* __restrict__ table, int32_t* __restrict__ out,
+                                         uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
+                                         unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum, int per_group,
+                                         unsigned int* __restrict__ counters, ValueMedian* __restrict__ vm, const void* head_src,
+                                         void* head_dst, unsigned int head_bytes) {
+  for (int v = threadIdx.x; v < kValLds; v += kThreads) {
+    unsigned int c = 0;
+    for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
+    st_cg(&hist_slabs[(size_t)blockIdx.x * kValLds + v], c);
+  }
+  unsigned int* total = s_hist;
+  if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
+  for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
+  __syncthreads();
+  if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
+  __syncthreads();
+  value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
+  __syncthreads();
+  export_words(head_dst, head_src, head_bytes);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  gc_rescale (+ value histogram for the cap median)
 template <bool ADJUST>
 __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restrict__ depth,
                                                          const uint64_t* __restrict__ gcbits, int64_t n,
@@ -537,7 +584,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
                                                          int per_group, unsigned int* __restrict__ counters,
                                                          ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
-                                                         unsigned int head_bytes) {
+                                                         unsigned int head_bytes, int materialize /* 1: only out[] is produced */) {
   __shared__ GcTile gt;
   __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
   __shared__ double s_table[kGcLevels];
@@ -576,7 +623,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
       const int v1 = one(cur.q[k].y, (g4 >> 8) & 0xffu);
       const int v2 = one(cur.q[k].z, (g4 >> 16) & 0xffu);
       const int v3 = one(cur.q[k].w, g4 >> 24);
-      if (((unsigned)v0 | (unsigned)v1 | (unsigned)v2 | (unsigned)v3) < (unsigned)kValLds) {   // the common case, branch-free
+      if (materialize) {
+      } else if (((unsigned)v0 | (unsigned)v1 | (unsigned)v2 | (unsigned)v3) < (unsigned)kValLds) {   // the common case, branch-free
         atomicAdd(&s_hist[v0 * 32 + phase], 1u); atomicAdd(&s_hist[v1 * 32 + phase], 1u);
         atomicAdd(&s_hist[v2 * 32 + phase], 1u); atomicAdd(&s_hist[v3 * 32 + phase], 1u);
       } else {
@@ -601,25 +649,122 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
     tile += gridDim.x;
   }
   __syncthreads();
-  // per-workgroup slab of kValLds counters, folded by k_hist_slab_reduce (no same-address atomics)
-  for (int v = threadIdx.x; v < kValLds; v += kThreads) {
-    unsigned int c = 0;
-    for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
-    st_cg(&hist_slabs[(size_t)blockIdx.x * kValLds + v], c);
+  if (materialize) {   // the tail quirks in out[], once every workgroup's stores are out
+    if (last_block_done(counters) && threadIdx.x < 64) gc_tail_fixup(depth, gcbits, n, table, 1, out, nullptr, nullptr);
+    return;
   }
-  // ---- the last workgroup to finish: folds the slabs into the value histogram, applies the tail quirks of the 20-slice
-  // write-back, walks the histogram to the median apply_cap needs (loaddata.cpp:233) and hands the chromosome's header
-  // (GC accumulators, counters, median, the first N-run entries) to the host through mapped memory: what used to be
-  // three launches and a device -> host copy behind this kernel ----
-  unsigned int* total = s_hist;
-  if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
-  for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
+  value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3'  value histogram of the rescaled depth from the byte copy: wave-autonomous like K2 (sub-tiles of 1024 bases, 16
+// consecutive bases = ONE 16-byte load per lane, GC words in a per-wave LDS slot, no workgroup barrier in the loop),
+// nothing written per base.  A lane whose 16 bytes contain the escape code fetches its 16 values from the int32 array.
+struct Sub8Regs { uint4 b; uint64_t gw; };
+__device__ inline void sub8_request(Sub8Regs& r, const uint8_t* __restrict__ d8, const uint64_t* __restrict__ gcbits,
+                                    int64_t nwords, int64_t base, int lane) {
+  r.b = *reinterpret_cast<const uint4*>(d8 + base + 16 * (int64_t)lane);   // the copy is padded to whole sub-tiles
+  const int64_t w = base / 64 - kGcLeft + lane;
+  r.gw = gcbits[(lane < kSubLds && w >= 0 && w < nwords) ? w : 0];
+}
+__device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
+  const uint32_t x = ~w;                          // a zero byte of x
+  return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
+}
+
+__global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth,
+                                                          const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
+                                                          const double* __restrict__ table, uint32_t* __restrict__ ghist,
+                                                          ValueHistAux* __restrict__ aux, unsigned int* __restrict__ hist_slabs,
+                                                          unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters,
+                                                          ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
+                                                          unsigned int head_bytes) {
+  __shared__ WaveGc s_gc[kThreads / 64];
+  __shared__ double s_table[kGcLevels];
+  __shared__ unsigned int s_hist[kValLds * 32];
+  for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
+  const double rdmean = table[kGcLevels];
   __syncthreads();
-  if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  WaveGc& G = s_gc[wave];
+  const int phase = lane & 31;
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+  const int64_t whole = n & ~(int64_t)3;   // the ragged last n % 4 bases belong to the tail fixup, as in K3
+
+  auto rescale = [&](int d, uint32_t g) { return (int)((double)d * rdmean / s_table[g] + 0.5); };   // gccontent.cpp:89, truncation
+  auto trip = [&](const Sub8Regs& cur, Sub8Regs& nxt, int64_t sub) {
+    const int64_t base = sub * kSubBases;
+    const int64_t first_bit = base - kGcLeft * 64;
+    {
+      const int64_t w = base / 64 - kGcLeft + lane;
+      const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
+      uint32_t c = __popcll(word), incl = c;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      if (lane < kSubLds + 1) { G.word[lane] = word; G.pre[lane] = incl - c; }
+    }
+    if (sub + stride < nsub) sub8_request(nxt, d8, gcbits, nwords, (sub + stride) * kSubBases, lane);
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = base + 16 * (int64_t)lane;
+    const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102 && base + kSubBases <= whole;
+    if (interior) {
+      const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
+      uint32_t cnt = wgc_rank(G, rel + 201) - wgc_rank(G, rel);
+      const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
+      int v[16];
+      const uint32_t w4[4] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
+      if (has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3])) {   // rare: the lane's 16 int32 values
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int4 q = *reinterpret_cast<const int4*>(depth + i0 + 4 * k);
+          v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (int)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu);
+      }
+      unsigned ored = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v[j] = rescale(v[j], cnt);
+        ored |= (unsigned)v[j];
+        cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+      }
+      if (ored < (unsigned)kValLds) {   // the common case, branch-free: sixteen LDS atomics into [value][lane phase]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * 32 + phase], 1u);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) value_hist_add(s_hist, ghist, aux, v[j], phase);
+      }
+    } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only, straight from the int32 array
+      for (int j = 0; j < 16; ++j) {
+        const int64_t i = i0 + j;
+        if (i >= whole) break;
+        int64_t lo = i - 100;
+        if (lo < 0) lo = 0;
+        if (lo > n - 202) lo = n - 202;
+        const uint32_t rel = (uint32_t)(lo - first_bit);
+        value_hist_add(s_hist, ghist, aux, rescale(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel)), phase);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
+  };
+
+  Sub8Regs ra, rb;
+  int64_t sub = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+  if (sub < nsub) sub8_request(ra, d8, gcbits, nwords, sub * kSubBases, lane);
+  while (sub < nsub) {
+    trip(ra, rb, sub);
+    sub += stride;
+    if (sub >= nsub) break;
+    trip(rb, ra, sub);
+    sub += stride;
+  }
   __syncthreads();
-  value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
-  __syncthreads();
-  export_words(head_dst, head_src, head_bytes);
+  value_hist_finish<true>(s_hist, depth, gcbits, n, table, nullptr, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -876,13 +1021,13 @@ static int gc_hist_grid(int64_t n) {
 size_t gc_hist_slab_bytes(int64_t n) { return (size_t)gc_hist_grid(n) * kGcSlab * 8; }
 size_t fold_scratch_bytes() { return (size_t)kFoldGroups * 256 * kResClasses * 4; }   // the widest slab (K4 at vr = 256)
 void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, int packed, void* slabs,
-                    void* gsum, unsigned int* counters, hipStream_t stream) {
+                    void* gsum, unsigned int* counters, uint8_t* depth8, hipStream_t stream) {
   const int grid = gc_hist_grid(n);
   unsigned long long* sl = static_cast<unsigned long long*>(slabs);
   unsigned long long* gs = static_cast<unsigned long long*>(gsum);
   const int pg = fold_per_group(grid);
-  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table);
-  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table);
+  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
+  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
 
@@ -895,8 +1040,29 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
-  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes);
-  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes);
+  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+}
+void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,
+                           unsigned int* counter, hipStream_t stream) {
+  const int grid = grid_for(n, kTileBases);
+  hipLaunchKernelGGL(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
+                     nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1);
+}
+static int value_hist8_grid(int64_t n) {
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  int64_t grid = (nsub + 3) / 4;
+  if (grid > 256 * 4) grid = 256 * 4;
+  return (int)(grid < 1 ? 1 : grid);
+}
+size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }
+void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                        uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
+                        const void* head_src, void* head_dst, size_t head_bytes, hipStream_t stream) {
+  const int grid = value_hist8_grid(n);
+  hipLaunchKernelGGL(k_value_hist8, dim3(grid), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, n / 64 + 1, table, hist, aux,
+                     static_cast<unsigned int*>(slabs), static_cast<unsigned int*>(gsum), fold_per_group(grid), counters, vm, head_src, head_dst,
+                     (unsigned int)head_bytes);
 }
 
 static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {

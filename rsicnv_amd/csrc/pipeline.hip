@@ -712,6 +712,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   }
   Phase ph_a1(ctx, "a1.classify+nruns");
   ctx->n = n; ctx->ncompact = 0; ctx->nb = 0; ctx->have_gc = ctx->have_nb = ctx->have_med = false;
+  ctx->rd_gc_valid = false; ctx->last_depth = d_depth;
   rsi_chrom_stats& S = res->stats;
   memset(&S, 0, sizeof(S));
   S.n = n;
@@ -769,9 +770,10 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // then issued once more with the two-atomic form
   auto issue_gc_chain = [&](int packed) -> int {
     if (P.gcadjust) {
-      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, st); }
-      HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-      { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+      // K2 leaves a byte copy of the depth; K3' streams that copy (1 byte per base instead of 4) and writes nothing per base
+      HIPCHK(ctx->depth8.ensure((size_t)n + 2048));
+      { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, ctx->depth8.as<uint8_t>(), st); }
+      { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
     } else if (want_cap) {
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
       { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
@@ -788,7 +790,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     memcpy(trans_raw.data(), head + kOffNtrans, (size_t)kEagerRuns * 8);
   };
   // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
-  if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), gc_rescale_slab_bytes(n))));
+  if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), std::max(gc_rescale_slab_bytes(n), value_hist8_slab_bytes(n)))));
   int rc = issue_gc_chain(1);
   if (rc != RSI_OK) return rc;
   ph_a1b.stop();
@@ -842,6 +844,11 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     double rdmean = (double)acc.possum;                       // gccontent.cpp:109-112 (the device's k_gc_table computes the same)
     if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
     S.gc_rdmean = rdmean;
+    S.byte_escapes = acc.escapes;
+    // TEMPORARY until K4 streams the byte copy itself: the rescaled int32 array for K4
+    HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
+    { Timer t(ctx, "gc_materialize", true); launch_gc_materialize(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->rd_gc.as<int32_t>(), d_done + 4 * kDoneStride, st); }
+    ctx->rd_gc_valid = true;
     d_src = ctx->rd_gc.as<int32_t>();
     ctx->have_gc = true;
   }

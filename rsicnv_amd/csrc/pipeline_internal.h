@@ -147,6 +147,7 @@ struct rsi_ctx {
   size_t text_pin_cap = 0;
   int64_t n_in = 0;                          // length of the depth currently in in_depth
   DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
+  DevBuf depth8;              // byte copy of the depth (K2 writes it, K3' and K4' stream it)
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf gsum;    // group sums of the in-kernel slab folds (device_util.h)
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
@@ -156,6 +157,8 @@ struct rsi_ctx {
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
   bool have_gc = false, have_nb = false, have_med = false;
+  bool rd_gc_valid = false;                  // rd_gc holds the rescaled depth of the last run (else rsi_hot_fetch builds it on demand)
+  const int32_t* last_depth = nullptr;       // device input of the last run (borrowed; needed to build rd_gc on demand)
   int last_scan_med = 0;
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
