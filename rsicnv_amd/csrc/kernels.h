@@ -103,6 +103,16 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
                             uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
                             const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
 
+// K4 fed from the byte copy of the RAW depth: the GC rescale happens inside, the rescaled int32 array is never needed.
+// Applies when cap_compact8_applies(): 1 <= capval < kByteEscape (every value fits a byte, res_hist is overwritten) and
+// m <= 104.  table: K2's [kGcLevels] level means + the mean of the positive depths.
+int cap_compact8_applies(int m, int32_t capval);
+size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact);
+void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                             const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                             int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
+
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =
 // complement of the smallest order key over the bins (atomicMax; zero on entry = nothing seen).

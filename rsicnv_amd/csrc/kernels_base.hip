@@ -656,6 +656,22 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
 }
 
+// The GC rescale without a division -- or any double arithmetic -- per base (f64 runs at half rate on gfx950, its
+// conversions at a quarter).  The reference's expression is (int)((double)d * rdmean / table[g] + 0.5) (gccontent.cpp:89:
+// product, IEEE division, truncation).  With ratio = (float)(rdmean / table[g]), f = fma((float)d, ratio, 0.5f) is within
+// 2^-23 (t + 0.5) of the reference's t + 0.5 (one rounding in the ratio, one in the fma; d < 2^24 is exact), so
+// floor(f) equals the reference's result unless f lies within tol = 2.5e-7 f + 1e-6 (twice that bound) of an integer.
+// Those bases raise `unsure` and the caller redoes them with the reference's own double expression: the result is the
+// reference's in every case; only one base in ten thousand takes the slow way.
+__device__ inline float rescale_f32(float d, float ratio, bool& unsure) {
+  const float f = __fmaf_rn(d, ratio, 0.5f);
+  const float fl = floorf(f);
+  const float fr = f - fl;
+  const float tol = __fmaf_rn(f, 2.5e-7f, 1.0e-6f);
+  unsure |= fabsf(fr - 0.5f) > 0.5f - tol;
+  return fl;
+}
+
 // ------------------------------------------------------------------------------------------
 // K3'  value histogram of the rescaled depth from the byte copy: wave-autonomous like K2 (sub-tiles of 1024 bases, 16
 // consecutive bases = ONE 16-byte load per lane, GC words in a per-wave LDS slot, no workgroup barrier in the loop),
@@ -681,10 +697,11 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
                                                           unsigned int head_bytes) {
   __shared__ WaveGc s_gc[kThreads / 64];
   __shared__ double s_table[kGcLevels];
+  __shared__ float s_ratio[kGcLevels];
   __shared__ unsigned int s_hist[kValLds * 32];
-  for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
-  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
   const double rdmean = table[kGcLevels];
+  for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(rdmean / t); }
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   WaveGc& G = s_gc[wave];
@@ -713,25 +730,35 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
       const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
       uint32_t cnt = wgc_rank(G, rel + 201) - wgc_rank(G, rel);
       const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
-      int v[16];
       const uint32_t w4[4] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
-      if (has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3])) {   // rare: the lane's 16 int32 values
+      const bool esc = has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3]);
+      const uint32_t cnt0 = cnt;
+      bool redo = esc;
+      int v[16];
+      if (!esc) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int4 q = *reinterpret_cast<const int4*>(depth + i0 + 4 * k);
-          v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        for (int j = 0; j < 16; ++j) {
+          v[j] = (int)rescale_f32((float)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu), s_ratio[cnt], redo);
+          cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
         }
-      } else {
+      }
+      if (redo) {   // rare: an escape byte (the lane's values come from the int32 array) or a rescaled value too close to
+                    // an integer boundary for the ratio form: the reference's own expression for the lane's sixteen bases
+        cnt = cnt0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = (int)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        for (int q = 0; q < 4; ++q) {
+          int4 x;
+          if (esc) x = *reinterpret_cast<const int4*>(depth + i0 + 4 * q);
+          else x = make_int4((int)(w4[q] & 0xffu), (int)((w4[q] >> 8) & 0xffu), (int)((w4[q] >> 16) & 0xffu), (int)(w4[q] >> 24));
+          v[4 * q] = rescale(x.x, cnt); cnt = cnt - ((leave >> (4 * q)) & 1u) + ((enter >> (4 * q)) & 1u);
+          v[4 * q + 1] = rescale(x.y, cnt); cnt = cnt - ((leave >> (4 * q + 1)) & 1u) + ((enter >> (4 * q + 1)) & 1u);
+          v[4 * q + 2] = rescale(x.z, cnt); cnt = cnt - ((leave >> (4 * q + 2)) & 1u) + ((enter >> (4 * q + 2)) & 1u);
+          v[4 * q + 3] = rescale(x.w, cnt); cnt = cnt - ((leave >> (4 * q + 3)) & 1u) + ((enter >> (4 * q + 3)) & 1u);
+        }
       }
       unsigned ored = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        v[j] = rescale(v[j], cnt);
-        ored |= (unsigned)v[j];
-        cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
-      }
+      for (int j = 0; j < 16; ++j) ored |= (unsigned)v[j];
       if (ored < (unsigned)kValLds) {   // the common case, branch-free: sixteen LDS atomics into [value][lane phase]
 #pragma unroll
         for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * 32 + phase], 1u);
@@ -984,6 +1011,280 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   export_words(exp_dst, exp_src, exp_bytes);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K4'  cap_compact_bin8: K4 fed from the byte copy of the RAW depth.  The GC rescale (gccontent.cpp:89) happens here, so
+// the rescaled int32 array is never written or read: per base this kernel reads 1 byte + 1 mask bit and writes the 4 bytes
+// of the capped, compacted depth -- 5.2 B/base against 8.4 for K4 behind a K3 that writes 4 more.
+//
+// A plain tile (no removed region cuts it) is a contiguous SOURCE range; it is covered by 16-byte chunks aligned in the
+// source, thread t owning chunk t (and t + 256): 16 consecutive bases = one 16-byte load, requested one tile ahead.
+// The window GC counts of 16 consecutive bases are two rank queries and one leaving / entering bit pair each (as in K2);
+// the tile's GC words sit in LDS with their popcount prefix.  Values are capped below 255 (the kernel is used when the
+// cap is), so the tile's values live in LDS as BYTES, chunk-aligned (ds_write_b128, conflict-free), and the per-bin
+// median phase reads its bin's bytes at whatever offset they have.  A chunk with an escape byte fetches its 16 values
+// from the int32 array.  Tiles that touch the chromosome's ends (clamped windows, App. A Q1; the tail quirks of the
+// 20-slice write-back, Q2/Q3) or are cut by a removed region take a per-element path that works from the int32 array.
+constexpr int kGc4Words = 112;   // staged GC words of a tile: 4 margin + up to 105 + 2 margin
+struct Gc4Tile { uint64_t word[kGc4Words]; uint32_t pre[kGc4Words + 1]; };
+__device__ inline uint32_t g4_rank(const Gc4Tile& t, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  const uint64_t m = b ? (t.word[k] & ((1ull << b) - 1)) : 0;
+  return t.pre[k] + (uint32_t)__popcll(m);
+}
+__device__ inline uint32_t g4_field16(const Gc4Tile& t, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  uint64_t v = t.word[k] >> b;
+  if (b > 48) v |= t.word[k + 1] << (64 - b);
+  return (uint32_t)v & 0xffffu;
+}
+// #GC in [lo, lo + 201) straight from the mask in HBM (per-element path only)
+__device__ inline int gc_count201(const uint64_t* __restrict__ gcbits, int64_t lo) {
+  int c = 0;
+  int64_t p = lo;
+  const int64_t end = lo + 201;
+  while (p < end) {
+    const int64_t w = p >> 6;
+    const int b = (int)(p & 63);
+    int take = 64 - b;
+    if (p + take > end) take = (int)(end - p);
+    uint64_t x = gcbits[w] >> b;
+    if (take < 64) x &= (1ull << take) - 1;
+    c += __popcll(x);
+    p += take;
+  }
+  return c;
+}
+
+struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t x, y, z, w; };   // 16 bytes at any byte address (gfx950 loads them in one go)
+
+template <int MAXC, int EPT>
+__global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
+    const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
+    const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
+    int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, int32_t* __restrict__ rdc, int32_t* __restrict__ binmed,
+    int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
+    int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
+  __shared__ Gc4Tile gt;
+  __shared__ double s_table[kGcLevels];
+  __shared__ float s_ratio[kGcLevels];
+  __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(table[kGcLevels] / t); }
+  if (nreg <= kRegInline) {
+    for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
+    for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
+  } else {
+    for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
+    for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  }
+  const double rdmean = table[kGcLevels];
+  __syncthreads();
+  const RegionTable R{cbreak, cum, nreg, s_break, s_cum};
+
+  const int64_t lim31 = (ncompact / 31) * 31;
+  const int64_t nb = ncompact / m;
+  const int tile_elems = TB * m;            // a multiple of 16 (TB = 64)
+  const int nchunks = tile_elems / 16;
+  const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
+  const int parts = kThreads / TB;          // threads cooperating on one bin
+  const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
+  // the 20-slice write-back's tail (App. A Q2/Q3): cells n-201 .. n-201+r-1 carry the rescaled depth of the last r bases,
+  // computed with the fresh edge window [n-201, n-1]; the last r bases keep their raw depth
+  const int64_t S20 = n / 20, r20 = n - 20 * S20;
+  const int64_t zone = n - 201;             // no fast-path tile may reach this base (also covers the clamped windows, i >= n-101)
+
+  auto rescale = [&](int d, uint32_t g) { return (int)((double)d * rdmean / s_table[g] + 0.5); };   // gccontent.cpp:89, truncation
+  auto slow_value = [&](int64_t i) -> int {   // the value K3 + its tail fixup would have left at source index i
+    if (r20 >= 2 && i >= n - 201 && i < n - 201 + r20) return rescale(depth[20 * S20 + (i - (n - 201))], (uint32_t)gc_count201(gcbits, n - 201));
+    if (i >= 20 * S20) return depth[i];
+    int64_t lo = i - 100;
+    if (lo < 0) lo = 0;
+    if (lo > n - 202) lo = n - 202;
+    return rescale(depth[i], (uint32_t)gc_count201(gcbits, lo));
+  };
+
+  int k = 0;
+  auto geometry = [&](int64_t tile, int64_t& P0, int64_t& P1, bool& fast, int64_t& soff) {
+    P0 = tile * tile_elems;
+    P1 = (P0 + tile_elems < ncompact) ? P0 + tile_elems : ncompact;
+    while (k < nreg && R.brk(k) <= P0) ++k;   // tiles are visited in increasing order
+    const bool plain = (k >= nreg) || (R.brk(k) >= P1);
+    soff = P0 + R.shift(k);
+    // fast: a whole tile, contiguous in the source, every base with an unclamped window, before the tail zone and before
+    // the last partial stride of the 31 MAD residue classes
+    fast = plain && P1 - P0 == tile_elems && P1 <= lim31 && soff >= 101 && soff + tile_elems <= zone;
+  };
+  // Chunks are aligned in the COMPACTED array (16 values = 64 aligned bytes of rdc, 16 aligned bytes of the LDS tile); in the
+  // source they start at any byte, which a 16-byte load of the byte copy does not mind.
+  uint4 regs[MAXC];
+  uint64_t gwa = 0, gwb = 0;
+  auto request = [&](int64_t soff) {   // branch-free: chunks beyond the tile re-read chunk 0 (ignored later)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int kc = c * kThreads + (int)threadIdx.x;
+      const Bytes16 b = *reinterpret_cast<const Bytes16*>(d8 + soff + 16 * (kc < nchunks ? kc : 0));
+      regs[c] = make_uint4(b.x, b.y, b.z, b.w);
+    }
+    if (threadIdx.x < 64) {
+      const int64_t w0 = (soff >> 6) - 4 + (int)threadIdx.x, w1 = w0 + 64;
+      gwa = gcbits[(w0 >= 0 && w0 < nwords) ? w0 : 0];
+      gwb = gcbits[((int)threadIdx.x < kGc4Words - 64 && w1 >= 0 && w1 < nwords) ? w1 : 0];
+    }
+  };
+
+  int64_t P0, P1, soff; bool fast;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) { geometry(tile, P0, P1, fast, soff); if (fast) request(soff); }
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();   // s_val and the GC tile are free (and s_hist zeroed on the first trip)
+    if (fast) {
+      if (threadIdx.x < 64) {   // wave 0 commits the tile's GC words with their popcount prefix
+        const int l = threadIdx.x;
+        const int64_t w0 = (soff >> 6) - 4 + l, w1 = w0 + 64;
+        const uint64_t a = (w0 >= 0 && w0 < nwords) ? gwa : 0;
+        const uint64_t b = (l < kGc4Words - 64 && w1 >= 0 && w1 < nwords) ? gwb : 0;
+        gt.word[l] = a;
+        uint32_t c = __popcll(a), incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (l >= d) incl += up; }
+        gt.pre[l] = incl - c;
+        const uint32_t total = __shfl(incl, 63);
+        if (l < kGc4Words - 64) gt.word[64 + l] = b;
+        uint32_t c2 = __popcll(b), incl2 = c2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl2, d); if (l >= d) incl2 += up; }
+        if (l < kGc4Words - 64) gt.pre[64 + l] = total + incl2 - c2;
+        if (l == kGc4Words - 64 - 1) gt.pre[kGc4Words] = total + incl2;
+      }
+      __syncthreads();
+      const int64_t first_bit = ((soff >> 6) - 4) * 64;
+      const uint32_t rel0 = (uint32_t)(soff - 100 - first_bit);   // staged bit of the window start of the tile's first base
+      const uint32_t p0mod = (uint32_t)(P0 % 31);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int kc = c * kThreads + (int)threadIdx.x;
+        if (kc >= nchunks) continue;
+        const uint32_t w4[4] = {regs[c].x, regs[c].y, regs[c].z, regs[c].w};
+        const bool esc = has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3]);
+        const uint32_t rel = rel0 + 16u * (uint32_t)kc;
+        const uint32_t g0 = g4_rank(gt, rel + 201) - g4_rank(gt, rel);
+        const uint32_t leave = g4_field16(gt, rel), enter = g4_field16(gt, rel + 201);
+        uint32_t g = g0;
+        bool redo = esc;
+        int v[16];
+        if (!esc) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            v[j] = (int)rescale_f32((float)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu), s_ratio[g], redo);
+            g = g - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+          }
+        }
+        if (redo) {   // rare: an escape byte (the chunk's values come from the int32 array) or a rescaled value too close to
+                      // an integer boundary for the ratio form: the reference's own expression for the chunk's sixteen bases
+          g = g0;
+          const int64_t i0 = soff + 16 * (int64_t)kc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int4 x;
+            if (esc) { const Quad4 y = *reinterpret_cast<const Quad4*>(depth + i0 + 4 * q); x = make_int4(y.x, y.y, y.z, y.w); }
+            else x = make_int4((int)(w4[q] & 0xffu), (int)((w4[q] >> 8) & 0xffu), (int)((w4[q] >> 16) & 0xffu), (int)(w4[q] >> 24));
+            v[4 * q] = rescale(x.x, g); g = g - ((leave >> (4 * q)) & 1u) + ((enter >> (4 * q)) & 1u);
+            v[4 * q + 1] = rescale(x.y, g); g = g - ((leave >> (4 * q + 1)) & 1u) + ((enter >> (4 * q + 1)) & 1u);
+            v[4 * q + 2] = rescale(x.z, g); g = g - ((leave >> (4 * q + 2)) & 1u) + ((enter >> (4 * q + 2)) & 1u);
+            v[4 * q + 3] = rescale(x.w, g); g = g - ((leave >> (4 * q + 3)) & 1u) + ((enter >> (4 * q + 3)) & 1u);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = v[j] > capval ? capval : v[j];
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
+        *reinterpret_cast<uint4*>(s_val + 16 * kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        int32_t* out = rdc + P0 + 16 * (int64_t)kc;   // 64-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<int4*>(out + 4 * q) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        // sixteen LDS atomics into [value][MAD residue class]: the class of element j is cls0 + j, minus 31 from the lane's
+        // wrap point on; the element index rides in the instruction's offset field
+        const uint32_t cls0 = (p0mod + 16u * (uint32_t)kc) % 31u;
+        unsigned int* ha = s_hist + cls0;
+        unsigned int* hb = ha - 31;
+        const int jw = 31 - (int)cls0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) atomicAdd((j >= jw ? hb : ha) + v[j] * kResClasses + j, 1u);
+      }
+    } else {
+      // ---- per-element path: contiguous source segments between removed regions, values from the int32 array ----
+      int kk = k;
+      int64_t seg = P0;
+      while (seg < P1) {
+        const int64_t nxt = (kk < nreg && R.brk(kk) < P1) ? R.brk(kk) : P1;
+        const int64_t len = nxt - seg;
+        if (len > 0) {
+          const int64_t so = seg + R.shift(kk);
+          const int dst = (int)(seg - P0);
+          for (int64_t e = threadIdx.x; e < len; e += kThreads) {
+            int x = slow_value(so + e);
+            if (x > capval) x = capval;
+            if (x < 0) x = 0;   // negative depth is refused by the caller (K2's flag); keep the byte store in range
+            s_val[dst + e] = (unsigned char)x;
+            rdc[seg + e] = x;
+            const int64_t p = seg + e;
+            atomicAdd(&s_hist[x * kResClasses + (p < lim31 ? (int)((uint32_t)p % 31u) : 31)], 1u);
+          }
+        }
+        seg = nxt;
+        if (kk < nreg && R.brk(kk) == nxt) ++kk;
+      }
+    }
+    __syncthreads();
+    // ---- request the next tile now: its loads fly during the median phase ----
+    const int64_t cur_tile = tile;
+    if (tile + gridDim.x < ntiles) { geometry(tile + gridDim.x, P0, P1, fast, soff); if (fast) request(soff); }
+    // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin, values in registers ----
+    const int b_local = threadIdx.x / parts, part = threadIdx.x % parts;
+    const int64_t b = cur_tile * TB + b_local;
+    const bool active = b < nb;
+    const unsigned char* x = s_val + b_local * m;
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    int ssum = 0;
+    int r[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int j = part + parts * i;
+      const bool in = active && j < m;
+      const int val = in ? (int)x[j] : 0x7fffffff;   // slots past the bin hold INT_MAX (never <= mid)
+      r[i] = val;
+      lo = (in && val < lo) ? val : lo; hi = (in && val > hi) ? val : hi; ssum += in ? val : 0;
+    }
+    for (int d = 1; d < parts; d <<= 1) {
+      const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d), os = __shfl_xor(ssum, d);
+      lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; ssum += os;
+    }
+    while (__any(active && lo < hi)) {   // bisection on the value: smallest v with #{x <= v} >= kth
+      const int mid = (lo + hi) >> 1;
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) c += r[i] <= mid;
+      for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
+      if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
+    }
+    if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+  }
+  __syncthreads();
+  // ---- per-workgroup histogram slab; the last workgroup folds them into res_hist (every value is below vr: overwrite)
+  // and hands [BinAccum | histogram] to the host ----
+  unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
+  if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&res_hist[e], s_hist[e]);
+  __syncthreads();
+  export_words(exp_dst, exp_src, exp_bytes);
+}
+
 inline int grid_for(int64_t items, int per_block) {
   int64_t g = (items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1077,6 +1378,43 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact) {
   int TB, vr, grid;
   k4_geometry(m, capval, ncompact, TB, vr, grid);
   return (size_t)grid * vr * kResClasses * 4;
+}
+// K4' applies when the cap keeps every value in a byte below the escape code and the bin fits the register median phase.
+int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteEscape && m <= 104 ? 1 : 0; }
+static void k48_geometry(int m, int32_t capval, int64_t ncompact, int& vr, int& grid, int& maxc) {
+  vr = 64;
+  while (vr < 256 && vr <= capval) vr <<= 1;
+  const int64_t tile = (int64_t)64 * m;
+  const int64_t ntiles = (ncompact + tile - 1) / tile;
+  grid = (int)(ntiles < 256 * 4 ? (ntiles < 1 ? 1 : ntiles) : 256 * 4);
+  maxc = tile / 16 <= kThreads ? 1 : 2;
+}
+size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact) {
+  int vr, grid, maxc;
+  k48_geometry(m, capval, ncompact, vr, grid, maxc);
+  return (size_t)grid * vr * kResClasses * 4;
+}
+void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                             const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                             int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
+  int vr, grid, maxc;
+  k48_geometry(m, capval, ncompact, vr, grid, maxc);
+  const int TB = 64;
+  const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
+  unsigned int* sl = static_cast<unsigned int*>(slabs);
+  unsigned int* gs = static_cast<unsigned int*>(gsum);
+  const int pg = fold_per_group(grid);
+  const int ept = (m + 3) / 4;
+#define RSI_K48(MC, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP>));                                                          \
+    hipLaunchKernelGGL((k_cap_compact_bin8<MC, EP>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
+                       cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
+                       exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
+  if (maxc == 1 && ept <= 13) RSI_K48(1, 13);
+  else if (ept <= 13) RSI_K48(2, 13);
+  else if (maxc == 1) RSI_K48(1, 26);
+  else RSI_K48(2, 26);
+#undef RSI_K48
 }
 int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact) {
   int TB, vr, grid;

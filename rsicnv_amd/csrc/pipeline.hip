@@ -694,6 +694,19 @@ struct PerBase {
 };
 constexpr size_t kResHead = 256;     // BinAccum sits in a header of the residue-class histogram: cleared and fetched with it
 
+// The GC-rescaled int32 array (what the reference leaves in RD after checkgccontent, gccontent.cpp:95): the run streams the
+// byte copy and never writes it, so it is built when somebody asks -- rsi_hot_fetch("rd_gc"), or K4 on the configurations K4'
+// does not cover -- from the last run's depth (still the caller's buffer), mask and GC table (still in the workspace).
+int materialize_rd_gc(rsi_ctx* ctx) {
+  if (ctx->rd_gc_valid) return RSI_OK;
+  if (!ctx->have_gc || !ctx->last_depth) return fail(ctx, RSI_ERR_BAD_ARG, "no GC-adjusted run to build rd_gc from");
+  uint8_t* small = ctx->small.as<uint8_t>();
+  HIPCHK(ctx->rd_gc.ensure((size_t)(ctx->n + 4) * 4));
+  { Timer t(ctx, "gc_materialize", true); launch_gc_materialize(ctx->last_depth, ctx->gcbits.as<uint64_t>(), ctx->n, reinterpret_cast<double*>(small + kOffTable), ctx->rd_gc.as<int32_t>(), reinterpret_cast<unsigned int*>(small + kOffDone) + 4 * kDoneStride, ctx->stream); }
+  ctx->rd_gc_valid = true;
+  return RSI_OK;
+}
+
 // A1-A9: GC mask and N runs, GC table and rescale, cap, compaction, bins, chromosome statistics (K1-K4).  The kernels are
 // HBM-bound: workers of a pool take turns through this phase (GpuGate, held until the function returns).
 int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n, rsi_result* res,
@@ -845,12 +858,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     if (acc.poscnt > 0) rdmean /= (double)acc.poscnt;
     S.gc_rdmean = rdmean;
     S.byte_escapes = acc.escapes;
-    // TEMPORARY until K4 streams the byte copy itself: the rescaled int32 array for K4
-    HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
-    { Timer t(ctx, "gc_materialize", true); launch_gc_materialize(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->rd_gc.as<int32_t>(), d_done + 4 * kDoneStride, st); }
-    ctx->rd_gc_valid = true;
-    d_src = ctx->rd_gc.as<int32_t>();
-    ctx->have_gc = true;
+    ctx->have_gc = true;   // rsi_hot_fetch builds the rescaled int32 array on demand (materialize_rd_gc)
   }
   // ---- A4: cap from the median of the uncompacted array (loaddata.cpp:229-240, Q15) ----
   int32_t capval = 0x7fffffff;
@@ -901,11 +909,26 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // cap below the kernel's LDS value range the fold overwrites res_hist (nothing to clear); otherwise (no cap, or a cap
   // of 256 and more) stray values reach res_hist through global atomics and it is cleared first.
   const size_t exp_bytes = kResHead + res_vals * kResClasses * 4;
-  const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact) != 0;
-  if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
   uint32_t* exp_slot = exp_bytes <= kMailboxMaxCopy ? static_cast<uint32_t*>(mb_alloc(ctx, exp_bytes)) : nullptr;
-  HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
-  { Timer t(ctx, "cap_compact_bin", true); launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st); }
+  if (P.gcadjust && want_cap && cap_compact8_applies(P.m, capval)) {
+    // K4': from the byte copy of the raw depth, rescaling on the way -- the rescaled int32 array is never written or read
+    HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
+    Timer t(ctx, "cap_compact_bin", true);
+    launch_cap_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+                            ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
+                            ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
+  } else {
+    if (P.gcadjust) {   // no cap, a cap of 255 and more, or a wide bin: K4 from the rescaled int32 array, built first
+      int rcm = materialize_rd_gc(ctx);
+      if (rcm != RSI_OK) return rcm;
+      d_src = ctx->rd_gc.as<int32_t>();
+    }
+    const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact) != 0;
+    if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
+    HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
+    Timer t(ctx, "cap_compact_bin", true);
+    launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
+  }
   BinAccum bacc;
   std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);
   if (!exp_slot) HIPCHK(copy_d2h(ctx, hres_all.data(), ctx->hist_res.p, hres_all.size() * 4));
@@ -1215,7 +1238,10 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   if (!ctx || !name) return RSI_ERR_BAD_ARG;
   const std::string s(name);
   const void* src = nullptr; int64_t cnt = 0;
-  if (s == "rd_gc" && ctx->have_gc) { src = ctx->rd_gc.p; cnt = ctx->n; }
+  if (s == "rd_gc" && ctx->have_gc) {
+    if (out) { HIPCHK(hipSetDevice(ctx->device)); const int rcm = materialize_rd_gc(ctx); if (rcm != RSI_OK) return rcm; }
+    src = out ? ctx->rd_gc.p : static_cast<const void*>(ctx); cnt = ctx->n;
+  }
   else if (s == "rd_concat") { src = ctx->rdc.p; cnt = ctx->ncompact; }
   else if (s == "depth_in" && ctx->in_depth.p) { src = ctx->in_depth.p; cnt = ctx->n_in; }
   else if (s == "binmedint") { src = ctx->binmed.p; cnt = ctx->nb; }

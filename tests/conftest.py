@@ -38,6 +38,11 @@ def small_cases():
         ("poisson_nocap", dict(n=350_019, seed=0xA11D2, model=0, n_events=4, gaps=1, max_len=20000, end_n=5000, gap_len=8000), dict(cap=-1.0)),
         ("gampois_all", dict(n=450_000, seed=0xB0D, model=1, n_events=5, gaps=1, max_len=20000, end_n=5000, gap_len=6000), dict(trans=2)),
         ("poisson_no_n", dict(n=300_000, seed=0xA11D3, model=0, n_events=4, gaps=0, max_len=15000, end_n=0), dict()),
+        # no N at the chromosome ends: the clamped GC windows (Q1) and the tail cells of the 20-slice write-back (Q2/Q3)
+        # survive into the compacted array, where the kernel that rescales from the byte copy has to reproduce them
+        ("poisson_no_n_tail13", dict(n=300_013, seed=0xA11D4, model=0, n_events=4, gaps=0, max_len=15000, end_n=0), dict()),
+        ("gampois_no_n_tail1", dict(n=320_001, seed=0xB0E, model=1, n_events=4, gaps=1, max_len=15000, end_n=0, gap_len=5000), dict(m=51, trans=1)),
+        ("gampois_no_n_tail19", dict(n=280_019, seed=0xB0F, model=1, mean=45.0, n_events=4, gaps=0, max_len=15000, end_n=0), dict()),
     ]
 
 

@@ -44,7 +44,10 @@ def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     cases = wide_scan_cases() if (len(sys.argv) > 1 and sys.argv[1] == "wide") else small_cases()
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 else None   # python tools/make_golden.py small NAME [NAME ...]
     for name, plan_kw, flag_kw in cases:
+        if only is not None and name not in only:
+            continue
         plan, fasta, depth = make_case(lib, plan_kw)
         p = oracle.make_params(**flag_kw)
         R.load(p, depth, fasta)
