@@ -37,9 +37,14 @@ __device__ inline void fill_ranges(const FillList& f) {
 // Hand-over between workgroups of ONE launch without fences.  An agent-scope fence (__threadfence) writes back the whole
 // L2 of the XCD on gfx942 / gfx950 (buffer_wbl2) -- with a streaming kernel's dirty output in it that costs microseconds
 // per workgroup, a millisecond per launch.  Instead: everything one workgroup hands to another is written with st_cg
-// (agent-scope store, write-through to the coherence point) or with atomics, the writer's __syncthreads() waits for those to
-// complete, only then does it bump the arrival counter; the reader uses ld_cg (agent-scope load).  Plain loads of data
-// other workgroups of the same launch wrote with plain stores are NOT safe and not used.
+// (agent-scope store, write-through to the coherence point) or with atomics; every wave of the writer waits for its own
+// stores and atomics to complete (drain(): s_waitcnt vmcnt(0) -- a workgroup barrier alone does not wait for global
+// stores on this target), the workgroup meets at a barrier, and only then does one lane bump the arrival counter; the
+// reader uses ld_cg (agent-scope load).  Plain loads of data other workgroups of the same launch wrote with plain stores
+// are NOT safe and not used.
+__device__ inline void drain() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's memory operations are done
+// barrier after which every thread of the workgroup may ld_cg what any of its threads wrote with st_cg / atomics before it
+__device__ inline void sync_drained() { drain(); __syncthreads(); }
 __device__ inline void st_cg(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_cg(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline unsigned int ld_cg(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -51,6 +56,7 @@ __device__ inline int ld_cg(const int* p) { return __hip_atomic_load(p, __ATOMIC
 // workgroup must call it (it synchronises the workgroup).
 __device__ inline bool last_block_done(unsigned int* counter) {
   __shared__ unsigned int s_last__;
+  drain();
   __syncthreads();   // this workgroup's st_cg stores and atomics have completed
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(counter, 1u);
@@ -78,6 +84,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   const int g = (int)blockIdx.x / per_group;
   const int ngroups = (nblocks + per_group - 1) / per_group;
   const int members = (g + 1) * per_group <= nblocks ? per_group : nblocks - g * per_group;
+  drain();
   __syncthreads();   // the slab's st_cg stores have completed
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(&counters[1 + g], 1u);
@@ -94,6 +101,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
     for (int k = 0; k < members; ++k) s += ld_cg(col + (size_t)k * width);
     st_cg(gsum + (size_t)g * width + e, s);
   }
+  drain();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int t = atomicAdd(&counters[0], 1u);

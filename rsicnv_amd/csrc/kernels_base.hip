@@ -565,11 +565,11 @@ __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __
   unsigned int* total = s_hist;
   if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
   for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
-  __syncthreads();
+  sync_drained();
   if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
-  __syncthreads();
+  sync_drained();
   value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
-  __syncthreads();
+  sync_drained();
   export_words(head_dst, head_src, head_bytes);
 }
 
@@ -649,10 +649,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
     tile += gridDim.x;
   }
   __syncthreads();
-  if (materialize) {   // the tail quirks in out[], once every workgroup's stores are out
-    if (last_block_done(counters) && threadIdx.x < 64) gc_tail_fixup(depth, gcbits, n, table, 1, out, nullptr, nullptr);
-    return;
-  }
+  if (materialize) return;   // the tail quirks are applied to out[] by a launch of their own (k_gc_tail_fixup_out)
   value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
 }
 
@@ -1007,7 +1004,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     const unsigned int c = s_hist[e];
     if (overwrite) st_cg(&res_hist[e], c); else if (c) atomicAdd(&res_hist[e], c);
   }
-  __syncthreads();
+  sync_drained();
   export_words(exp_dst, exp_src, exp_bytes);
 }
 
@@ -1281,7 +1278,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
   if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&res_hist[e], s_hist[e]);
-  __syncthreads();
+  sync_drained();
   export_words(exp_dst, exp_src, exp_bytes);
 }
 
@@ -1341,14 +1338,24 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
+  // adjust = 1 is not issued by the pipeline any more (K3' builds the histogram from the byte copy, launch_gc_materialize the
+  // array): in one launch the tail cells of out[] would be stored twice, by the streaming loop and by the last workgroup,
+  // from different XCDs -- no defined order.  Kept for the -NOGC histogram (adjust = 0, out = NULL).
   if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
   else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+}
+// The tail quirks in out[] as a launch of its own: the cells it rewrites were written by other workgroups of the streaming
+// launch, and two stores to one address from different XCDs within one launch have no defined order.
+__global__ void k_gc_tail_fixup_out(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                                    const double* __restrict__ table, int32_t* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) gc_tail_fixup(depth, gcbits, n, table, 1, out, nullptr, nullptr);
 }
 void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,
                            unsigned int* counter, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   hipLaunchKernelGGL(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
                      nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1);
+  hipLaunchKernelGGL(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
 }
 static int value_hist8_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;

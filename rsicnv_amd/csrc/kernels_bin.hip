@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict_
   }
   if (!last_block_done(counter)) return;
   if (!g->flags) grid_walk_block(hist, g);
-  __syncthreads();
+  sync_drained();
   for (int k = 0; k < 2; ++k) export_words(ex.dst[k], ex.src[k], ex.bytes[k]);
 }
 
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   __syncthreads();
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) st_cg(&hist_u[e], s_u[e]);
   if (threadIdx.x == 0) { st_cg(&head[2], ldel); st_cg(&head[3], stop_level_walk(s_u, Lmax, nb)); }
-  __syncthreads();
+  sync_drained();
   export_words(host_copy, work, host_bytes);
 }
 
