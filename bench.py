@@ -2,26 +2,42 @@
 """bench.py -- bases/s through the RSI read-depth hot path on MI355X.
 
 A "step" is one pass of the whole hot path (GC correction -> cap -> N removal -> bins -> NB
-transform -> RSI scan -> calls) over one synthetic genome already resident in HBM: the 24
-chromosomes totalling 3.0 Gb at 30x of BASELINE.json configs[3] with `-m 101 -NB` (the workload
-north_star's target is quoted on: ">= 50 Mbases/s ... on a 3 Gb synthetic genome at 1 MI355X").
-With N > 1 every rank (one process per GPU) processes its own genome (different sample seed);
-the per-chromosome summaries (chr median/SD + calls) are all-gathered over RCCL once per step
--- the path's only exchange -- so scaling is weak and `value` is the whole-job bases/s.
+transform -> RSI scan -> calls -> rows in chromosome order) over ONE synthetic genome already
+resident in HBM: the 24 chromosomes totalling 3.0 Gb at 30x of BASELINE.json configs[3] with
+`-m 101 -NB` (the workload north_star's target is quoted on: ">= 50 Mbases/s ... on a 3 Gb synthetic
+genome at 1 MI355X").
 
-  python bench.py --gpus 1 --steps 3 --warmup 1
+With N > 1 (one process per GPU) the genome is SHARDED by chromosome, longest first, each to the
+least loaded rank (configs[3]: "sharded per-chrom across 8 MI355X"): the parallel form of the
+reference's loop rsi.cpp:2189-2217.  Ranks never exchange depth data; the one collective per step
+is an all_gather of the per-chromosome summary blocks (chromosome median / SD + calls, rsi_result_
+summary) over RCCL, after which rank 0 puts the rows in chromosome order as the reference's writer
+does (rsi.cpp:1594-1608).  Total work is fixed as N grows: `scaling` is "strong" and `value` is
+genome bases x steps / time.  `--shard sample` is the other reading (every rank its own genome of
+a cohort, weak scaling), reported with that label.
+
+  python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see README "Benchmark").  `roofline` is for the dominant kernel,
-timed with HIP events on the library's own stream inside the timed region; `cpu_baseline` times
-the compiled reference (oracle/_ref, kind "reference") or the CPU restatement (kind "port") on a
-bounded sample of the same workload, on one host core.
+Rank 0 prints ONE JSON line.  In it:
+  roofline      the dominant per-base kernel (cap_compact_bin): algorithmic bytes (9.1
+                B/base) over its HIP-event time inside the timed steps (on the library's own
+                streams), `isolated` = the same launches with the chip to themselves (one extra,
+                untimed pass), `whole_path` = 23.7 (m = 101) / 24.3 (m = 51) algorithmic B/base x
+                genome bases over the step time: the fraction BASELINE.md defines for the path.
+  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or the CPU restatement
+                (kind "port") on one 60 Mb chromosome of the same model, one core; `all_cores` =
+                one such process per host core at once.
+  t_device_h2d  rsi_hot_run from pinned host buffers (H2D of the inputs included) for configs[1]
+                and configs[2]; t_e2e = the command line on a 60 Mb depth text file (parse included).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,10 +45,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per base of the per-base kernels
-ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1, "fasta_classify": 1.0,
+ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "value_hist8": 9.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1, "fasta_classify": 1.0,
                        "value_hist": 4.0}
+WHOLE_PATH_BYTES_PER_BASE = {101: 23.7, 51: 24.3}   # SURVEY 8d, GC on
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
-MAX_CALLS = 256         # per-chromosome slots in the gathered result block
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py --json
 
 
@@ -59,10 +75,12 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config (1-based as in SURVEY 8d): 2, 3, 4 or 5")
+    ap.add_argument("--shard", choices=("genome", "sample"), default="genome",
+                    help="N > 1: one genome sharded by chromosome over the ranks (strong scaling, the north_star mode) or one genome per rank (weak)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink chromosome lengths (debug only; invalidates the metric)")
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single", action="store_true", help="skip the side measurement of the single-chromosome configs")
+    ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
     ap.add_argument("--workers", type=int, default=12, help="host threads / HIP streams per GPU (chromosomes in flight)")
     args = ap.parse_args()
 
@@ -70,6 +88,7 @@ def main():
     import torch
     import torch.distributed as dist
     from rsicnv_amd import api, synth
+    from rsicnv_amd import dist as rd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,47 +121,59 @@ def main():
 
     lib = api.load_library()
     pool = api.RsiPool(local_rank, args.workers)
-    # HIP events around the per-base (HBM-bound) kernels only: those are the roofline's kernels.  Event pairs around all
-    # sixty launches per chromosome cost 13 % of the step; the full per-kernel table comes from one extra, untimed pass.
-    pool.set_timing(2)
+    # HIP events around the dominant per-base kernel only inside the timed steps (event records are not free); the
+    # per-kernel tables come from extra, untimed passes.
+    pool.set_timing(3)
     flags = synth.config_flags(args.config)
     params = api.make_params(**flags)
 
-    # ---- synthetic genome, generated directly in HBM (not timed) ----
-    chroms = [0] if args.config in (2, 3) else list(range(24))
+    # ---- the genome: every chromosome's plan; this rank generates (directly in HBM, not timed) the ones it will process ----
+    chrom_ids = [0] if args.config in (2, 3) else list(range(24))
+    sharded = args.shard == "genome"
     plans = []
-    for c in chroms:
+    for c in chrom_ids:
         p = synth.config_plan(args.config, chrom=c, scale=args.scale)
-        p["seed"] = p["seed"] + 1000003 * rank     # every rank = another sample of the cohort
+        if not sharded:
+            p["seed"] = p["seed"] + 1000003 * rank     # every rank = another sample of the cohort
         plans.append(p)
+    lengths = [p["n"] for p in plans]
+    parts = rd.lpt_assign(lengths, world) if sharded else [list(range(len(plans)))] * world
+    mine = parts[rank]
     t0 = time.time()
     dev = torch.device("cuda", local_rank)
-    data = []
-    for p in plans:
+    data = {}
+    for i in mine:
+        p = plans[i]
         d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device=dev)
         d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device=dev)
         synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
-        data.append((d_rd, d_fa, p["n"]))
+        data[i] = (d_rd, d_fa, p["n"])
     torch.cuda.synchronize()
-    total_bases = sum(n for _, _, n in data)
+    my_bases = sum(data[i][2] for i in mine)
+    genome_bases = sum(lengths)
     if rank == 0:
-        log(f"[bench] generated {len(data)} chromosomes, {total_bases/1e9:.3f} Gb per rank in {time.time()-t0:.1f} s")
+        log(f"[bench] rank 0: {len(mine)} of {len(plans)} chromosomes, {my_bases/1e9:.3f} of {genome_bases/1e9:.3f} Gb, generated in {time.time()-t0:.1f} s")
 
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    gather_in = torch.zeros(len(data), 4 + 4 * MAX_CALLS, dtype=torch.float64, device=coll_dev)
-    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
-
-    chrom_args = [(d_rd.data_ptr(), d_fa.data_ptr(), n) for d_rd, d_fa, n in data]
+    nslots = max(len(p) for p in parts)
+    names = [f"chr{c + 1}" for c in chrom_ids]
+    chrom_args = [(data[i][0].data_ptr(), data[i][1].data_ptr(), data[i][2]) for i in mine]
 
     def step(timed=False):
-        results = pool.run(params, chrom_args, collect_times=timed)
-        host_block = np.zeros((len(data), 4 + 4 * MAX_CALLS), dtype=np.float64)
-        for ci, res in enumerate(results):   # per chromosome: median, SD, number of calls, calls (start, end, type, qscore)
-            res.summary_into(host_block[ci], MAX_CALLS)
-        if world > 1:   # the one exchange of the path: per-chromosome summaries to every rank
-            gather_in.copy_(torch.from_numpy(host_block))
-            dist.all_gather(gather_out, gather_in)
-        return int(host_block[:, 2].sum())
+        """One genome: this rank's chromosomes through the pool, the gather, rank 0's rows in chromosome order."""
+        results = pool.run(params, chrom_args, collect_times=timed) if chrom_args else []
+        block = rd.pack_results(mine, results, nslots)
+        if world > 1:   # the one exchange of the path
+            blocks = rd.gather_blocks(block, world, coll_dev)
+        else:
+            blocks = [block]
+        if rank != 0:
+            return 0
+        merged = rd.unpack_blocks(blocks)
+        if sharded and len(merged) != len(plans):
+            raise RuntimeError(f"gather returned {len(merged)} of {len(plans)} chromosomes")
+        rows = rd.format_rows(lib, merged, names) if sharded or world == 1 else []
+        return len(rows) if rows else sum(m["ncalls"] for m in merged.values())
 
     def fence():
         if world > 1:
@@ -163,6 +194,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    total_bases = genome_bases if sharded else world * genome_bases
+    ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (HIP events on the library's streams, timed region) ----
     per_kernel = pool.kernel_table()      # name -> (sum ms, launches, sum of chromosome lengths)
@@ -179,14 +212,18 @@ def main():
         dom = max(streaming, key=lambda k: per_kernel[k][0])
         ms, cnt, bases, byts, achieved = kernel_roofline(per_kernel, dom)
         tpb = pmc_traffic_per_base(dom)
+        whole_bpb = WHOLE_PATH_BYTES_PER_BASE.get(flags["m"], 23.7)
+        whole = whole_bpb * total_bases / world / (ms_per_step * 1e-3) / 1e9   # per GPU
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": None if tpb is None else round(tpb * bases / cnt),
                     "avg_launch_ms": round(ms / cnt, 4), "launches": int(cnt),
                     "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[dom],
                     "algorithmic_bytes_per_launch": round(byts / cnt),
-                    "measured": "in situ: the timed steps, with the bin-level kernels of up to "
-                                f"{args.workers - 1} other chromosomes and a second per-base phase sharing the GPU"}
+                    "measured": "in situ: the timed steps, with the kernels of up to "
+                                f"{args.workers - 1} other chromosomes sharing the GPU",
+                    "whole_path": {"algorithmic_bytes_per_base": whole_bpb, "achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
+                                   "note": "SURVEY 8d's whole-path algorithmic bytes x the bases one GPU processed per step / step time"}}
         # The same kernel with the per-base phases run alone on the chip (rsi_pool_set_schedule isolate=1):
         # one extra, untimed genome pass; `value` above does not include it.
         pool.set_schedule(isolate=True)
@@ -202,7 +239,6 @@ def main():
             roofline["isolated"] = {"achieved": round(iach, 1), "frac": round(iach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ims / icnt, 4),
                                     "launches": int(icnt), "note": "same launches with the chip to themselves (untimed extra pass)"}
         pool.times = timed_tables[0]
-    kernel_ms = {k: round(v[0] / args.steps, 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
     # every launch of one more untimed pass (normal schedule), for the per-kernel picture of the whole path
     timed_table = pool.times
     pool.reset_times()
@@ -211,36 +247,13 @@ def main():
     step(timed=True)
     fence()
     kernel_ms_all = {k: round(v[0], 3) for k, v in sorted(pool.kernel_table().items(), key=lambda kv: -kv[1][0])}
-    pool.set_timing(2)
+    pool.set_timing(3)
     pool.times = timed_table
     phase_ms = pool.phase_table()
 
-    # ---- the single-chromosome configurations (configs[1], configs[2]) on the same pool: latency of ONE chromosome, i.e.
-    # no other chromosome to overlap with; reported next to `value`, never part of it ----
-    single = None
+    side = None
     if rank == 0 and world == 1 and args.config == 4 and args.scale == 1.0 and not args.no_single:
-        single = {}
-        pool.set_timing(0)
-        for cfg, label in ((2, "configs[1]: one 60 Mb chromosome, 30x Poisson"), (3, "configs[2]: one 250 Mb chromosome, 30x gamma-Poisson + GC")):
-            sp = synth.config_plan(cfg)
-            s_fa = torch.empty(sp["n"] + 64, dtype=torch.uint8, device=dev)
-            s_rd = torch.empty(sp["n"] + 16, dtype=torch.int32, device=dev)
-            synth.generate_device(lib, sp, s_fa.data_ptr(), s_rd.data_ptr())
-            torch.cuda.synchronize()
-            sparams = api.make_params(**synth.config_flags(cfg))
-            one = [(s_rd.data_ptr(), s_fa.data_ptr(), sp["n"])]
-            for _ in range(2):
-                pool.run(sparams, one)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                r1 = pool.run(sparams, one)
-            torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t1) / reps
-            single[label] = {"ms": round(dt1 * 1e3, 3), "bases_per_s": round(sp["n"] / dt1, 1), "calls": len(r1[0].calls("calls"))}
-            del s_fa, s_rd
-        pool.set_timing(2)
+        side = side_measurements(lib, pool, dev, args)
 
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
     cpu = None
@@ -248,24 +261,104 @@ def main():
         cpu = cpu_baseline(lib, args, flags)
 
     if rank == 0:
-        value = world * total_bases * args.steps / elapsed
+        value = total_bases * args.steps / elapsed
+        if sharded:
+            par = (f"{world} rank(s), one genome sharded by chromosome (longest first to the least loaded rank): rank 0 runs "
+                   f"{len(mine)} of {len(plans)} chromosomes, {args.workers} in flight per GPU; one all_gather of per-chromosome "
+                   "summary blocks per step, rank 0 orders the rows")
+        else:
+            par = f"{world} rank(s), one genome per GPU (another sample each), {args.workers} chromosomes in flight per GPU, all_gather of summaries"
         out = {
             "metric": "bases/sec through RSI pipeline (bin+GC+NB+segment)", "value": round(value, 1), "unit": "bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload_name(args), "chromosomes": len(data), "bases_per_gpu": total_bases,
-                       "flags": flag_string(flags), "calls_per_genome": ncalls,
-                       "parallelism": f"{world} rank(s), one genome per GPU, {args.workers} chromosomes in flight per GPU, "
-                                      "all_gather of per-chromosome summaries"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms,
-            "kernel_ms_all_launches_extra_pass": kernel_ms_all, "single_chromosome_configs": single,
+            "config": {"workload": workload_name(args), "chromosomes": len(plans), "genome_bases": genome_bases,
+                       "bases_on_rank0": my_bases, "flags": flag_string(flags), "calls_per_genome": ncalls, "shard": args.shard,
+                       "parallelism": par},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernel_ms_all_launches_extra_pass": kernel_ms_all,
             "worker_phase_ms_per_step": {k: round(v / args.steps, 2) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
         }
+        if side:
+            out.update(side)
         print(json.dumps(out), flush=True)
     pool.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def side_measurements(lib, pool, dev, args):
+    """Next to `value`, never part of it: the single-chromosome configurations on resident inputs (latency of ONE chromosome,
+    nothing to overlap with), the same from pinned host buffers (t_device_h2d) and the command line on a depth
+    text file (t_e2e)."""
+    import numpy as np
+    import torch
+    from rsicnv_amd import api, synth
+    out = {"single_chromosome_configs": {}, "t_device_h2d": {}}
+    pool.set_timing(0)
+    hot = api.RsiHot(dev.index or 0)
+    host_case = None
+    for cfg, label in ((2, "configs[1]: one 60 Mb chromosome, 30x Poisson"), (3, "configs[2]: one 250 Mb chromosome, 30x gamma-Poisson + GC")):
+        sp = synth.config_plan(cfg)
+        n = sp["n"]
+        s_fa = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        s_rd = torch.empty(n + 16, dtype=torch.int32, device=dev)
+        synth.generate_device(lib, sp, s_fa.data_ptr(), s_rd.data_ptr())
+        torch.cuda.synchronize()
+        sparams = api.make_params(**synth.config_flags(cfg))
+        one = [(s_rd.data_ptr(), s_fa.data_ptr(), n)]
+        for _ in range(2):
+            pool.run(sparams, one)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            r1 = pool.run(sparams, one)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        out["single_chromosome_configs"][label] = {"ms": round(dt1 * 1e3, 3), "bases_per_s": round(n / dt1, 1), "calls": len(r1[0].calls("calls"))}
+        # the same chromosome from pinned host memory through rsi_hot_run: H2D of depth + FASTA (5 B/base) inside the time
+        h_rd = torch.empty(n, dtype=torch.int32).pin_memory()
+        h_fa = torch.empty(n, dtype=torch.uint8).pin_memory()
+        h_rd.copy_(s_rd[:n]); h_fa.copy_(s_fa[:n])
+        torch.cuda.synchronize()
+        del s_fa, s_rd
+        depth_np, fasta_np = h_rd.numpy(), h_fa.numpy()
+        hot.run(sparams, depth_np, fasta_np)
+        t2 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            r2 = hot.run(sparams, depth_np, fasta_np)
+        dt2 = (time.perf_counter() - t2) / reps
+        out["t_device_h2d"][label] = {"ms": round(dt2 * 1e3, 3), "bases_per_s": round(n / dt2, 1), "calls": len(r2.calls("calls")),
+                                      "note": "rsi_hot_run: pinned host depth + FASTA -> results on the host, one context"}
+        if cfg == 2:
+            host_case = (fasta_np.copy(), depth_np.copy())
+        del h_rd, h_fa
+    hot.close()
+    pool.set_timing(3)
+    # ---- t_e2e: the command line on the 60 Mb chromosome as files (FASTA + .fai, 700 MB of "pos depth" text) ----
+    try:
+        fasta_np, depth_np = host_case
+        exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            fa, rdf = synth.write_case_files(lib, fasta_np, depth_np, d)
+            best, calls = None, 0
+            for _ in range(2):
+                t3 = time.perf_counter()
+                r = subprocess.run([exe, "rsi", "-f", fa, "-d", rdf, "-c", "chrS", "-o", os.path.join(d, "out.txt"), "-np"], capture_output=True, timeout=300)
+                dt3 = time.perf_counter() - t3
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+                best = dt3 if best is None else min(best, dt3)
+                calls = sum(1 for l in open(os.path.join(d, "out.txt")) if not l.startswith("#"))
+            out["t_e2e"] = {"s": round(best, 3), "bases_per_s": round(depth_np.size / best, 1), "calls": calls,
+                            "text_bytes": os.path.getsize(rdf),
+                            "note": "rsicnv rsi -f REF -d RDFILE -c chrS on configs[1] (process start, FASTA, depth text parse, device path, output file)"}
+    except Exception as e:   # a side measurement must not take the bench line down
+        out["t_e2e"] = {"error": str(e)[:200]}
+    return out
 
 
 def flag_string(f):
@@ -276,16 +369,46 @@ def flag_string(f):
 def workload_name(args):
     names = {2: "synthetic 60 Mb chromosome, 30x Poisson depth (configs[1])",
              3: "synthetic 250 Mb chromosome, 30x gamma-Poisson depth with GC dependence (configs[2])",
-             4: "24 synthetic chromosomes totalling 3 Gb, 30x, per GPU (configs[3] data; north_star 3 Gb genome)",
-             5: "24 synthetic chromosomes totalling 3 Gb, 60x, -m 51 -MED -cap 4, per GPU (configs[4] data)"}
+             4: "24 synthetic chromosomes totalling 3 Gb, 30x (configs[3]; north_star's 3 Gb genome)",
+             5: "24 synthetic chromosomes totalling 3 Gb, 60x, -m 51 -MED -cap 4 (configs[4])"}
     s = names[args.config]
     if args.scale != 1.0:
         s += f" [scaled x{args.scale}: NOT the metric's configuration]"
     return s
 
 
+def host_cpu_share():
+    """CPUs this process may really use: the cgroup quota when there is one (a GPU box gives a 1-GPU job 16 of its 256
+    CPUs), else the affinity mask; at most 32 (the all-cores sample stays bounded)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+_CPU_CHILD = r"""
+import sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+d = np.load(sys.argv[2])
+p = oracle.make_params(**eval(sys.argv[3]))
+t0 = time.perf_counter()
+if oracle.ref_available():
+    nc, _ = oracle.Ref().run_timed(p, d["depth"], d["fasta"])
+else:
+    nc = oracle.Oracle().run(p, d["depth"], d["fasta"], snapshots=False)
+print(time.perf_counter() - t0, nc)
+"""
+
+
 def cpu_baseline(lib, args, flags):
-    """Reference (or the oracle port) on one chromosome of the same model, compute-only, one core."""
+    """Reference (or the oracle port) on one chromosome of the same model, compute-only, one core; then the same chromosome
+    in one process per host core at once (the reference has no threads: processes are how it uses a machine)."""
+    import numpy as np
     import oracle
     from rsicnv_amd import synth
     n = int(args.cpu_sample_mb * 1e6 * min(args.scale, 1.0)) if args.scale < 1 else int(args.cpu_sample_mb * 1e6)
@@ -301,17 +424,36 @@ def cpu_baseline(lib, args, flags):
         kind = "reference"
     else:
         if not os.path.exists(oracle.ORACLE_SO):
-            import subprocess
             subprocess.run(["make", "-f", "oracle/Makefile", "oracle/librsi_oracle.so"], cwd=ROOT, check=True)
         O = oracle.Oracle()
         nc = O.run(p, depth, fasta, snapshots=False)
         stages = list(O.f64("stage_s"))
         kind = "port"
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 1), "unit": "bases/s", "cores": 1, "kind": kind,
-            "sample": f"one {n/1e6:.0f} Mb chromosome of the same depth model and flags, compute-only "
-                      f"(arrays in memory -> calls), {dt:.1f} s, {nc} calls",
-            "stage_s": [round(s, 3) for s in stages]}
+    out = {"value": round(n / dt, 1), "unit": "bases/s", "cores": 1, "kind": kind,
+           "sample": f"one {n/1e6:.0f} Mb chromosome of the same depth model and flags, compute-only "
+                     f"(arrays in memory -> calls), {dt:.1f} s, {nc} calls",
+           "stage_s": [round(s, 3) for s in stages]}
+    # ---- all host cores: one process per core, each the same chromosome (bounded: one chromosome per core) ----
+    try:
+        cores = host_cpu_share()
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            path = os.path.join(d, "case.npz")
+            np.savez(path, depth=depth, fasta=fasta)
+            t1 = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, path, repr(flags)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                     for _ in range(cores)]
+            outs = [pr.communicate(timeout=600) for pr in procs]
+            wall = time.perf_counter() - t1
+            if any(pr.returncode != 0 for pr in procs):
+                raise RuntimeError(outs[0][1].decode()[-200:])
+            each = [float(o[0].split()[0]) for o in outs]
+        out["all_cores"] = {"value": round(cores * n / wall, 1), "unit": "bases/s", "cores": cores, "kind": kind,
+                            "sample": f"{cores} processes at once, one {n/1e6:.0f} Mb chromosome each: {wall:.1f} s wall "
+                                      f"(compute {min(each):.1f}-{max(each):.1f} s per process, process start and input load included in the wall time)"}
+    except Exception as e:
+        out["all_cores"] = {"error": str(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":

@@ -139,11 +139,20 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
  * defaults (-1) there. */
 int rsi_result_annotate_bam(rsi_result* r, const char* bam_path, const char* chrom);
 int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0);
-/* Fixed-size summary of one chromosome for the gather across ranks (the collection of per-chromosome results that
- * replaces the reference's sequential output loop, rsi.cpp:1594-1608): out[0..3] = chromosome median, SD, number of final
- * calls, number of calls stored; then (start, end, type, qscore) per stored call, at most max_calls of them.
- * Returns the number of doubles written (4 + 4 * stored). */
-int rsi_result_summary(const rsi_result* r, double* out, int max_calls);
+/* Fixed-layout summary of a chromosome's result for the one exchange of a multi-GPU run (the gather of per-chromosome
+ * results that replaces the reference's sequential output loop, rsi.cpp:1594-1608):
+ *   out[0..7]  = chromosome id (the caller's), chromosome median, SD, number of final calls, number stored here, 0, 0, 0
+ *   then RSI_SUMMARY_CALL doubles per stored call: start, end, type, qscore, cnvmed, cnviqr, refmed, refiqr,
+ * at most max_calls of them (stored < number of calls means the block was too small: callers treat that as an error).
+ * Returns the number of doubles written.  rsi_summary_format_row: the output row of stored call i of such a block. */
+#define RSI_SUMMARY_HEAD 8
+#define RSI_SUMMARY_CALL 8
+int rsi_result_summary(const rsi_result* r, int chrom_id, double* out, int max_calls);
+int rsi_summary_format_row(const double* block, int i, const char* chrom, char* buf, int cap);
+/* The per-L lines rsistatus writes to the log (rsi.cpp:1221-1224 "DEL-", 1251-1254 "DUP+": L, bins marked so far, bins,
+ * portion) for the four sweeps of the chromosome's (last) scan, first pass first: line i (0-based) into buf; returns i + 1,
+ * or 0 when there is no such line. */
+int rsi_result_log_line(const rsi_result* r, int i, char* buf, int cap);
 /* Reference sequences of the BAM header: names as one '\n'-separated string into names[names_cap], lengths into
  * lengths[max_refs]; returns their number (also when the buffers are too small or NULL), < 0 on error. */
 int rsi_bam_references(const char* bam_path, char* names, int names_cap, int64_t* lengths, int max_refs);

@@ -45,6 +45,11 @@ int rsi_synth_generate_host(const rsi_synth_spec* spec, uint8_t* fasta, int32_t*
  * (NULL = default stream).  Synchronises the stream before returning. */
 int rsi_synth_generate_device(const rsi_synth_spec* spec, void* d_fasta, void* d_depth, void* stream);
 
+/* Files for the command-line runs of tests and bench.py: depth as "pos<TAB>depth" lines (1-based positions, one
+ * comment line first), the chromosome as a FASTA file of 60-base lines with its .fai index next to it.  0 or < 0. */
+int rsi_synth_write_depth_text(const char* path, const int32_t* depth, int64_t n);
+int rsi_synth_write_fasta(const char* path, const char* chrom, const uint8_t* fasta, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,10 +25,10 @@ STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3:
 
 # every symbol include/rsi_hot.h and include/rsi_synth.h declare
 EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
-           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
+           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
-           "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_synth_generate_host", "rsi_synth_generate_device"]
+           "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_result_log_line", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
 
 
 class RsiParams(C.Structure):
@@ -56,6 +56,7 @@ class RsiChromStats(C.Structure):
 
 
 RSI_MAX_TIMED = 64
+SUMMARY_HEAD, SUMMARY_CALL = 8, 8   # rsi_hot.h: RSI_SUMMARY_HEAD, RSI_SUMMARY_CALL
 
 
 class RsiTextStats(C.Structure):
@@ -118,8 +119,12 @@ def load_library():
     L.rsi_result_stats.argtypes = [C.c_void_p]
     L.rsi_result_stats.restype = C.POINTER(RsiChromStats)
     L.rsi_result_noncode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
-    L.rsi_result_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.rsi_result_summary.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.rsi_result_summary.restype = C.c_int
+    L.rsi_summary_format_row.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.rsi_summary_format_row.restype = C.c_int
+    L.rsi_result_log_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.rsi_result_log_line.restype = C.c_int
     L.rsi_result_format_row.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.rsi_result_free.argtypes = [C.c_void_p]
     for nm, ct in (("rsi_hot_fetch_i32", C.c_int32), ("rsi_hot_fetch_f32", C.c_float), ("rsi_hot_fetch_i64", C.c_int64)):
@@ -195,10 +200,20 @@ class Result:
             self._lists[which] = [{f: getattr(arr[i], f) for f in CALL_FIELDS} for i in range(k)]
         return self._lists[which]
 
-    def summary_into(self, row, max_calls):
-        """Write [median, SD, number of calls, stored, (start, end, type, qscore)...] into a float64 numpy row (rsi_result_summary)."""
-        assert row.dtype == np.float64 and row.flags["C_CONTIGUOUS"] and row.size >= 4 + 4 * max_calls
-        return self._lib.rsi_result_summary(self._h, row.ctypes.data, int(max_calls))
+    def summary_into(self, row, chrom_id, max_calls):
+        """Write the fixed-layout summary block (rsi_result_summary: [chrom id, median, SD, number of calls, stored, 0, 0, 0]
+        then 8 doubles per stored call) into a float64 numpy row; returns the number of doubles written."""
+        assert row.dtype == np.float64 and row.flags["C_CONTIGUOUS"] and row.size >= SUMMARY_HEAD + SUMMARY_CALL * max_calls
+        return self._lib.rsi_result_summary(self._h, int(chrom_id), row.ctypes.data, int(max_calls))
+
+    def log_lines(self):
+        """The per-L "DEL-" / "DUP+" lines of the scan passes (rsi.cpp:1221-1224, 1251-1254)."""
+        out, i, buf = [], 0, C.create_string_buffer(256)
+        while True:
+            i = self._lib.rsi_result_log_line(self._h, i, buf, 256)
+            if i <= 0:
+                return out
+            out.append(buf.value.decode())
 
     @property
     def lists(self):

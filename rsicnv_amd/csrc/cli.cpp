@@ -16,6 +16,10 @@
 #include <sstream>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <algorithm>
 
 #include "../../include/rsi_hot.h"
 
@@ -25,6 +29,8 @@ struct Options {
   std::string function = "rsi", rdfile, bamfile, reffile, outfile = "rsiout.txt", chr = "1-22XY", plotfolder = "cnv_plots";
   rsi_params P;
   int minq = 0, min_baseQ = 13, device = 0;
+  int gpus = 0;      // -gpus N: chromosomes spread over N devices, several in flight per device (0: one context, one at a time)
+  int workers = 4;   // -workers W: chromosomes in flight per device with -gpus
   bool saverd = false, plot = true;
 };
 
@@ -43,6 +49,8 @@ int usage() {
             << "   -o   STR  output file, default=rsiout.txt \n"
             << "   -np       do not plot CNV\n"
             << "   -gpu INT  HIP device to run on, default=0\n"
+            << "   -gpus INT spread the chromosomes of a BAM over INT devices (longest first), several in flight per\n"
+            << "             device (-workers INT, default=4); rows are written in BAM header order all the same\n"
             << "\nNote:\n"
             << "   This build runs the read-depth hot path on an MI355X; input is a read depth file\n"
             << "   (samtools mpileup BAM | cut -f2,4) with -c RNAME, or a coordinate-sorted BAM file (all\n"
@@ -95,6 +103,8 @@ void parse(int argc, char** argv, Options& o) {
     else if (s == "-hist" || s == "-overlap" || s == "-combine" || s == "-nocode") {}
     else if (s == "-NOGC") o.P.gcadjust = 0;
     else if (s == "-gpu") { o.device = atoi(need(i).c_str()); ++i; }
+    else if (s == "-gpus") { o.gpus = atoi(need(i).c_str()); ++i; }
+    else if (s == "-workers") { o.workers = atoi(need(i).c_str()); ++i; }
     else { std::cerr << "unknown option " << s << std::endl; exit(usage()); }
   }
   if (o.rdfile.empty() && o.bamfile.empty()) { std::cerr << "need input file " << std::endl; exit(usage()); }
@@ -136,6 +146,95 @@ const char* kHeader =
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// What one iteration of the reference's chromosome loop (rsi.cpp:2189-2217) leaves behind: its log lines and its rows.
+struct ChromOutput {
+  std::string log;                 // everything the iteration prints (stderr + OUT.log), in order
+  std::vector<std::string> rows;   // output rows (cnv_format1), without the header
+  bool populated = false;          // the chromosome was processed (has reads / could be read): it counts for the header
+  bool fatal = false;              // the single-chromosome modes stop here (the reference exits)
+};
+
+// One chromosome on one context: FASTA, depth (text or BAM, on the device), the hot path, RP / Q0, the rows.
+void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, bool many, ChromOutput& co) {
+  const bool from_bam = !o.bamfile.empty();
+  std::ostringstream info;
+  info << "#processing " << chr << "\n";
+  const double t0 = now_s();
+  std::string fasta;
+  if (!read_fasta(o.reffile, chr, fasta)) { co.log = info.str(); co.fatal = !many; return; }
+  const double t1 = now_s();
+
+  rsi_result* res = nullptr;
+  rsi_text_stats ts;
+  rsi_bam_stats bs;
+  memset(&ts, 0, sizeof(ts)); memset(&bs, 0, sizeof(bs));
+  // the depth comes from a text file parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517) or from
+  // the BAM file's reads, inflated on the host and piled up on the device (load_data_from_bam, loaddata.cpp:277-333)
+  const int rc = from_bam
+      ? rsi_hot_run_bam(ctx, &o.P, o.bamfile.c_str(), chr.c_str(), o.minq, o.min_baseQ, reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &bs)
+      : rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
+  if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
+    info << rsi_hot_last_error(ctx) << "\n";
+    co.log = info.str();
+    co.fatal = !(many && from_bam && bs.on_chrom == 0);   // a reference without reads is simply not "populated" (rsi.cpp:2125)
+    return;
+  }
+  const double t2 = now_s();
+  if (from_bam && many && bs.on_chrom == 0) {   // not "populated": the reference does not process it (rsi.cpp:2125)
+    info << "no reads on " << chr << "\n";
+    co.log = info.str();
+    rsi_result_free(res);
+    return;
+  }
+  co.populated = true;
+  if (from_bam && o.saverd) {   // -s: write_rd_to_file, loaddata.cpp:340-344, 464-470
+    const std::string dump = o.outfile + "." + chr + "_rd";
+    std::vector<int32_t> rd((size_t)bs.n);
+    rsi_hot_fetch_i32(ctx, "depth_in", rd.data(), bs.n);
+    FILE* f = fopen(dump.c_str(), "w");
+    if (f) { for (int64_t i = 0; i < bs.n; ++i) fprintf(f, "%lld\t%d\n", (long long)i + 1, rd[(size_t)i]); fclose(f); }
+    info << "RD of " << chr << " is saved to " << dump << "\n";
+  }
+  const rsi_chrom_stats* S = rsi_result_stats(res);
+  info << "#Noseq regions excluded\n";
+  {
+    std::vector<int32_t> pairs((size_t)S->n_noncode * 2 + 2);
+    const int k = rsi_result_noncode(res, pairs.data(), S->n_noncode);
+    for (int i = 0; i < k; ++i) info << chr << "\t" << pairs[2 * i] << "\t" << pairs[2 * i + 1] << "\n";
+  }
+  if (o.P.gcadjust) info << "RD mean before GC adjust = " << S->gc_rdmean << "\n";
+  if (o.P.cap > 1) info << "applying cap " << o.P.cap << " times of mean " << S->cap_median << "\ncap = " << o.P.cap * S->cap_median << "\n";
+  info << "region  : " << chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
+  info << "RD median absolute deviation : " << S->nb_mad << "\n";
+  {   // the reference's per-L lines of the two rsistatus passes (rsi.cpp:1221-1224, 1251-1254): L, newly marked bins, running total
+    char line[256];
+    int n = 0;
+    while ((n = rsi_result_log_line(res, n, line, (int)sizeof(line))) > 0) info << line << "\n";
+  }
+  info << "first pass\n\tmedian of transformations : " << S->tmedian1 << "\n\tsigma : " << S->tsigma1 << "\n\tlamda : " << S->tlamda1 << "\n"
+       << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
+       << "Selected " << rsi_result_ncalls(res, 3) << " segments for testing\n"
+       << "Found " << rsi_result_ncalls(res, 1) << " CNVs before sd_filters, " << rsi_result_ncalls(res, 0) << " written\n"
+       << "timing: fasta " << (t1 - t0) << " s, ";
+  if (from_bam)
+    info << "BAM pileup " << bs.t_total_ms * 1e-3 << " s (" << bs.bytes_compressed << " bytes compressed, " << bs.records << " reads read, " << bs.used
+         << " counted, inflate " << bs.t_inflate_ms * 1e-3 << " s" << (bs.indexed ? ", index used" : ", no index: scanned from the top") << ")";
+  else
+    info << "depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
+         << (ts.fallback ? ", host parser: positions not increasing" : "") << ")";
+  info << ", whole device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
+  if (from_bam) {   // if ( fp_in ) cnv_stat(fp_in, bamidx, cnvlist), rsi.cpp:2210
+    if (rsi_result_annotate_bam(res, o.bamfile.c_str(), chr.c_str()) != RSI_OK) info << "RP / Q0 annotation failed: " << rsi_hot_last_error(nullptr) << "\n";
+  }
+  char row[1024];
+  for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
+    rsi_result_format_row(res, i, chr.c_str(), row, (int)sizeof(row));
+    co.rows.push_back(row);
+  }
+  co.log = info.str();
+  rsi_result_free(res);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -157,109 +256,105 @@ int main(int argc, char** argv) {
   // chromosomes to process: -c RNAME, or (BAM input, rsi.cpp:2114-2131) every reference of the header that is not
   // a mitochondrial / decoy name and has reads
   std::vector<std::string> todo;
+  std::vector<int64_t> todo_len;
   if (from_bam && (o.chr.empty() || o.chr == "1-22XY")) {
     std::vector<char> names(1 << 20);
-    const int nref = rsi_bam_references(o.bamfile.c_str(), names.data(), (int)names.size(), nullptr, 0);
+    std::vector<int64_t> lens(1 << 16);
+    const int nref = rsi_bam_references(o.bamfile.c_str(), names.data(), (int)names.size(), lens.data(), (int)lens.size());
     if (nref < 0) { std::cerr << rsi_hot_last_error(nullptr) << std::endl; return 0; }
     std::istringstream iss(names.data());
     std::string nm;
     std::cerr << "#Check bam header for 1-22XY \n"; log << "#Check bam header for 1-22XY \n";
+    int k = 0;
     while (std::getline(iss, nm)) {
+      const int64_t len = k < (int)lens.size() ? lens[(size_t)k] : 0;
+      ++k;
       if (nm.find("MT") != std::string::npos || nm.find(".") != std::string::npos) continue;
-      todo.push_back(nm);
+      todo.push_back(nm); todo_len.push_back(len);
     }
   } else {
-    todo.push_back(o.chr);
+    todo.push_back(o.chr); todo_len.push_back(0);
   }
+  const bool many = todo.size() > 1;
 
-  int st = 0;
-  rsi_ctx* ctx = rsi_hot_create(o.device, &st);
-  if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
+  // write_cnv_to_file, rsi.cpp:1592-1616: the first processed chromosome opens the file and writes the header, the others
+  // append.  Rows always leave in the order of `todo` (the BAM header's), whatever ran where.
   bool wrote_header = false;
-  for (const std::string& chr : todo) {
-  std::cerr << "#processing " << chr << std::endl; log << "#processing " << chr << std::endl;
+  auto emit = [&](const std::string& chr, const ChromOutput& co) {
+    std::cerr << co.log; log << co.log;
+    if (!co.populated) return;
+    std::ofstream out(o.outfile.c_str(), wrote_header ? std::ios::app : std::ios::trunc);
+    if (!wrote_header) {
+      if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << chr << std::endl;
+      if (from_bam) out << "#input " << o.bamfile << std::endl;
+      if (o.P.gcadjust) out << "#GC adjusted\n";
+      out << kHeader << std::endl;
+      wrote_header = true;
+    }
+    for (const std::string& r : co.rows) out << r << std::endl;
+    out.close();
+    std::cerr << "output written to " << o.outfile << std::endl; log << "output written to " << o.outfile << std::endl;
+  };
 
-  const double t0 = now_s();
-  std::string fasta;
-  if (!read_fasta(o.reffile, chr, fasta)) { if (todo.size() > 1) continue; rsi_hot_destroy(ctx); return 0; }
-  const double t1 = now_s();
-
-  rsi_result* res = nullptr;
-  rsi_text_stats ts;
-  rsi_bam_stats bs;
-  memset(&ts, 0, sizeof(ts)); memset(&bs, 0, sizeof(bs));
-  // the depth comes from a text file parsed on the device (load_data_from_text's loop, loaddata.cpp:496-517) or from
-  // the BAM file's reads, inflated on the host and piled up on the device (load_data_from_bam, loaddata.cpp:277-333)
-  const int rc = from_bam
-      ? rsi_hot_run_bam(ctx, &o.P, o.bamfile.c_str(), chr.c_str(), o.minq, o.min_baseQ, reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &bs)
-      : rsi_hot_run_text(ctx, &o.P, o.rdfile.c_str(), reinterpret_cast<const uint8_t*>(fasta.data()), (int64_t)fasta.size(), &res, &ts);
-  if (rc != RSI_OK) {   // the reference prints its message and exits with status 0
-    std::cerr << rsi_hot_last_error(ctx) << std::endl; log << rsi_hot_last_error(ctx) << std::endl;
-    if (todo.size() > 1 && from_bam && bs.on_chrom == 0) continue;   // a reference without reads is simply not "populated" (rsi.cpp:2125)
+  if (o.gpus <= 0 || !many) {   // the reference's own shape: one chromosome after the other on one context
+    int st = 0;
+    rsi_ctx* ctx = rsi_hot_create(o.device, &st);
+    if (!ctx) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
+    for (const std::string& chr : todo) {
+      ChromOutput co;
+      process_chromosome(ctx, o, chr, many, co);
+      emit(chr, co);
+      if (co.fatal) break;
+    }
     rsi_hot_destroy(ctx);
     return 0;
   }
-  const double t2 = now_s();
-  if (from_bam && todo.size() > 1 && bs.on_chrom == 0) {   // not "populated": the reference does not process it (rsi.cpp:2125)
-    std::cerr << "no reads on " << chr << std::endl; log << "no reads on " << chr << std::endl;
-    rsi_result_free(res);
-    continue;
-  }
-  if (from_bam && o.saverd) {   // -s: write_rd_to_file, loaddata.cpp:340-344, 464-470
-    const std::string dump = o.outfile + "." + chr + "_rd";
-    std::vector<int32_t> rd((size_t)bs.n);
-    rsi_hot_fetch_i32(ctx, "depth_in", rd.data(), bs.n);
-    FILE* f = fopen(dump.c_str(), "w");
-    if (f) { for (int64_t i = 0; i < bs.n; ++i) fprintf(f, "%lld\t%d\n", (long long)i + 1, rd[(size_t)i]); fclose(f); }
-    std::cerr << "RD of " << chr << " is saved to " << dump << std::endl; log << "RD of " << chr << " is saved to " << dump << std::endl;
-  }
-  const rsi_chrom_stats* S = rsi_result_stats(res);
-  std::ostringstream info;
-  info << "#Noseq regions excluded\n";
-  {
-    std::vector<int32_t> pairs((size_t)S->n_noncode * 2 + 2);
-    const int k = rsi_result_noncode(res, pairs.data(), S->n_noncode);
-    for (int i = 0; i < k; ++i) info << chr << "\t" << pairs[2 * i] << "\t" << pairs[2 * i + 1] << "\n";
-  }
-  if (o.P.gcadjust) info << "RD mean before GC adjust = " << S->gc_rdmean << "\n";
-  if (o.P.cap > 1) info << "applying cap " << o.P.cap << " times of mean " << S->cap_median << "\ncap = " << o.P.cap * S->cap_median << "\n";
-  info << "region  : " << chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
-  info << "RD median absolute deviation : " << S->nb_mad << "\n"
-       << "first pass\n\tmedian of transformations : " << S->tmedian1 << "\n\tsigma : " << S->tsigma1 << "\n\tlamda : " << S->tlamda1 << "\n"
-       << "second pass\n\tmedian of transformations : " << S->tmedian2 << "\n\tsigma : " << S->tsigma2 << "\n\tlamda : " << S->tlamda2 << "\n"
-       << "Selected " << rsi_result_ncalls(res, 3) << " segments for testing\n"
-       << "Found " << rsi_result_ncalls(res, 1) << " CNVs before sd_filters, " << rsi_result_ncalls(res, 0) << " written\n"
-       << "timing: fasta " << (t1 - t0) << " s, ";
-  if (from_bam)
-    info << "BAM pileup " << bs.t_total_ms * 1e-3 << " s (" << bs.bytes_compressed << " bytes compressed, " << bs.records << " reads read, " << bs.used
-         << " counted, inflate " << bs.t_inflate_ms * 1e-3 << " s" << (bs.indexed ? ", index used" : ", no index: scanned from the top") << ")";
-  else
-    info << "depth text " << ts.t_total_ms * 1e-3 << " s (" << ts.bytes << " bytes, " << ts.lines << " lines"
-         << (ts.fallback ? ", host parser: positions not increasing" : "") << ")";
-  info << ", whole device path " << (t2 - t1) << " s (" << S->t_device_ms << " ms on resident inputs)\n";
-  if (from_bam) {   // if ( fp_in ) cnv_stat(fp_in, bamidx, cnvlist), rsi.cpp:2210
-    if (rsi_result_annotate_bam(res, o.bamfile.c_str(), chr.c_str()) != RSI_OK) info << "RP / Q0 annotation failed: " << rsi_hot_last_error(nullptr) << "\n";
-  }
-  std::cerr << info.str(); log << info.str();
 
-  // write_cnv_to_file, rsi.cpp:1592-1616: the first chromosome opens the file and writes the header, the others append
-  std::ofstream out(o.outfile.c_str(), wrote_header ? std::ios::app : std::ios::trunc);
-  if (!wrote_header) {
-    if (!o.rdfile.empty()) out << "#input " << o.rdfile << " " << chr << std::endl;
-    if (from_bam) out << "#input " << o.bamfile << std::endl;
-    if (o.P.gcadjust) out << "#GC adjusted\n";
-    out << kHeader << std::endl;
-    wrote_header = true;
+  // ---- -gpus N: the iterations of the loop are independent.  Chromosomes go to devices longest first
+  // (each to the least loaded one), every device gets a pool whose workers take that device's chromosomes longest first;
+  // nothing is exchanged between devices but the finished rows, which the main thread writes in header order. ----
+  const int ndev = std::max(1, o.gpus), nwork = std::max(1, std::min(o.workers, 32));
+  std::vector<rsi_pool*> pools;
+  for (int d = 0; d < ndev; ++d) {
+    int st = 0;
+    rsi_pool* pl = rsi_pool_create(o.device + d, nwork, &st);
+    if (!pl) {
+      if (d == 0) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
+      std::cerr << "rsicnv: device " << o.device + d << " not available, using " << d << " device(s)" << std::endl;
+      break;
+    }
+    pools.push_back(pl);
   }
-  char row[1024];
-  for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
-    rsi_result_format_row(res, i, chr.c_str(), row, (int)sizeof(row));
-    out << row << std::endl;
+  std::vector<std::vector<int>> per_dev(pools.size());
+  {
+    std::vector<int> order(todo.size());
+    for (size_t i = 0; i < todo.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return todo_len[(size_t)a] > todo_len[(size_t)b]; });
+    std::vector<int64_t> load(pools.size(), 0);
+    for (int i : order) {
+      size_t best = 0;
+      for (size_t d = 1; d < pools.size(); ++d) if (load[d] < load[best]) best = d;
+      per_dev[best].push_back(i);
+      load[best] += todo_len[(size_t)i];
+    }
   }
-  out.close();
-  std::cerr << "output written to " << o.outfile << std::endl; log << "output written to " << o.outfile << std::endl;
-  rsi_result_free(res);
-  }   // chromosomes
-  rsi_hot_destroy(ctx);
+  std::vector<ChromOutput> outs(todo.size());
+  std::vector<std::thread> threads;
+  std::vector<std::atomic<int>> next(pools.size());
+  for (auto& a : next) a = 0;
+  for (size_t d = 0; d < pools.size(); ++d)
+    for (int w = 0; w < nwork; ++w)
+      threads.emplace_back([&, d, w]() {
+        rsi_ctx* ctx = rsi_pool_worker(pools[d], w);
+        for (;;) {
+          const int k = next[d].fetch_add(1);
+          if (k >= (int)per_dev[d].size()) break;
+          const int i = per_dev[d][(size_t)k];
+          process_chromosome(ctx, o, todo[(size_t)i], true, outs[(size_t)i]);
+        }
+      });
+  for (auto& t : threads) t.join();
+  for (size_t i = 0; i < todo.size(); ++i) emit(todo[i], outs[i]);
+  for (rsi_pool* pl : pools) rsi_pool_destroy(pl);
   return 0;
 }

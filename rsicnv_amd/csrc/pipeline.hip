@@ -1057,6 +1057,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       S.tmedian1 = so.tmedian1; S.tsigma1 = so.tsigma1; S.tlamda1 = so.tlamda1;
       S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;
       S.Lmax = so.Lmax; S.trim_escapes += (int)so.escapes; S.inexact_sums = (int)so.inexact;
+      for (int w = 0; w < 4; ++w) { res->level_log[w] = so.level_log[w]; res->stop_levels[w] = so.stop_levels[w]; }
       for (const Candidate& c : so.segs) segs_all.push_back(c);
       segs = so.segs;
       { Phase ph(ctx, "a15.blocks"); rsih::test_block_segments(in, so.status2, segs); }   // areblockscnv, rsi.cpp:1847
@@ -1196,7 +1197,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
 
 const char* rsi_hot_last_error(const rsi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on < 0 ? 0 : on > 2 ? 1 : on; }
+void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on < 0 ? 0 : on > 3 ? 1 : on; }
 
 int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n, rsi_result** out) {
   if (!ctx || !p || !d_depth || !d_fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");
@@ -1315,15 +1316,50 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
   return k;
 }
 
-int rsi_result_summary(const rsi_result* r, double* out, int max_calls) {
+// The reference's per-L lines of rsistatus (rsi.cpp:1221-1224, 1251-1254), "DEL-\tL\tmarked so far\tbins\tportion", for the
+// four sweeps in the order the reference runs them; line i into buf, returns i + 1, or 0 when there is no line i.
+int rsi_result_log_line(const rsi_result* r, int i, char* buf, int cap) {
+  if (!r || i < 0 || !buf || cap <= 0) return 0;
+  int left = i;
+  for (int w = 0; w < 4; ++w) {
+    const int stop = (int)r->stop_levels[w];
+    const std::vector<uint32_t>& h = r->level_log[w];
+    if (stop <= 0 || h.empty()) continue;
+    if (left >= stop) { left -= stop; continue; }
+    const int L = left + 1;
+    unsigned long long cum = 0;
+    for (int l = 1; l <= L && l < (int)h.size(); ++l) cum += h[(size_t)l];
+    const double portion = (double)(int)cum / (double)(int)r->stats.nbins;
+    snprintf(buf, (size_t)cap, "%s\t%d\t%d\t%d\t%g", (w & 1) ? "DUP+" : "DEL-", L, (int)cum, (int)r->stats.nbins, portion);
+    return i + 1;
+  }
+  return 0;
+}
+
+int rsi_result_summary(const rsi_result* r, int chrom_id, double* out, int max_calls) {
   if (!r || !out || max_calls < 0) return RSI_ERR_BAD_ARG;
   const std::vector<rsi_call>& L = r->lists[0];
   const int stored = (int)std::min<size_t>(L.size(), (size_t)max_calls);
-  out[0] = r->stats.RDmedian; out[1] = r->stats.RDsd; out[2] = (double)L.size(); out[3] = (double)stored;
+  out[0] = (double)chrom_id; out[1] = r->stats.RDmedian; out[2] = r->stats.RDsd; out[3] = (double)L.size(); out[4] = (double)stored;
+  out[5] = out[6] = out[7] = 0.0;
   for (int i = 0; i < stored; ++i) {
-    out[4 + 4 * i] = L[(size_t)i].start; out[5 + 4 * i] = L[(size_t)i].end; out[6 + 4 * i] = L[(size_t)i].type; out[7 + 4 * i] = L[(size_t)i].qscore;
+    const rsi_call& c = L[(size_t)i];
+    double* o = out + RSI_SUMMARY_HEAD + RSI_SUMMARY_CALL * i;
+    o[0] = c.start; o[1] = c.end; o[2] = c.type; o[3] = c.qscore; o[4] = c.cnvmed; o[5] = c.cnviqr; o[6] = c.refmed; o[7] = c.refiqr;
   }
-  return 4 + 4 * stored;
+  return RSI_SUMMARY_HEAD + RSI_SUMMARY_CALL * stored;
+}
+
+// One output row from a gathered summary block (what rank 0 of a multi-process run writes): same text as
+// rsi_result_format_row on the rank that produced the block, RP / Q0 as on the depth-file path (-1).
+int rsi_summary_format_row(const double* block, int i, const char* chrom, char* buf, int cap) {
+  if (!block || !chrom || !buf || i < 0 || i >= (int)block[4]) return RSI_ERR_BAD_ARG;
+  const double* o = block + RSI_SUMMARY_HEAD + RSI_SUMMARY_CALL * i;
+  static const char* kType[3] = {"DEL", "DUP", "UNKNOWN"};
+  const int type = (int)o[2];
+  return snprintf(buf, (size_t)cap, "%s\t%d\t%d\t%s\t%d\t%d\t%g(%g);%g(%g);%g(%g)\tRP=%d;Q0=%g\trsi", chrom, (int)o[0], (int)o[1],
+                  kType[type < 0 || type > 2 ? 2 : type], (int)o[3], (int)o[1] - (int)o[0] + 1, o[4], o[5] / 1.349, o[6], o[7] / 1.349,
+                  block[1], block[2], -1, -1.0);
 }
 
 int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0) {

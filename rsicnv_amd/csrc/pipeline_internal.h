@@ -127,6 +127,10 @@ struct rsi_result {
   std::vector<int32_t> noncode;   // pairs
   std::vector<int32_t> rp;        // per final call, after rsi_result_annotate_bam
   std::vector<double> q0;
+  // per-L counts of newly marked bins of the four sweeps of the (last) scan -- pass 1 DEL, DUP, pass 2 DEL, DUP -- and the L
+  // each sweep stopped at: the reference's "DEL-" / "DUP+" log lines (rsi.cpp:1221-1224, 1251-1254)
+  std::vector<uint32_t> level_log[4];
+  uint32_t stop_levels[4] = {0, 0, 0, 0};
   rsi_chrom_stats stats;
   rsi_params params;
 };
@@ -136,7 +140,7 @@ struct rsi_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
   std::string err;
-  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base (HBM-bound) kernels only
+  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around cap_compact_bin only
   std::vector<KernelTime> ktimes;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
@@ -290,7 +294,7 @@ constexpr int kMaxL = 2048;
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
   Timer(rsi_ctx* c, const char* nm, bool per_base = false) : ctx(c), name(nm) {
-    if (!ctx->timing || (ctx->timing == 2 && !per_base)) return;
+    if (!ctx->timing || (ctx->timing == 2 && !per_base) || (ctx->timing == 3 && strcmp(nm, "cap_compact_bin") != 0)) return;
     auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
     a = get(); b = get();
     (void)hipEventRecord(a, ctx->stream);

@@ -3,6 +3,9 @@
 // whatever CPU runs this.
 #include <string.h>
 #include <thread>
+#include <string>
+#include <stdio.h>
+#include <string.h>
 #include <vector>
 #include "synth_tables.h"
 
@@ -120,4 +123,55 @@ extern "C" int rsi_synth_generate_host(const rsi_synth_spec* spec, uint8_t* fast
     }
   });
   return 0;
+}
+
+// Test / bench plumbing: the "pos<TAB>depth" text of samtools mpileup | cut -f2,4 for depth[n], and the FASTA file (60
+// bases per line) with its .fai index for one chromosome -- written fast enough (hand-rolled digits, big buffers) that a
+// 60 Mb chromosome's 700 MB of text take a second or two instead of a minute of Python formatting.
+extern "C" int rsi_synth_write_depth_text(const char* path, const int32_t* depth, int64_t n) {
+  if (!path || !depth || n <= 0) return -1;
+  FILE* f = fopen(path, "wb");
+  if (!f) return -2;
+  const size_t kBuf = size_t(16) << 20;
+  std::vector<char> buf(kBuf + 64);
+  size_t used = 0;
+  auto put_int = [&](long long v) {
+    char tmp[24];
+    int k = 0;
+    unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) buf[used++] = '-';
+    while (k) buf[used++] = tmp[--k];
+  };
+  const char head[] = "#pos depth\n";
+  memcpy(buf.data(), head, sizeof(head) - 1); used = sizeof(head) - 1;
+  for (int64_t i = 0; i < n; ++i) {
+    put_int(i + 1); buf[used++] = '\t'; put_int(depth[i]); buf[used++] = '\n';
+    if (used >= kBuf) { if (fwrite(buf.data(), 1, used, f) != used) { fclose(f); return -3; } used = 0; }
+  }
+  if (used && fwrite(buf.data(), 1, used, f) != used) { fclose(f); return -3; }
+  return fclose(f) == 0 ? 0 : -3;
+}
+
+extern "C" int rsi_synth_write_fasta(const char* path, const char* chrom, const uint8_t* fasta, int64_t n) {
+  if (!path || !chrom || !fasta || n <= 0) return -1;
+  FILE* f = fopen(path, "wb");
+  if (!f) return -2;
+  const std::string head = std::string(">") + chrom + "\n";
+  fwrite(head.data(), 1, head.size(), f);
+  std::vector<char> line(61 * 16384);
+  for (int64_t i = 0; i < n;) {
+    size_t used = 0;
+    for (int l = 0; l < 16384 && i < n; ++l) {
+      const int64_t k = n - i < 60 ? n - i : 60;
+      memcpy(line.data() + used, fasta + i, (size_t)k); used += (size_t)k; line[used++] = '\n';
+      i += k;
+    }
+    if (fwrite(line.data(), 1, used, f) != used) { fclose(f); return -3; }
+  }
+  if (fclose(f) != 0) return -3;
+  FILE* fai = fopen((std::string(path) + ".fai").c_str(), "w");
+  if (!fai) return -2;
+  fprintf(fai, "%s\t%lld\t%zu\t60\t61\n", chrom, (long long)n, head.size());
+  return fclose(fai) == 0 ? 0 : -3;
 }

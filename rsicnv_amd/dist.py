@@ -1,12 +1,18 @@
 """Multi-GPU plumbing of the path: chromosomes are independent iterations of
-the reference's loop (rsi.cpp:2189-2217), so ranks never exchange depth data.  The one collective
-is an all_gather of fixed-size per-chromosome result blocks (chromosome median/SD + calls), a few
-hundred KB, latency-bound, over RCCL (backend "nccl") on GPUs or gloo in the CPU tests.
+the reference's loop (rsi.cpp:2189-2217), so ranks never exchange depth data.  One genome is sharded
+by chromosome -- longest first, each to the least loaded rank -- and the one collective is an
+all_gather of fixed-size per-chromosome summary blocks (rsi_result_summary: chromosome id, median,
+SD, calls), a few hundred KB, latency-bound, over RCCL (backend "nccl") on GPUs or gloo in the CPU
+tests.  Rank 0 then writes the rows in chromosome order, as the reference's writer does
+(rsi.cpp:1594-1608).
 """
+import ctypes as C
+
 import numpy as np
 
 MAX_CALLS = 256
-BLOCK_W = 4 + 4 * MAX_CALLS   # [chrom id, RDmedian, RDsd, ncalls, (start, end, type, qscore) * MAX_CALLS]
+SUMMARY_HEAD, SUMMARY_CALL = 8, 8           # include/rsi_hot.h: RSI_SUMMARY_HEAD, RSI_SUMMARY_CALL
+BLOCK_W = SUMMARY_HEAD + SUMMARY_CALL * MAX_CALLS
 
 
 def lpt_assign(lengths, world):
@@ -23,21 +29,23 @@ def lpt_assign(lengths, world):
 
 
 def pack_results(chrom_ids, results, nslots):
-    """results: objects with .stats dict and .calls() list (rsicnv_amd.api.Result).
-    Returns a float64 [nslots, BLOCK_W] block; unused slots have chrom id -1."""
+    """results: rsicnv_amd.api.Result objects (anything with summary_into).  Returns a float64
+    [nslots, BLOCK_W] block in the layout of rsi_result_summary; unused slots have chromosome id -1.
+    A chromosome with more than MAX_CALLS calls does not fit its slot: that is an error, not a
+    silent truncation."""
     block = np.zeros((nslots, BLOCK_W), dtype=np.float64)
     block[:, 0] = -1
     for slot, (cid, res) in enumerate(zip(chrom_ids, results)):
-        calls = res.calls("calls")
-        block[slot, 0:4] = (cid, res.stats["RDmedian"], res.stats["RDsd"], len(calls))
-        for k, c in enumerate(calls[:MAX_CALLS]):
-            block[slot, 4 + 4 * k: 8 + 4 * k] = (c["start"], c["end"], c["type"], c["qscore"])
+        res.summary_into(block[slot], cid, MAX_CALLS)
+        if block[slot, 4] < block[slot, 3]:
+            raise OverflowError(f"chromosome {cid}: {int(block[slot, 3])} calls do not fit the {MAX_CALLS} slots of a summary block")
     return block
 
 
 def unpack_blocks(blocks):
     """blocks: iterable of [nslots, BLOCK_W] arrays (one per rank).  Returns {chrom id: dict} with
-    RDmedian, RDsd and the call tuples, i.e. what rank 0 needs to write the output file in order."""
+    RDmedian, RDsd, the call tuples (start, end, type, qscore) and the raw block row (for
+    format_rows), i.e. what rank 0 needs to write the output file in order."""
     out = {}
     for b in blocks:
         b = np.asarray(b)
@@ -45,10 +53,25 @@ def unpack_blocks(blocks):
             cid = int(row[0])
             if cid < 0:
                 continue
-            k = int(row[3])
-            calls = [tuple(int(x) for x in row[4 + 4 * j: 8 + 4 * j]) for j in range(min(k, MAX_CALLS))]
-            out[cid] = dict(RDmedian=float(row[1]), RDsd=float(row[2]), ncalls=k, calls=calls)
+            k, stored = int(row[3]), int(row[4])
+            if stored < k:
+                raise OverflowError(f"chromosome {cid}: summary block truncated ({stored} of {k} calls)")
+            calls = [tuple(int(x) for x in row[SUMMARY_HEAD + SUMMARY_CALL * j: SUMMARY_HEAD + SUMMARY_CALL * j + 4]) for j in range(k)]
+            out[cid] = dict(RDmedian=float(row[1]), RDsd=float(row[2]), ncalls=k, calls=calls, block=np.ascontiguousarray(row))
     return out
+
+
+def format_rows(lib, merged, names):
+    """The output rows of a gathered genome in chromosome order (names[cid] = chromosome name):
+    rsi_summary_format_row on every stored call -- the text the producing rank's rsi_result_format_row gives."""
+    rows, buf = [], C.create_string_buffer(1024)
+    for cid in sorted(merged):
+        blk = merged[cid]["block"]
+        for i in range(merged[cid]["ncalls"]):
+            if lib.rsi_summary_format_row(blk.ctypes.data, i, names[cid].encode(), buf, 1024) < 0:
+                raise RuntimeError("rsi_summary_format_row failed")
+            rows.append(buf.value.decode())
+    return rows
 
 
 def gather_blocks(block, world, device=None):
@@ -63,3 +86,14 @@ def gather_blocks(block, world, device=None):
     outs = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return [o.cpu().numpy() for o in outs]
+
+
+def run_sharded(pool, params, chrom_args, lengths, rank, world, device=None):
+    """One genome sharded over the ranks: `chrom_args[i]` = (depth ptr, fasta ptr, n) of chromosome i
+    is only needed (and only dereferenced) for the chromosomes lpt_assign gives this rank.  Returns
+    {chrom id: summary} of the WHOLE genome on every rank (the all_gather's result)."""
+    parts = lpt_assign(lengths, world)
+    mine = parts[rank]
+    results = pool.run(params, [chrom_args[i] for i in mine]) if mine else []
+    nslots = max(len(p) for p in parts)
+    return unpack_blocks(gather_blocks(pack_results(mine, results, nslots), world, device))

@@ -165,3 +165,18 @@ def generate_device(lib, plan, d_fasta_ptr, d_depth_ptr, stream=0):
     if rc != 0:
         raise RuntimeError(f"rsi_synth_generate_device failed: {rc}")
     del keep
+
+
+def write_case_files(lib, fasta, depth, workdir, chrom="chrS"):
+    """FASTA (+ .fai) and "pos depth" text of one chromosome for command-line runs; returns (fasta path, depth path)."""
+    import os
+    fa, rd = os.path.join(workdir, "ref.fa"), os.path.join(workdir, "depth.txt")
+    lib.rsi_synth_write_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.rsi_synth_write_depth_text.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+    fasta = np.ascontiguousarray(fasta, dtype=np.uint8)
+    depth = np.ascontiguousarray(depth, dtype=np.int32)
+    if lib.rsi_synth_write_fasta(fa.encode(), chrom.encode(), fasta.ctypes.data, fasta.size) != 0:
+        raise RuntimeError("rsi_synth_write_fasta failed")
+    if lib.rsi_synth_write_depth_text(rd.encode(), depth.ctypes.data, depth.size) != 0:
+        raise RuntimeError("rsi_synth_write_depth_text failed")
+    return fa, rd

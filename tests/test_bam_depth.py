@@ -126,6 +126,14 @@ def test_cli_walks_all_chromosomes_of_a_bam(hotlib, tmp_path):
         assert np.array_equal(dump[:, 1].astype(np.int32), g[f"{chrom}_q0_Q13"]), chrom
     text = open(out).read()
     assert text.count("#CHROM") == 1 and text.startswith(f"#input {bam}\n")
+    # -gpus N -workers W: the chromosomes spread over pools (here one device, three in flight), rows still in header
+    # order: the file is the same byte for byte (the parallel form of the loop rsi.cpp:2189-2217 and its writer :1594-1608)
+    out2 = str(tmp_path / "all_pool.txt")
+    r = subprocess.run([exe, "rsi", "-b", bam, "-f", fa, "-o", out2, "-np", "-gpus", "1", "-workers", "3"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert open(out2).read().replace(out2, out) == text.replace(out2, out)
+    log2 = open(out2 + ".log").read()
+    assert [l for l in log2.splitlines() if l.startswith("#processing")] == [l for l in log.splitlines() if l.startswith("#processing")]
 
 
 @pytest.mark.gpu

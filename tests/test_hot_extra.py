@@ -55,13 +55,13 @@ def test_pool_equals_single_context(hot, hotlib):
             assert ok, why
             assert a.stats["RDmedian"] == b.stats["RDmedian"] and a.stats["RDsd"] == b.stats["RDsd"]
             # the fixed-size summary row of the cross-rank gather (rsi_result_summary), here with room for two calls only
-            row = np.full(4 + 4 * 2, -7.0)
+            row = np.full(8 + 8 * 2, -7.0)
             calls = b.calls("calls")
-            assert b.summary_into(row, 2) == 4 + 4 * min(len(calls), 2)
-            assert list(row[:4]) == [b.stats["RDmedian"], b.stats["RDsd"], len(calls), min(len(calls), 2)]
+            assert b.summary_into(row, 17, 2) == 8 + 8 * min(len(calls), 2)
+            assert list(row[:5]) == [17.0, b.stats["RDmedian"], b.stats["RDsd"], len(calls), min(len(calls), 2)]
             for k, c in enumerate(calls[:2]):
-                assert list(row[4 + 4 * k: 8 + 4 * k]) == [c["start"], c["end"], c["type"], c["qscore"]]
-            assert (row[4 + 4 * min(len(calls), 2):] == -7.0).all()
+                assert list(row[8 + 8 * k: 16 + 8 * k]) == [c["start"], c["end"], c["type"], c["qscore"], c["cnvmed"], c["cnviqr"], c["refmed"], c["refiqr"]]
+            assert (row[8 + 8 * min(len(calls), 2):] == -7.0).all()
     pool.close()
 
 
@@ -97,6 +97,11 @@ def test_cli_output_file_matches_reference_binary(hotlib, tmp_path, extra):
     a, b = open(ours, "rb").read(), open(theirs, "rb").read()
     assert a == b, f"output files differ:\n{a.decode()}\n---\n{b.decode()}"
     assert a.count(b"\n") >= 4
+    # the per-L lines of the two rsistatus passes in OUT.log (rsi.cpp:1221-1224, 1251-1254): L, bins marked so far, bins, portion
+    sweep = lambda path: [l for l in open(path + ".log").read().splitlines() if l.startswith(("DEL-\t", "DUP+\t"))]
+    la, lb = sweep(ours), sweep(theirs)
+    assert la == lb and len(la) >= 4 * 20, f"{len(la)} vs {len(lb)} sweep lines; first difference: " + \
+        str(next(((x, y) for x, y in zip(la, lb) if x != y), None))
 
 
 def test_error_behaviour(hot, hotlib):
