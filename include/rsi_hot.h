@@ -128,6 +128,7 @@ typedef struct rsi_bam_stats {
   int64_t bytes_compressed, bytes_inflated, records, on_chrom, used, runs;   /* records walked, reads of `chrom`, reads that passed the filters, runs of counted bases */
   int32_t tid, indexed;              /* reference id of `chrom`; 1 if the .bai was used */
   double t_total_ms, t_inflate_ms, t_walk_ms, t_wait_ms;   /* wall time of the load; of which: inflate (threads), record walk, waiting for the device */
+  int64_t malformed;                 /* records whose name / CIGAR / sequence lengths overrun their block_size: skipped, never followed */
 } rsi_bam_stats;
 /* Depth of `chrom` into the context's device depth buffer (int32[stats->n]); rsi_hot_fetch_i32("depth_in") reads it back. */
 int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom, int minq, int min_baseq, rsi_bam_stats* stats);

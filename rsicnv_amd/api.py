@@ -67,7 +67,8 @@ class RsiTextStats(C.Structure):
 class RsiBamStats(C.Structure):
     _fields_ = [("n", C.c_int64), ("bytes_compressed", C.c_int64), ("bytes_inflated", C.c_int64), ("records", C.c_int64), ("on_chrom", C.c_int64),
                 ("used", C.c_int64), ("runs", C.c_int64), ("tid", C.c_int32), ("indexed", C.c_int32),
-                ("t_total_ms", C.c_double), ("t_inflate_ms", C.c_double), ("t_walk_ms", C.c_double), ("t_wait_ms", C.c_double)]
+                ("t_total_ms", C.c_double), ("t_inflate_ms", C.c_double), ("t_walk_ms", C.c_double), ("t_wait_ms", C.c_double),
+                ("malformed", C.c_int64)]
 
 
 class RsiBatchTimes(C.Structure):

@@ -193,6 +193,8 @@ int BamReader::next(BamRecord& r, std::string& err) {
   r.n_cigar = (int)le16(b + 12); r.flag = (int)le16(b + 14);
   r.l_seq = (int32_t)le32(b + 16);
   r.mtid = (int32_t)le32(b + 20); r.mpos = (int32_t)le32(b + 24); r.isize = (int32_t)le32(b + 28);
+  // the variable-length fields must lie inside the record (a corrupt file must not send the CIGAR walk past the buffer)
+  if (32ull + (uint64_t)l_name + 4ull * (uint64_t)r.n_cigar > (uint64_t)bs) { err = "malformed BAM record (name / CIGAR overrun the record)"; return -1; }
   int64_t end = r.pos;
   const uint8_t* cig = b + 32 + l_name;
   for (int k = 0; k < r.n_cigar; ++k) {

@@ -70,6 +70,10 @@ DepthPager::DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, std:
     : d_(d_ptr), n_(n), stream_(stream), mirror_source_(std::move(mirror)), have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 0),
       staging_(static_cast<int32_t*>(staging)), staging_elems_((int64_t)(staging_bytes / sizeof(int32_t))), sync_ev_(sync_event) {}
 
+DepthPager::DepthPager(const int32_t* host_ptr, int64_t n)
+    : d_(host_ptr), n_(n), stream_(nullptr), mirror_(const_cast<int32_t*>(host_ptr)),
+      have_((size_t)((n + (1 << kBits) - 1) >> kBits) + 1, 1) {}
+
 void DepthPager::wait() {
   if (!sync_ev_) { (void)hipStreamSynchronize(stream_); return; }
   (void)hipEventRecord(sync_ev_, stream_);

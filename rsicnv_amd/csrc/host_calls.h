@@ -35,6 +35,8 @@ class DepthPager {
   // optional pinned buffer for the DMA.
   DepthPager(const int32_t* d_ptr, int64_t n, hipStream_t stream, std::function<int32_t*()> mirror, void* staging = nullptr,
              size_t staging_bytes = 0, hipEvent_t sync_event = nullptr);
+  // The array already sits in host memory (the CPU harness of the candidate stages, tests/sanitize): no pages, no copies.
+  DepthPager(const int32_t* host_ptr, int64_t n);
   DepthPager(const DepthPager&) = delete;
   DepthPager& operator=(const DepthPager&) = delete;
   int64_t size() const { return n_; }

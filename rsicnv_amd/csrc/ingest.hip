@@ -372,7 +372,7 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
   BamDepthStats hs;
   HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
   { const double tq = now_ms(); HIPCHK(hipStreamSynchronize(ctx->stream)); st->t_wait_ms += now_ms() - tq; }
-  st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs;
+  st->used = (int64_t)hs.used; st->runs = (int64_t)hs.runs; st->malformed = (int64_t)hs.malformed;
   st->t_total_ms = now_ms() - t0;
   return RSI_OK;
 }

@@ -210,16 +210,28 @@ void launch_best_items(const void* items, const ItemsInline* inl, int nitems, co
 void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl,
                       int nruns, double delthr, double addthr, hipStream_t stream);
 
-// Dynamic LDS beyond 48 KB has to be allowed per kernel.  Done once per kernel and for all the CU has left next to the
-// kernel's static use: a per-launch setting from several host threads (a pool) would race with the other threads' launches.
+// Dynamic LDS beyond 48 KB has to be allowed per kernel and per device.  Done once per (kernel, device) and for all the CU
+// has left next to the kernel's static use: a per-launch setting from several host threads (a pool) would race with the
+// other threads' launches.  A failed attribute call is reported (stderr) -- the launch that needed it then fails and the
+// pipeline's next wait returns the launch error.
+constexpr int kMaxDevices = 16;
+void report_attribute_failure(const char* kernel, const char* what);
 #define RSI_ALLOW_FULL_LDS(kernel)                                                                                  \
   do {                                                                                                              \
-    static std::once_flag once__;                                                                                   \
-    std::call_once(once__, [] {                                                                                     \
+    static std::once_flag once__[rsik::kMaxDevices];                                                                \
+    int dev__ = 0;                                                                                                  \
+    if (hipGetDevice(&dev__) != hipSuccess || dev__ < 0 || dev__ >= rsik::kMaxDevices) dev__ = 0;                   \
+    std::call_once(once__[dev__], [dev__] {                                                                         \
       hipFuncAttributes a__;                                                                                        \
-      if (hipFuncGetAttributes(&a__, reinterpret_cast<const void*>(kernel)) != hipSuccess) return;                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024 - (int)a__.sharedSizeBytes);                                             \
+      int lds__ = 0;                                                                                                \
+      if (hipFuncGetAttributes(&a__, reinterpret_cast<const void*>(kernel)) != hipSuccess) {                        \
+        rsik::report_attribute_failure(#kernel, "hipFuncGetAttributes"); return;                                    \
+      }                                                                                                             \
+      if (hipDeviceGetAttribute(&lds__, hipDeviceAttributeMaxSharedMemoryPerBlock, dev__) != hipSuccess || lds__ <= 0) \
+        lds__ = 160 * 1024;                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              lds__ - (int)a__.sharedSizeBytes) != hipSuccess)                                      \
+        rsik::report_attribute_failure(#kernel, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");                 \
     });                                                                                                             \
   } while (0)
 
@@ -285,7 +297,7 @@ void launch_parse_depth_text(const void* text, long long nbytes, long long size,
                              long long* wg_max, TextParseStats* stats, hipStream_t stream);
 
 // ---- BAM pileup -> depth (kernels_io.hip; load_data_from_bam, loaddata.cpp:277-333 + resolve_cigar_pos, samfunctions.cpp:38-100) ----
-struct BamDepthStats { unsigned long long used, runs; };
+struct BamDepthStats { unsigned long long used, runs, malformed; };   // malformed: records whose fields overrun their block_size (skipped)
 // One thread per record: data = inflated BAM bytes, rec_off[i] = offset of record i's block_size field.  diff: int32[n + 1], zeroed
 // before the first chunk; launch_inclusive_scan_i32 over n turns it into the depth (tile_scratch: scan_tiles(n) ints).
 void launch_bam_depth(const void* data, const uint32_t* rec_off, int nrec, int tid, int minq, int min_baseq, long long n, int32_t* diff,

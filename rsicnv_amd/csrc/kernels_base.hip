@@ -5,6 +5,7 @@
 //
 // Built with -ffp-contract=off: the only floating-point here is the GC rescale, which must round
 // exactly like the reference's x86-64 SSE2 build.
+#include <stdio.h>
 #include "kernels.h"
 #include "device_util.h"
 
@@ -1291,6 +1292,9 @@ inline int grid_for(int64_t items, int per_block) {
 
 }  // namespace
 
+void report_attribute_failure(const char* kernel, const char* what) {
+  fprintf(stderr, "librsi_hot: %s failed for %s: its launches with more than 48 KB of dynamic LDS will be rejected\n", what, kernel);
+}
 void launch_fasta_classify(const uint8_t* fasta, int64_t n, uint64_t* gcbits, uint64_t* nbits, int64_t nwords,
                            const FillList& fill, hipStream_t stream) {
   hipLaunchKernelGGL(k_fasta_classify, dim3(grid_for(nwords * 4, kThreads)), dim3(kThreads), 0, stream, fasta, n, gcbits,

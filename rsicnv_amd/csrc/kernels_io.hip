@@ -134,15 +134,21 @@ __global__ __launch_bounds__(256) void k_bam_depth(const unsigned char* __restri
                                                    int nrec, int tid, int minq, int min_baseq, long long n,
                                                    int32_t* __restrict__ diff, BamDepthStats* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned used = 0, runs = 0;
+  unsigned used = 0, runs = 0, bad = 0;
   if (i < nrec) {
+    const long long bsize = (long long)ld_u32(data + rec_off[i]);   // block_size: bytes of the record behind this field
     const unsigned char* b = data + rec_off[i] + 4;       // past block_size
     const int rtid = (int)ld_u32(b), pos0 = (int)ld_u32(b + 4);
     const int l_name = b[8], mapq = b[9];
     const int n_cig = (int)ld_u16(b + 12), flag = (int)ld_u16(b + 14);
     const int l_seq = (int)ld_u32(b + 16);
+    // A record whose variable-length fields do not fit its block_size (corrupt or crafted file) is counted and skipped:
+    // nothing below may read past the record or write outside the depth array.  pos < 0 (an unplaced read that carries a
+    // reference id) is never yielded by the reference's region iterator: skipped like the other filtered reads.
+    const bool fits = l_seq >= 0 && 32ll + l_name + 4ll * n_cig + ((long long)l_seq + 1) / 2 + (long long)l_seq <= bsize;
+    if (!fits) bad = 1;
     // loaddata.cpp:315-319: pos == 0, tid < 0, mapq, secondary, duplicate (the iterator only yields this tid)
-    const bool keep = rtid == tid && pos0 != 0 && mapq >= minq && !(flag & 0x100) && !(flag & 0x400);
+    const bool keep = fits && rtid == tid && pos0 > 0 && mapq >= minq && !(flag & 0x100) && !(flag & 0x400);
     if (keep) {
       const unsigned char* cig = b + 32 + l_name;
       const unsigned char* qual = cig + 4 * n_cig + (l_seq + 1) / 2;
@@ -162,14 +168,15 @@ __global__ __launch_bounds__(256) void k_bam_depth(const unsigned char* __restri
             long long run_start = -1;
             for (int t = 0; t < len; ++t) {
               const long long p = p1 + t;
-              if (p >= n) break;
+              if (p >= n || q + t >= l_seq) break;   // the second: a CIGAR longer than the read (malformed)
               const bool ok = qual[q + t] >= min_baseq;
               if (ok && run_start < 0) run_start = p;
               if (!ok && run_start >= 0) { atomicAdd(&diff[run_start], 1); atomicAdd(&diff[p], -1); run_start = -1; ++runs; }
             }
             if (run_start >= 0) {
               long long e = p1 + len; if (e > n) e = n;
-              atomicAdd(&diff[run_start], 1); atomicAdd(&diff[e], -1); ++runs;
+              if (q + len > l_seq) { const long long eq = p1 + (l_seq - q); e = eq < e ? eq : e; }
+              if (e > run_start) { atomicAdd(&diff[run_start], 1); atomicAdd(&diff[e], -1); ++runs; }
             }
           }
           // ops before the anchor never match (they are I / S / H / N / P); their positions are not needed
@@ -179,8 +186,12 @@ __global__ __launch_bounds__(256) void k_bam_depth(const unsigned char* __restri
       }
     }
   }
-  for (int d = 32; d >= 1; d >>= 1) { used += __shfl_xor(used, d); runs += __shfl_xor(runs, d); }
-  if ((threadIdx.x & 63) == 0) { if (used) atomicAdd(&stats->used, (unsigned long long)used); if (runs) atomicAdd(&stats->runs, (unsigned long long)runs); }
+  for (int d = 32; d >= 1; d >>= 1) { used += __shfl_xor(used, d); runs += __shfl_xor(runs, d); bad += __shfl_xor(bad, d); }
+  if ((threadIdx.x & 63) == 0) {
+    if (used) atomicAdd(&stats->used, (unsigned long long)used);
+    if (runs) atomicAdd(&stats->runs, (unsigned long long)runs);
+    if (bad) atomicAdd(&stats->malformed, (unsigned long long)bad);
+  }
 }
 
 // ---- inclusive scan of int32 in place: tile sums, scan of the tile sums, tile scan + offset ----

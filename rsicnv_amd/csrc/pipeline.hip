@@ -1173,7 +1173,7 @@ rsi_ctx* rsi_hot_create(int device, int* status) {
   rsi_ctx* ctx = new rsi_ctx();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming) != hipSuccess) {
     set_global_error("hipSetDevice / hipStreamCreate failed");
     if (status) *status = RSI_ERR_HIP;
     delete ctx;
@@ -1195,7 +1195,12 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   delete ctx;
 }
 
-const char* rsi_hot_last_error(const rsi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+const char* rsi_hot_last_error(const rsi_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  static thread_local std::string copy;   // the global record changes under other threads' feet: hand out a snapshot
+  { std::lock_guard<std::mutex> lk(g_err_mu); copy = g_last_error; }
+  return copy.c_str();
+}
 
 void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on < 0 ? 0 : on > 3 ? 1 : on; }
 

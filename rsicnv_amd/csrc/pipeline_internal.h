@@ -138,7 +138,7 @@ struct rsi_result {
 struct rsi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t sync_ev = nullptr;   // blocking-sync event used by every wait on the stream
+  hipEvent_t sync_ev = nullptr;   // event every wait on the stream polls (stream_wait)
   std::string err;
   int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around cap_compact_bin only
   std::vector<KernelTime> ktimes;
@@ -197,6 +197,10 @@ namespace rsip {
 // between polls.  With one busy-spinning thread per worker a 16-CPU quota is exhausted by the waits alone and the whole
 // process gets throttled; a blocking hipEventSynchronize sleeps until the completion interrupt, and when nothing else
 // is running on the GPU (one chromosome alone in a pool) that wake-up now and then came 30 ms late on some boxes.
+// The naps need a small timer slack (10 us, not 10 + 50): lowered for the duration of the wait only -- worker 0 of a pool
+// runs on the caller's thread, whose settings are the host application's.  A queue that makes no progress for a minute is
+// reported as a failure instead of being polled for ever.
+constexpr double kStreamWaitDeadlineMs = 60000.0;
 inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
   hipError_t e = hipEventRecord(ev, stream);
   if (e != hipSuccess) return e;
@@ -204,14 +208,18 @@ inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev) {
     e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
   }
-  static thread_local bool slack_set = false;
-  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL); slack_set = true; }   // naps of 10 us, not 10 + 50
+  const int slack_before = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+  (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
+  const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     struct timespec nap = {0, 10000};   // 10 us
     nanosleep(&nap, nullptr);
     e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
+    if (e != hipErrorNotReady) break;
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > kStreamWaitDeadlineMs) { e = hipErrorLaunchTimeOut; break; }
   }
+  if (slack_before > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack_before, 0UL, 0UL, 0UL);
+  return e;
 }
 
 // Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
@@ -253,8 +261,13 @@ inline hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t by
   memcpy(slot, src, bytes);
   return hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
 }
+// Every wait also collects the launch errors of the chain in front of it: a rejected launch (too much dynamic LDS, a bad
+// grid) raises no error at the launch site -- the launch wrappers return nothing -- and the copies and event calls behind it
+// still succeed; without this check the run would return RSI_OK on stale data.
 inline hipError_t ctx_sync(rsi_ctx* ctx) {
-  const hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
+  hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
+  const hipError_t launch = hipGetLastError();   // this thread's last failed runtime call; cleared by the read
+  if (e == hipSuccess && launch != hipSuccess) e = launch;
   if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
   ctx->pending.clear();
   return e;

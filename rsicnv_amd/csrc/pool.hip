@@ -58,7 +58,12 @@ void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
   for (rsi_ctx* c : pool->workers) c->gate_shared = isolate != 0;
   if (streamers >= 1) pool->gate.max_streamers = streamers;
 }
-const char* rsi_pool_last_error(const rsi_pool* pool) { return pool ? pool->err.c_str() : g_last_error.c_str(); }
+const char* rsi_pool_last_error(const rsi_pool* pool) {
+  if (pool) return pool->err.c_str();
+  static thread_local std::string copy;   // the global record changes under other threads' feet: hand out a snapshot
+  { std::lock_guard<std::mutex> lk(g_err_mu); copy = g_last_error; }
+  return copy.c_str();
+}
 
 int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
                  const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {

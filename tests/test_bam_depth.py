@@ -223,3 +223,38 @@ def test_ingest_error_paths(hotlib, tmp_path):
     if f"{chrom}_q{q}_Q{Q}" in g:
         assert np.array_equal(h.fetch("depth_in"), g[f"{chrom}_q{q}_Q{Q}"])
     h.close()
+
+
+@pytest.mark.gpu
+def test_malformed_records_are_skipped_not_followed(hotlib, tmp_path):
+    """Records a corrupt or crafted BAM could carry: a position of -1 with the chromosome's reference id, a sequence length
+    that overruns the record, a CIGAR count that overruns it, a CIGAR longer than the read.  The first is filtered like any
+    read the reference's region iterator never yields, the next two are counted as malformed and skipped, the last is cut at
+    the read's end; none may touch memory outside the record or the depth array -- the depth equals that of the clean file
+    plus the cut read's bases."""
+    import struct
+    from rsicnv_amd import api
+    _, refs, recs = bu.build_golden_bam(str(tmp_path))
+    chrom, n = refs[0]
+    clean = [r for r in recs if struct.unpack("<i", r[4:8])[0] == 0]
+    q = bytes([30] * 50)
+    neg = bu.encode_read(0, -1, 60, 0, [("M", 50)], 50, q)
+    long_seq = bytearray(bu.encode_read(0, 1000, 60, 0, [("M", 50)], 50, q)); long_seq[20:24] = struct.pack("<i", 1 << 20)        # l_seq
+    many_cig = bytearray(bu.encode_read(0, 2000, 60, 0, [("M", 50)], 50, q)); many_cig[16:18] = struct.pack("<H", 60000)        # n_cigar_op
+    cig_long = bu.encode_read(0, 3000, 60, 0, [("M", 80)], 50, q)      # 80M on a 50-base read: counts 50 bases
+    bad = str(tmp_path / "bad.bam")
+    extra = sorted([bytes(long_seq), bytes(many_cig), cig_long], key=lambda r: struct.unpack("<i", r[8:12])[0])
+    # keep the file coordinate-sorted: the crafted records go in front of the clean reads that start later
+    merged = sorted(clean + extra, key=lambda r: struct.unpack("<i", r[8:12])[0])
+    bu.write_bam(bad, refs, [neg] + merged)
+    good = str(tmp_path / "good.bam")
+    bu.write_bam(good, refs, clean)
+    h = api.RsiHot(0)
+    h.load_depth_bam(good, chrom)
+    want = h.fetch("depth_in").copy()
+    want[3000:3050] += 1
+    st = h.load_depth_bam(bad, chrom)
+    got = h.fetch("depth_in")
+    assert st["malformed"] == 2
+    assert np.array_equal(got, want)
+    h.close()

@@ -1,0 +1,29 @@
+"""CPU: the product's host code (host_calls.cpp, bam_host.cpp, hostmath.h, the generators) and the oracle built with
+AddressSanitizer + UndefinedBehaviorSanitizer and driven by tests/sanitize/host_harness.cpp (sanitizers
+on the CPU build only, never on the GPU).  The harness also compares the candidate stages' host path and the histogram
+quantiles with the oracle, and walks truncated / bit-flipped copies of a BAM."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import bam_util as bu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_host_code_under_asan_ubsan(tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run(["g++", "-fsanitize=address,undefined", "-x", "c++", "-", "-o", str(tmp_path / "probe")], input=b"int main(){return 0;}",
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ cannot link the sanitizer runtimes here")
+    r = subprocess.run(["make", "-f", "tests/sanitize/Makefile"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    bam, _, _ = bu.build_golden_bam(str(tmp_path))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "host_harness"), bam], capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0 and "host harness ok" in r.stdout, (r.stdout[-1500:] + r.stderr[-3000:])
