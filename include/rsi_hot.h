@@ -188,6 +188,11 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
 int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t cap);
 int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t cap);
 
+/* Test hook: filterstatus' per-level sums (rsi.cpp:967-976: float accumulation in index order per status level) of HOST arrays
+ * T[nb], status[nb] (values in [-Lmax, Lmax]) through the device's exact parallel form; sums / counts: 2 Lmax + 1 entries, index
+ * = level + Lmax.  counts[Lmax] == -1: the device declined the input (the pipeline then runs the sequential loop itself). */
+int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status, int64_t nb, int Lmax, float* sums, int32_t* counts);
+
 /* Timing hooks for bench.py: per-kernel HIP-event times (ms) of the last run, by kernel name.
  * names/ms receive up to cap entries; returns the number of timed launches. */
 int rsi_hot_kernel_times(const rsi_ctx* ctx, const char** names, float* ms, int cap);

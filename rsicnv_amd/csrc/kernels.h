@@ -165,6 +165,9 @@ struct ScanParams {
   double lim_del;    // 0.75 * RDmedian
   double lim_dup;    // 1.25 * RDmedian
 };
+// Longest scan the kernel's LDS tile holds: 256 bins + a halo of Lmax/2 + 1 each side must stay below 4096 staged bins (12-bit
+// staged indices) and 160 KB; the reference's Lmax is max(20, 10000/m, cal_max) (rsi.cpp:1830-1831): 3333 at -m 3.
+constexpr int kMaxScanL = 3800;
 constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable entries (-inf / +inf) after index Lmax
 // thr_del[L], thr_dup[L] (L = 1..Lmax, index L): a window of length L is a DEL hit iff
 // sum <= thr_del[L], a DUP hit iff sum >= thr_dup[L] (host-derived, see scan_thresholds()).
@@ -180,7 +183,7 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
 // work: [16 uint32: escapes, inexact (the scan's), ldel, ldup, both-count, ...][hist_del kMaxLevels][hist_dup kMaxLevels], zero
 // before the scan; both: scratch for kBothCap (first_del, first_dup) pairs.  The last workgroup copies host_bytes of work to
 // host_copy (mapped host memory).
-constexpr int kMaxLevels = 2064;
+constexpr int kMaxLevels = 4112;   // >= kMaxScanL + 1 + kScanPad, a multiple of 4
 constexpr size_t kScanWorkBytes = 64 + 2 * (size_t)kMaxLevels * 4;
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream);
@@ -209,6 +212,16 @@ void launch_best_items(const void* items, const ItemsInline* inl, int nitems, co
 // edge trimming of filterstatus (rsi.cpp:1023-1044): one thread per run
 void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl,
                       int nruns, double delthr, double addthr, hipStream_t stream);
+
+// ---- filterstatus' per-level float sums on the device (kernels_fs.hip; rsi.cpp:967-976, App. A Q13) ----
+// out: [2 Lmax + 1] float sums then [2 Lmax + 1] int32 counts, index = level + Lmax: the sum of T over the bins of each
+// status level accumulated in FLOAT in index order, bit for bit what the sequential loop gives (an exact parallel form, see
+// the file).  A count of -1 at level 0: the device declined (negative / non-finite values, or more than clist_cap marked
+// bins) and the caller runs the loop itself.  ws: level_sums_workspace_bytes(); its first 16 bytes zero before the launch.
+// counter: one arrival counter, zero before and after.  host_copy: mapped host memory for `out` (2 (2 Lmax + 1) words).
+size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap);
+void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int32_t clist_cap, float* out,
+                       unsigned int* counter, void* host_copy, hipStream_t stream);
 
 // Dynamic LDS beyond 48 KB has to be allowed per kernel and per device.  Done once per (kernel, device) and for all the CU
 // has left next to the kernel's static use: a per-launch setting from several host threads (a pool) would race with the

@@ -1,0 +1,251 @@
+// kernels_fs.hip -- filterstatus' per-level sums on the device (rsi.cpp:948-1047, App. A Q13).
+//
+// The reference accumulates, for every status level, the transformed bin values of that level IN FLOAT, in index order:
+// s <- fl(s + x).  The result depends on the order, so it cannot be a tree reduction; it can still be parallel, because
+// within one binade of s (2^k <= s < 2^(k+1), unit u = 2^(k-23)) an addition is an INTEGER step: with s = S u and
+// x = X u + r (0 <= r < u), fl(s + x) = (S + X + c) u where c = 0 / 1 for r below / above u/2 and, on a tie, whatever
+// makes the result even.  So every element is a function S -> S + a[S & 1] with two small constants, such functions
+// compose into functions of the same form, and the composition over a chunk of bins is an ordered reduction.  The binade
+// the sum is in when it reaches a chunk is not known in advance, but it is known to within one: the float sum of at
+// most 2^22 non-negative terms stays within 15 % of their exact sum, so two candidate binades per chunk cover it.  A
+// last, sequential pass over the CHUNKS applies each chunk's function in one step when the sum stays inside the
+// candidate binade (values are >= 0: if it is inside at the end it never left), and walks the chunk's bins one by one
+// when it does not -- the ~25 binade crossings of a chromosome, and whatever precedes the first unmarked bin.
+//
+// The unmarked level (almost every bin) goes that way.  The marked levels hold few bins each: the marked bins are
+// compacted in order, and one thread per level walks the compact list.
+#include "kernels.h"
+#include "device_util.h"
+
+namespace rsik {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPerThread = 8;
+constexpr int kChunk = kThreads * kPerThread;   // bins per chunk
+
+struct StepFn { long long a0, a1; };            // S -> S + (S even ? a0 : a1)
+__device__ inline StepFn fs_compose(StepFn f, StepFn g) {   // first f, then g
+  StepFn h;
+  h.a0 = f.a0 + ((f.a0 & 1) ? g.a1 : g.a0);                 // S even: S + f.a0 has the parity of f.a0
+  h.a1 = f.a1 + (((1 + f.a1) & 1) ? g.a1 : g.a0);           // S odd
+  return h;
+}
+// the step of adding x (a non-negative finite float) while the sum is in the binade with unit 2^ue
+__device__ inline StepFn fs_step(float x, int ue) {
+  // x = m 2^e exactly (m a 24-bit integer, or 0): in units of 2^ue it is m 2^(e-ue), integer part X, remainder r
+  const uint32_t bits = __float_as_uint(x);
+  const int ex = (int)((bits >> 23) & 0xff);
+  unsigned long long m = ex ? ((bits & 0x7fffffu) | 0x800000u) : (bits & 0x7fffffu);
+  const int e = (ex ? ex : 1) - 150;                        // x = m * 2^e
+  const int sh = e - ue;
+  StepFn f;
+  if (m == 0) { f.a0 = f.a1 = 0; return f; }
+  if (sh >= 0) { const long long X = (long long)(m << (sh > 39 ? 39 : sh)); f.a0 = f.a1 = X; return f; }   // a multiple of the unit
+  const int d = -sh;                                        // X = m >> d, r = low d bits
+  if (d > 25) { f.a0 = f.a1 = 0; return f; }                // less than a quarter of the unit: rounds away (m < 2^24)
+  const long long X = (long long)(m >> d);
+  const unsigned long long r = m & ((1ull << d) - 1), half = 1ull << (d - 1);
+  if (r > half) { f.a0 = f.a1 = X + 1; }
+  else if (r < half) { f.a0 = f.a1 = X; }
+  else { f.a0 = X + (X & 1); f.a1 = X + ((X + 1) & 1); }    // tie: to even
+  return f;
+}
+
+// Pass 1: per chunk, the exact-enough double sum and the count of the unmarked bins, the count of the marked ones.
+__global__ __launch_bounds__(kThreads) void k_fs_chunk_sums(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
+                                                            double* __restrict__ csum, int32_t* __restrict__ cmark,
+                                                            int32_t* __restrict__ total /* [1]: values the integer-step form cannot take */) {
+  __shared__ double s_d[kThreads / 64];
+  __shared__ int s_m[kThreads / 64];
+  const int64_t i0 = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * kPerThread;
+  double acc = 0.0;
+  int marked = 0;
+  bool odd = false;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t i = i0 + k;
+    if (i < nb) {
+      const float x = T[i];
+      if (!(x >= 0.0f && x <= 3.0e38f)) odd = true;   // negative, NaN or infinite (marked or not: the per-level walks add them too)
+      if (status[i] == 0) acc += (double)x; else ++marked;
+    }
+  }
+  if (odd) atomicOr(reinterpret_cast<unsigned int*>(&total[1]), 1u);
+  for (int d = 32; d >= 1; d >>= 1) { acc += __shfl_xor(acc, d); marked += __shfl_xor(marked, d); }
+  if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = acc; s_m[threadIdx.x >> 6] = marked; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) { acc += s_d[w]; marked += s_m[w]; }
+    csum[blockIdx.x] = acc; cmark[blockIdx.x] = marked;
+  }
+}
+
+// Pass 2 (one workgroup): exclusive prefixes over the chunks.
+__global__ __launch_bounds__(kThreads) void k_fs_chunk_scan(double* __restrict__ csum, int32_t* __restrict__ cmark, int nchunks,
+                                                            int32_t* __restrict__ total_marked) {
+  __shared__ double s_d[kThreads];
+  __shared__ int s_m[kThreads];
+  double cd = 0.0;
+  int cm = 0;
+  for (int t0 = 0; t0 < nchunks; t0 += kThreads) {
+    const int t = t0 + (int)threadIdx.x;
+    const double v = t < nchunks ? csum[t] : 0.0;
+    const int m = t < nchunks ? cmark[t] : 0;
+    s_d[threadIdx.x] = v; s_m[threadIdx.x] = m;
+    __syncthreads();
+    double pd = 0.0; int pm = 0;
+    for (int k = 0; k < (int)threadIdx.x; ++k) { pd += s_d[k]; pm += s_m[k]; }   // 256 x 128 adds: nothing next to the passes over the bins
+    double td = 0.0; int tm = 0;
+    for (int k = 0; k < kThreads; ++k) { td += s_d[k]; tm += s_m[k]; }
+    if (t < nchunks) { csum[t] = cd + pd; cmark[t] = cm + pm; }
+    cd += td; cm += tm;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total_marked[0] = cm;
+}
+
+// Pass 3: per chunk, the step functions of its unmarked bins for the two candidate binades of the sum that reaches it, and
+// its marked bins appended, in order, to the compact list.
+struct ChunkFn { int ue0; StepFn f0, f1; };   // unit exponents ue0 and ue0 + 1
+__global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
+                                                           const double* __restrict__ cpre, const int32_t* __restrict__ mpre,
+                                                           ChunkFn* __restrict__ fns, int32_t* __restrict__ clist_s,
+                                                           float* __restrict__ clist_t, int32_t clist_cap) {
+  __shared__ StepFn s_f[2][kThreads];
+  __shared__ int s_cnt[kThreads];
+  // candidate binades: the float sum that reaches the chunk lies within 15 % of the exact prefix P (at most 2^22 terms, each
+  // addition off by at most 2^-24 of the sum); the binade of 0.85 P and the one above it cover [0.85 P, 1.15 P]
+  const double P = cpre[blockIdx.x];
+  int ue0 = -200;
+  if (P > 0.0) { int ex; (void)frexp(P * 0.85, &ex); ue0 = (ex - 1) - 23; }   // 0.85 P in [2^(ex-1), 2^ex)
+  const int64_t i0 = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * kPerThread;
+  StepFn f0 = {0, 0}, f1 = {0, 0};
+  int nm = 0;
+  int ms[kPerThread]; float mt[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t i = i0 + k;
+    ms[k] = 0; mt[k] = 0.0f;
+    if (i < nb) {
+      const int st = status[i];
+      const float x = T[i];
+      if (st == 0) { f0 = fs_compose(f0, fs_step(x, ue0)); f1 = fs_compose(f1, fs_step(x, ue0 + 1)); }
+      else { ms[nm] = st; mt[nm] = x; ++nm; }
+    }
+  }
+  s_f[0][threadIdx.x] = f0; s_f[1][threadIdx.x] = f1; s_cnt[threadIdx.x] = nm;
+  __syncthreads();
+  if (threadIdx.x < 2) {   // ordered composition over the 256 threads' functions (one lane per candidate)
+    StepFn acc = {0, 0};
+    for (int t = 0; t < kThreads; ++t) acc = fs_compose(acc, s_f[threadIdx.x][t]);
+    if (threadIdx.x == 0) { fns[blockIdx.x].ue0 = ue0; fns[blockIdx.x].f0 = acc; } else fns[blockIdx.x].f1 = acc;
+  }
+  int before = 0;
+  for (int t = 0; t < (int)threadIdx.x; ++t) before += s_cnt[t];
+  const int base = mpre[blockIdx.x] + before;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) if (k < nm && base + k < clist_cap) { clist_s[base + k] = ms[k]; clist_t[base + k] = mt[k]; }
+}
+
+// Pass 4 (two workgroups).  Workgroup 0 carries the unmarked level's float sum over the chunks: the chunk records are staged
+// in LDS a batch at a time, lane 0 applies them one after the other and stops at the first chunk it cannot take in one step;
+// the whole workgroup then stages that chunk's bins in LDS and lane 0 adds them one by one.  Workgroup 1 takes the marked
+// levels, one level per thread (round robin), over the compact list.  out: [2 Lmax + 1] float sums then [2 Lmax + 1] int
+// counts (index = level + Lmax); the workgroup that finishes last copies them to mapped host memory.  A count of -1 at the
+// unmarked level tells the host to do the sums itself (more marked bins than the compact list holds, or a negative /
+// non-finite value: the integer-step argument needs x >= 0).
+constexpr int kFnBatch = 1024;
+__global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
+                                                            int nchunks, const ChunkFn* __restrict__ fns, const int32_t* __restrict__ clist_s,
+                                                            const float* __restrict__ clist_t, const int32_t* __restrict__ total_marked,
+                                                            int32_t clist_cap, int Lmax, float* __restrict__ out,
+                                                            unsigned int* __restrict__ counter, void* host_copy) {
+  __shared__ ChunkFn s_fn[kFnBatch];
+  __shared__ float s_x[kChunk];
+  __shared__ int s_stop;
+  const int nlev = 2 * Lmax + 1;
+  unsigned int* out_bits = reinterpret_cast<unsigned int*>(out);
+  unsigned int* out_cnt = out_bits + nlev;
+  const int M = total_marked[0];
+  const bool bad = total_marked[1] != 0 || M > clist_cap;
+  if (blockIdx.x == 0) {
+    float s = 0.0f;
+    for (int b0 = 0; b0 < nchunks; b0 += kFnBatch) {
+      const int bn = nchunks - b0 < kFnBatch ? nchunks - b0 : kFnBatch;
+      __syncthreads();
+      for (int e = threadIdx.x; e < bn; e += kThreads) s_fn[e] = fns[b0 + e];
+      __syncthreads();
+      int c = 0;
+      while (c < bn) {
+        if (threadIdx.x == 0) {
+          while (c < bn) {
+            const ChunkFn F = s_fn[c];
+            const uint32_t bits = __float_as_uint(s);
+            const int ex = (int)((bits >> 23) & 0xff);
+            const int ue = ex - 150;                           // s = S 2^ue with 2^23 <= S < 2^24 (normal s)
+            if (ex == 0 || ex == 255 || (ue != F.ue0 && ue != F.ue0 + 1)) break;
+            const StepFn f = ue == F.ue0 ? F.f0 : F.f1;
+            const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+            const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
+            if (S2 >= (1ll << 24)) break;                      // the sum leaves the binade inside this chunk
+            s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S2 & 0x7fffffu));
+            ++c;
+          }
+          s_stop = c;
+        }
+        __syncthreads();
+        c = s_stop;
+        if (c >= bn) break;
+        // chunk b0 + c bin by bin: its unmarked values into LDS (marked ones as -1), lane 0 adds them in order
+        const int64_t i0 = (int64_t)(b0 + c) * kChunk;
+        for (int e = threadIdx.x; e < kChunk; e += kThreads) {
+          const int64_t i = i0 + e;
+          s_x[e] = (i < nb && status[i] == 0) ? T[i] : -1.0f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) for (int e = 0; e < kChunk; ++e) { const float x = s_x[e]; if (x >= 0.0f) s += x; }
+        ++c;
+        __syncthreads();
+      }
+    }
+    if (threadIdx.x == 0) { st_cg(&out_bits[Lmax], __float_as_uint(s)); st_cg(&out_cnt[Lmax], bad ? 0xffffffffu : (unsigned int)(nb - M)); }
+  } else if (!bad) {
+    for (int li = (int)threadIdx.x; li < nlev; li += kThreads) {
+      const int l = li - Lmax;
+      if (l == 0) continue;
+      float s = 0.0f;
+      int c = 0;
+      for (int k = 0; k < M; ++k) if (clist_s[k] == l) { s += clist_t[k]; ++c; }
+      st_cg(&out_bits[li], __float_as_uint(s)); st_cg(&out_cnt[li], (unsigned int)c);
+    }
+  }
+  if (!last_block_done(counter)) return;
+  export_words(host_copy, out, (size_t)nlev * 8);
+}
+
+}  // namespace
+
+size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap) {
+  const size_t nchunks = (size_t)((nb + kChunk - 1) / kChunk);
+  return nchunks * (8 + sizeof(ChunkFn)) + ((nchunks * 4 + 15) & ~size_t(15)) + 16 + (size_t)clist_cap * 8 + 256;
+}
+void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int32_t clist_cap, float* out,
+                       unsigned int* counter, void* host_copy, hipStream_t stream) {
+  const int nchunks = (int)((nb + kChunk - 1) / kChunk);
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  int32_t* total = reinterpret_cast<int32_t*>(p); p += 16;   // [0] marked bins, [1] flag; cleared by the caller's fill list
+  double* csum = reinterpret_cast<double*>(p); p += (size_t)nchunks * 8;
+  ChunkFn* fns = reinterpret_cast<ChunkFn*>(p); p += (size_t)nchunks * sizeof(ChunkFn);
+  int32_t* cmark = reinterpret_cast<int32_t*>(p); p += ((size_t)nchunks * 4 + 15) & ~size_t(15);
+  int32_t* clist_s = reinterpret_cast<int32_t*>(p); p += (size_t)clist_cap * 4;
+  float* clist_t = reinterpret_cast<float*>(p);
+  hipLaunchKernelGGL(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
+  hipLaunchKernelGGL(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
+  hipLaunchKernelGGL(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap);
+  hipLaunchKernelGGL(k_fs_level_sums, dim3(2), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, clist_cap, Lmax, out,
+                     counter, host_copy);
+}
+
+}  // namespace rsik

@@ -27,6 +27,33 @@ struct ScanOut {
   uint32_t stop_levels[4] = {0, 0, 0, 0};
 };
 
+// partition_stat_tp's early return (wufunctions.cpp:371-381): when the selection spans less than the grid step its "median"
+// is its MEAN, accumulated in double in index order.  Rare (a chromosome whose bins all carry the same value), so it simply
+// runs on the host over a copy of the array.
+int selection_mean(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, int use_abs, double center, double* mean,
+                   uint64_t* count) {
+  HIPCHK(ctx->h_T.ensure((size_t)nb * 4));
+  HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_x, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (d_mask) {
+    HIPCHK(ctx->h_status.ensure((size_t)nb * 4));
+    HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_mask, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(CTX_SYNC());
+  const float* x = ctx->h_T.as<float>();
+  const int* mk = d_mask ? ctx->h_status.as<int>() : nullptr;
+  double acc = 0.0;
+  uint64_t k = 0;
+  for (int64_t i = 0; i < nb; ++i) {
+    if (mk && mk[i] != 0) continue;
+    const float v = use_abs ? (float)fabs((double)x[i] - center) : x[i];   // RDtmp[i] = abs(RDtrans[i]-tmedian), rsi.cpp:1276
+    acc += v;
+    ++k;
+  }
+  *count = k;
+  *mean = k ? acc / (double)k : 0.0;
+  return RSI_OK;
+}
+
 // 0.01-grid median of the selected values of a device float array (partition_stat_tp semantics)
 int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t nb, int use_abs, double center,
                 double* med, uint64_t* count) {
@@ -40,8 +67,7 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
   if (mm.nonfinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
   auto unkey = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
   const double ymin = unkey(~mm.min_inv), ymax = unkey(mm.max_bits);
-  if ((ymax - ymin) < 0.01)
-    return fail(ctx, RSI_ERR_UNSUPPORTED, "degenerate transform: all selected bins within 0.01 (the reference returns their mean)");
+  if ((ymax - ymin) < 0.01) return selection_mean(ctx, d_x, d_mask, nb, use_abs, center, med, count);
   const size_t np = (size_t)((ymax - ymin) / 0.01 + 2);
   if (np > (64u << 20)) return fail(ctx, RSI_ERR_UNSUPPORTED, "transformed bin range too wide for the 0.01 grid");
   HIPCHK(ctx->hist_f.ensure(np * 4));
@@ -62,6 +88,7 @@ int grid_median(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64_t n
 // in the pinned mailbox with the last launch, which also clears what the scan pass behind it accumulates into.
 // A range wider than the resident histogram falls back to grid_median().
 constexpr uint32_t kGridCap = 1u << 20;
+constexpr int32_t kFsListCap = 1 << 20;   // marked bins the level sums' compact list holds (more: the host loop)
 struct ChainOut { GridMedian g[2]; uint32_t rawmin_inv; uint32_t pad[15]; };   // what a chain leaves in the mailbox
 GridChain grid_chain(rsi_ctx* ctx) {
   uint8_t* small = ctx->small.as<uint8_t>();
@@ -76,6 +103,7 @@ void scan_fill_list(rsi_ctx* ctx, int pass, int64_t nb, FillList& fl) {
   fill_add(fl, d_first_del, (size_t)(nbpad + nb) * 4, 0xffffffffu);
   fill_add(fl, small + kOffScanPass + (size_t)pass * kScanPassBytes, kScanPassBytes, 0u);
   fill_add(fl, small + kOffCounters, 32, 0u);
+  if (pass == 0 && ctx->fs_ws.p) fill_add(fl, ctx->fs_ws.p, 16, 0u);   // filterstatus' level sums: marked count, flag
 }
 // Issues the (median, MAD) pair of the selection (mask == 0 where given).  planned: the first link's min/max + plan has been
 // done by the kernel that produced x (launch_nb_scale_minmax).  with_median = false: only the MAD around `center`
@@ -105,12 +133,13 @@ int grid_pair_issue(rsi_ctx* ctx, const float* d_x, const int32_t* d_mask, int64
   *out = slot;
   return RSI_OK;
 }
-// what grid_median() would have returned for this record (same tests, same order, same messages)
-int grid_result(rsi_ctx* ctx, const GridMedian& g, double* med, uint64_t* count) {
+// what grid_median() would have returned for this record (same tests, same order, same messages); the selection's own
+// description is needed for the degenerate case (its mean, on the host)
+struct Selection { const float* d_x; const int32_t* d_mask; int64_t nb; int use_abs; double center; };
+int grid_result(rsi_ctx* ctx, const GridMedian& g, const Selection& sel, double* med, uint64_t* count) {
   if (g.flags & kGridEmpty) { *count = 0; *med = 0; return RSI_OK; }
   if (g.flags & kGridNonFinite) return fail(ctx, RSI_ERR_UNSUPPORTED, "non-finite value in the transformed bins");
-  if (g.flags & kGridDegenerate)
-    return fail(ctx, RSI_ERR_UNSUPPORTED, "degenerate transform: all selected bins within 0.01 (the reference returns their mean)");
+  if (g.flags & kGridDegenerate) return selection_mean(ctx, sel.d_x, sel.d_mask, sel.nb, sel.use_abs, sel.center, med, count);
   *med = g.med; *count = g.count;
   return RSI_OK;
 }
@@ -464,8 +493,12 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       if ((rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt)) != RSI_OK) return rc;
     } else {
       tmedian = RDmedian;
-      if (!use_med && (rc = grid_result(ctx, g[0], &tmedian, &cnt)) != RSI_OK) return rc;
-      if ((rc = grid_result(ctx, g[1], &absmed, &cnt)) != RSI_OK) return rc;
+      if (!use_med && (rc = grid_result(ctx, g[0], Selection{d_T, nullptr, nb, 0, 0.0}, &tmedian, &cnt)) != RSI_OK) return rc;
+      // the device chained the MAD to its own median; had that one been degenerate (its record then carries no median), the
+      // deviations are taken again around the mean just computed
+      if (!use_med && (g[0].flags & kGridDegenerate)) rc = grid_median(ctx, d_T, nullptr, nb, 1, tmedian, &absmed, &cnt);
+      else rc = grid_result(ctx, g[1], Selection{d_T, nullptr, nb, 1, tmedian}, &absmed, &cnt);
+      if (rc != RSI_OK) return rc;
     }
     if (!use_med) {   // the scaled reference levels (bins 0 and 2), as k_nb_scale_mm derived them from the raw minimum
       const uint32_t key = ~first->rawmin_inv;
@@ -497,7 +530,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   int Lmax = LmaxBase;
   if (Lmax < cal_max) Lmax = cal_max;
-  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond the LDS tile limit (2048)");
+  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond the LDS tile limit (3800: bins of 3 bases and more)");
   if (Lmax > nb) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length (the reference exits in runmean)");
   out.tmedian1 = tmedian; out.tsigma1 = tsigma; out.tlamda1 = tlamda; out.Lmax = Lmax;
 
@@ -509,36 +542,50 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, d_st1f, &wslot, &rslot)) != RSI_OK) return rc; }
 
   Phase ph_filter(ctx, "scan.filterstatus");
-  // ---- filterstatus (rsi.cpp:948-1047): float per-level sums in index order are sequential by
-  // definition (App. A Q13) -> host; the edge trimming runs on the device, one thread per run ----
-  HIPCHK(ctx->h_T.ensure((size_t)nb * 4));
-  HIPCHK(ctx->h_status.ensure((size_t)nb * 4));
-  const float* hT = ctx->h_T.as<float>();
-  const int* hst = ctx->h_status.as<int>();
-  HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-  { Phase phc(ctx, "fs.copy"); HIPCHK(CTX_SYNC()); }
+  // ---- filterstatus (rsi.cpp:948-1047): the per-level sums are float accumulations in index order (App. A Q13) -- computed
+  // on the device by an exact parallel form of the sequential loop (kernels_fs.hip), so neither the transformed bins nor
+  // the status array travel to the host; the edge trimming runs on the device too, one thread per run ----
+  const int nlev = 2 * Lmax + 1;
+  uint32_t* fs_slot = static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
+  if (!fs_slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+  {
+    GateShared gs(ctx);
+    Timer t(ctx, "level_sums");
+    launch_level_sums(d_T, d_st1, nb, Lmax, ctx->fs_ws.p, kFsListCap, ctx->fs_out.as<float>(),
+                      reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4, fs_slot, ctx->stream);
+  }
+  { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
   out.escapes += wslot[0]; out.inexact = wslot[1];
   out.level_log[0].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[1].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
   out.stop_levels[0] = wslot[2]; out.stop_levels[1] = wslot[3];
   {
     Phase phs(ctx, "fs.sums");
-    // status values lie in [-Lmax, Lmax]; the unmarked level (almost every bin) is summed in a register.
-    // The level range the reference works on is [min status, max status]: taken from the counts afterwards.
-    std::vector<float> wsum((size_t)(2 * Lmax + 1), 0.0f);
-    std::vector<int> wcnt((size_t)(2 * Lmax + 1), 0);
-    {
+    // status values lie in [-Lmax, Lmax].  The level range the reference works on is [min status, max status]: taken from
+    // the counts afterwards.
+    std::vector<float> wsum((size_t)nlev, 0.0f);
+    std::vector<int> wcnt((size_t)nlev, 0);
+    memcpy(wsum.data(), fs_slot, (size_t)nlev * 4);
+    memcpy(wcnt.data(), fs_slot + nlev, (size_t)nlev * 4);
+    if (wcnt[(size_t)Lmax] < 0) {   // the device declined (negative / non-finite values, too many marked bins): the loop itself
+      Phase phc(ctx, "fs.copy");
+      HIPCHK(ctx->h_T.ensure((size_t)nb * 4));
+      HIPCHK(ctx->h_status.ensure((size_t)nb * 4));
+      HIPCHK(hipMemcpyAsync(ctx->h_T.p, d_T, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->h_status.p, d_st1, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(CTX_SYNC());
+      const int* st = ctx->h_status.as<int>();
+      const float* tv = ctx->h_T.as<float>();
+      std::fill(wsum.begin(), wsum.end(), 0.0f);
+      std::fill(wcnt.begin(), wcnt.end(), 0);
       float s0 = 0.0f;
       int n0 = 0;
-      const int* st = hst;
-      const float* tv = hT;
       for (int64_t i = 0; i < nb; ++i) {
-        const int s = st[i];
-        if (s == 0) { s0 += tv[i]; ++n0; }
-        else { wsum[s + Lmax] += tv[i]; ++wcnt[s + Lmax]; }
+        const int sv = st[i];
+        if (sv == 0) { s0 += tv[i]; ++n0; }
+        else { wsum[(size_t)(sv + Lmax)] += tv[i]; ++wcnt[(size_t)(sv + Lmax)]; }
       }
-      wsum[Lmax] = s0; wcnt[Lmax] = n0;
+      wsum[(size_t)Lmax] = s0; wcnt[(size_t)Lmax] = n0;
     }
     int lo = 0, hi = 0;
     { int a = 0, b = 2 * Lmax; while (a < b && wcnt[a] == 0) ++a; while (b > a && wcnt[b] == 0) --b; lo = a - Lmax; hi = b - Lmax; }
@@ -578,11 +625,11 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   {
     GateShared gs_q2(ctx);
     const bool wide2 = (g2[0].flags & kGridTooWide) != 0;
-    if ((rc = wide2 ? grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k) : grid_result(ctx, g2[0], &tmed2, &k)) != RSI_OK) return rc;
+    if ((rc = wide2 ? grid_median(ctx, d_T, d_st1f, nb, 0, 0.0, &tmed2, &k) : grid_result(ctx, g2[0], Selection{d_T, d_st1f, nb, 0, 0.0}, &tmed2, &k)) != RSI_OK) return rc;
     if (k > (uint64_t)(nb / 2)) {
       tmedian = tmed2;
-      if ((rc = (wide2 || (g2[1].flags & kGridTooWide)) ? grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)
-                                                        : grid_result(ctx, g2[1], &absmed, &cnt)) != RSI_OK) return rc;
+      if ((rc = (wide2 || (g2[1].flags & (kGridTooWide)) || (g2[0].flags & kGridDegenerate)) ? grid_median(ctx, d_T, d_st1f, nb, 1, tmedian, &absmed, &cnt)
+                                                        : grid_result(ctx, g2[1], Selection{d_T, d_st1f, nb, 1, tmedian}, &absmed, &cnt)) != RSI_OK) return rc;
       tsigma = absmed / 0.6745;
       tlamda = factor * tsigma;
       tlamda = std::max(tlamda, target);
@@ -1000,6 +1047,8 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
     HIPCHK(ctx->status2.ensure((size_t)nb * 4));
     HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
+    HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap)));
+    HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
 
     // ---- A10: NB transform (K5), always computed as the reference does (Q10).  The raw minimum stays on the device: the
     // scaling kernel derives the scaled levels from it and from the three raw reference levels computed here (host libm, as
@@ -1289,6 +1338,31 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
     HIPCHK(CTX_SYNC());
   }
   return ctx->nb;
+}
+
+// Test hook: filterstatus' per-level sums of host arrays through the device kernels (include/rsi_hot.h).
+int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status, int64_t nb, int Lmax, float* sums, int32_t* counts) {
+  if (!ctx || !T || !status || !sums || !counts || nb <= 0 || Lmax < 1 || Lmax > kMaxL) return fail(ctx, RSI_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  mailbox_reset(ctx);
+  HIPCHK(ctx->small.ensure(kSmallBytes));
+  HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
+  HIPCHK(ctx->status1.ensure((size_t)nb * 4));
+  HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap)));
+  HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
+  HIPCHK(hipMemcpyAsync(ctx->tnb.p, T, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->status1.p, status, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4;
+  HIPCHK(hipMemsetAsync(ctx->fs_ws.p, 0, 16, ctx->stream));
+  HIPCHK(hipMemsetAsync(counter, 0, 4, ctx->stream));
+  const int nlev = 2 * Lmax + 1;
+  uint32_t* slot = static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
+  if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+  launch_level_sums(ctx->tnb.as<float>(), ctx->status1.as<int32_t>(), nb, Lmax, ctx->fs_ws.p, kFsListCap, ctx->fs_out.as<float>(), counter, slot, ctx->stream);
+  HIPCHK(CTX_SYNC());
+  memcpy(sums, slot, (size_t)nlev * 4);
+  memcpy(counts, slot + nlev, (size_t)nlev * 4);
+  return RSI_OK;
 }
 
 int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int cap) {

@@ -157,6 +157,7 @@ struct rsi_ctx {
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64, cand_mid, cand_hist;   // candidate tests on the device (kernels_cand.hip)
   DevBuf sharpen_ws;          // workspace of k_sharpen_edges, cleared when (re)allocated
+  DevBuf fs_ws, fs_out;       // filterstatus' level sums on the device (kernels_fs.hip)
   int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
@@ -297,12 +298,12 @@ constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMax
 constexpr size_t kOffTable = kOffNtrans + (size_t)kMaxTransitions * 8;   // double[202]
 constexpr size_t kOffGrid = kOffTable + 1792;                     // GridMedian[2]: the two links of a median -> MAD chain
 constexpr size_t kOffScanPass = kOffGrid + 1024;                  // 2 x ScanPassWork (one per rsistatus pass)
-constexpr size_t kScanPassBytes = 64 + 2 * 8256;                  // ScanPassOut, level histograms of the two sweeps (Lmax <= 2048)
+constexpr size_t kScanPassBytes = kScanWorkBytes;                 // ScanPassOut, level histograms of the two sweeps (kernels.h)
 constexpr size_t kOffBreaks = kOffScanPass + 2 * kScanPassBytes + 128;   // int64 cbreak[4100], cum[4097]
 constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
 constexpr int kMaxRegions = 4096;
 constexpr uint32_t kMaxRunEntries = 1u << 20;
-constexpr int kMaxL = 2048;
+constexpr int kMaxL = kMaxScanL;
 
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;

@@ -48,12 +48,14 @@ def small_cases():
 
 def wide_scan_cases():
     """Small bins make the scan long (Lmax = 10000/m, rsi.cpp:1830): 909, 1428 and 2000 window lengths
-    per bin.  They exercise the scan kernel's big tiles, its capped mark levels and the
+    per bin, and 3333 at -m 3.  They exercise the scan kernel's big tiles, its capped mark levels and the
     chromosome-end tiles.  Kept short: the reference needs minutes for them (golden files only)."""
     return [
         ("wide_m11_nb", dict(n=80_007, seed=0x5CA1, model=0, n_events=3, gaps=1, max_len=4000, end_n=1500, gap_len=2000), dict(m=11)),
         ("wide_m7_med", dict(n=60_003, seed=0x5CA2, model=1, mean=45.0, n_events=3, gaps=0, max_len=3000, end_n=1000), dict(m=7, trans=1)),
         ("wide_m5_nb", dict(n=60_001, seed=0x5CA3, model=0, mean=40.0, n_events=3, gaps=0, max_len=2500, end_n=1000), dict(m=5)),
+        # -m 3: Lmax = 3333, beyond the 2048 the scan kernel used to stop at (one 256-bin tile + 2 x 1667 halo bins in LDS)
+        ("wide_m3_nb", dict(n=45_003, seed=0x5CA4, model=0, mean=40.0, n_events=3, gaps=0, max_len=2000, end_n=900), dict(m=3)),
     ]
 
 

@@ -1,0 +1,142 @@
+"""GPU: every BASELINE.json configuration at its STATED size (the parity matrix of test_hot_parity.py runs the same
+workloads at sizes the CPU oracle finishes in seconds).  Checks that scale: call tables against golden files made by the
+compiled reference at full size (tools/make_golden_full.py), size-independent properties of the per-base and bin arrays
+(checksum of checksums, exact bin medians, cap, moments), the 24 chromosomes in flight against one at a time."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from conftest import calls_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hot():
+    from rsicnv_amd import api
+    h = api.RsiHot(0)
+    yield h
+    h.close()
+
+
+def _device_case(lib, plan):
+    import torch
+    from rsicnv_amd import synth
+    n = plan["n"]
+    d_fa = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    d_rd = torch.empty(n + 16, dtype=torch.int32, device="cuda")
+    synth.generate_device(lib, plan, d_fa.data_ptr(), d_rd.data_ptr())
+    torch.cuda.synchronize()
+    return d_rd, d_fa
+
+
+def _golden(name):
+    path = os.path.join(gu.GOLDEN_DIR, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated (tools/make_golden_full.py needs the compiled reference)")
+    g = np.load(path, allow_pickle=False)
+    return g, json.loads(str(g["plan"])), json.loads(str(g["flags"]))
+
+
+def _plan(plan):
+    plan = dict(plan)
+    for k in ("events", "nruns", "lower"):
+        plan[k] = [tuple(e) for e in plan[k]]
+    return plan
+
+
+def _check_against_golden(res, g, what):
+    assert np.array_equal(res.noncode, g["noncode"]), what
+    assert (res.stats["RDmedian"], res.stats["RDsd"]) == tuple(g["chrom_scalars"]), what
+    assert res.stats["n_compact"] == int(g["n_compact"])
+    for which in ("calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), gu.calls_from_array(g[which]))
+        assert ok, f"{what} {which}: {why}"
+
+
+def _properties(hot, res, m, cap, plan):
+    """What must hold at any size: bins are exact order statistics / exact sums of the compacted depth, the cap holds, the
+    moments are those of the array, every implanted event (but the chromosome's last marked run, App. A Q11) is called."""
+    rdc = hot.fetch("rd_concat")
+    medint = hot.fetch("binmedint")
+    sums = hot.fetch("binsum")
+    nb = len(medint)
+    removed = int(np.sum(res.noncode[1::2] - res.noncode[0::2] + 1))
+    assert len(rdc) == plan["n"] - removed and nb == len(rdc) // m
+    bins = rdc[:nb * m].reshape(nb, m)
+    assert np.array_equal(np.median(bins, axis=1).astype(np.int32), medint)
+    assert np.array_equal(bins.sum(axis=1, dtype=np.int64), sums)
+    assert rdc.max() <= int(res.stats["cap_median"] * cap)
+    x = rdc.astype(np.float64)
+    assert res.stats["RDsd"] == pytest.approx(float(np.sqrt((x ** 2).mean() - x.mean() ** 2)), rel=1e-12)
+    calls = res.calls("calls")
+    missed = []
+    for (a, b, code) in plan["events"][:-1]:
+        typ = 0 if code in (1, 2) else 1
+        if not [c for c in calls if c["type"] == typ and abs(c["start"] - a) <= 2 * m and abs(c["end"] - b) <= 2 * m]:
+            missed.append((a, b, code))
+    return rdc, missed
+
+
+def test_config2_250mb_against_reference_golden(hot, hotlib):
+    """configs[2]: the 250 Mb gamma-Poisson chromosome with GC adjustment, -m 101 -NB."""
+    from rsicnv_amd import api
+    g, plan, flags = _golden("cfg3_250mb")
+    plan = _plan(plan)
+    d_rd, d_fa = _device_case(hotlib, plan)
+    res = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
+    _check_against_golden(res, g, "250 Mb")
+    rdc, missed = _properties(hot, res, 101, 4.0, plan)
+    assert gu.sha(rdc) == str(g["rd_concat_sha"])          # the whole capped + compacted array, bit for bit
+    assert len(missed) <= 2, missed                        # 0.5x / 1.5x events of 3 kb at 30x gamma-Poisson are at the method's limit
+    # idempotence: inputs untouched, same calls again
+    res2 = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
+    ok, why = calls_equal(res.calls("calls_raw"), res2.calls("calls_raw"), rtol=0)
+    assert ok, why
+
+
+def test_config4_one_60x_med_chromosome_against_reference_golden(hot, hotlib):
+    """configs[4]: a 112 Mb chromosome at 60x with -m 51 -MED -cap 4 (small bins, median transform, cap at work)."""
+    from rsicnv_amd import api
+    g, plan, flags = _golden("cfg5_chr13")
+    plan = _plan(plan)
+    assert plan["n"] >= 100_000_000 and flags == dict(m=51, trans=1, cap=4.0, gcadjust=1)
+    d_rd, d_fa = _device_case(hotlib, plan)
+    res = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
+    _check_against_golden(res, g, "60x MED m51")
+    rdc, _ = _properties(hot, res, 51, 4.0, plan)
+    assert gu.sha(rdc) == str(g["rd_concat_sha"])
+
+
+def test_config3_genome_in_flight_equals_one_at_a_time_and_golden(hot, hotlib):
+    """configs[3]: the 24 chromosomes of the 3 Gb genome, twelve in flight on one GPU: every chromosome's calls and statistics
+    equal the same chromosome alone on one context, and three of them (<= 60 Mb) equal the reference's golden tables."""
+    from rsicnv_amd import api, synth
+    flags = synth.config_flags(4)
+    params = api.make_params(**flags)
+    plans = [synth.config_plan(4, chrom=c) for c in range(24)]
+    assert abs(sum(p["n"] for p in plans) - 3_000_000_000) < 1000
+    bufs = [_device_case(hotlib, p) for p in plans]
+    args = [(b[0].data_ptr(), b[1].data_ptr(), p["n"]) for b, p in zip(bufs, plans)]
+    pool = api.RsiPool(0, 12)
+    batch = pool.run(params, args)
+    batch2 = pool.run(params, args)          # a second genome pass through warm workspaces
+    ncalls = 0
+    for c, (a, b) in enumerate(zip(batch, batch2)):
+        one = hot.run_device(params, *args[c])
+        for other in (a, b):
+            for which in ("calls_raw", "calls"):
+                ok, why = calls_equal(one.calls(which), other.calls(which), rtol=0)
+                assert ok, f"chromosome {c + 1} {which}: {why}"
+            for k in ("RDmedian", "RDsd", "cap_median", "nb_mad", "tmedian1", "tlamda1", "tmedian2", "tlamda2", "Lmax", "n_compact", "nbins"):
+                assert one.stats[k] == other.stats[k], (c + 1, k)
+        ncalls += len(one.calls("calls"))
+        if c in (18, 20, 21):
+            g, gplan, gflags = _golden(f"cfg4_chr{c + 1}")
+            assert _plan(gplan)["seed"] == plans[c]["seed"] and gflags == flags
+            _check_against_golden(a, g, f"chr{c + 1} in flight")
+    pool.close()
+    assert ncalls >= 300

@@ -125,6 +125,32 @@ def test_error_behaviour(hot, hotlib):
         hot.run(api.make_params(), depth[:-1], fasta)
 
 
+@pytest.mark.parametrize("flags", [dict(trans=1, m=51, gcadjust=0), dict(trans=1, gcadjust=0), dict(trans=1)], ids=["med51_nogc", "med101_nogc", "med101"])
+def test_equal_bin_medians_take_the_degenerate_quantile(hot, hotlib, oracle_cls, flags):
+    """Every bin median the same: the 0.01-grid "median" of a selection that spans less than the grid step is its MEAN
+    (partition_stat_tp's early return, wufunctions.cpp:371-381) -- the -MED transform's MAD is then 0, sigma 0, lambda the
+    target alone.  Depth 28, 32, 30, 28, ... keeps the per-base MAD at 2 (the NB transform, always computed, stays finite)
+    while every bin of 51 or 101 bases has median 30.  The product used to decline this input; it follows the reference now."""
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, _ = make_case(hotlib, dict(n=300_000, seed=0xF1A7, model=0, n_events=2, gaps=1, max_len=9000, end_n=3000, gap_len=5000))
+    depth = np.tile(np.array([28, 32, 30], dtype=np.int32), fasta.size // 3 + 1)[:fasta.size].copy()
+    depth[fasta == ord("N")] = 0
+    O = oracle_cls()
+    O.run(oracle.make_params(**flags), depth, fasta)
+    res = hot.run(api.make_params(**flags), depth, fasta)
+    sc = O.f64("scan_med")
+    got = [res.stats[k] for k in ("tmedian1", "tsigma1", "tlamda1", "tmedian2", "tsigma2", "tlamda2")]
+    assert got == list(sc[:6]) and got[0] == 30.0
+    assert res.stats["Lmax"] == int(sc[7])
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    if not flags.get("gcadjust", 1):   # without the GC rescale every bin median IS 30: the first-pass MAD is the degenerate one
+        assert set(hot.fetch("binmedint").tolist()) == {30} and got[1] == 0.0
+    assert np.array_equal(hot.fetch("status2"), O.i32("med_status2"))
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
+
+
 def test_huge_depth_values_take_the_wide_gc_path(hot, hotlib, oracle_cls):
     """Depths of 2^21 and more invalidate the packed GC accumulators: the pipeline re-runs the wide
     form and must still match the oracle (the cap removes the outliers afterwards)."""
@@ -341,9 +367,10 @@ def test_bin_size_extremes(hot, hotlib, oracle_cls):
     assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
     ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
     assert ok, why
+    # -m 3 (Lmax 3333) runs since the scan tile holds 3800 (golden case wide_m3_nb); -m 1 would need Lmax = 10000
     with pytest.raises(api.RsiError) as e:
-        hot.run(api.make_params(m=3), depth[:200_000], fasta[:200_000])
-    assert e.value.code == -5 and "2048" in str(e.value)
+        hot.run(api.make_params(m=1), depth[:200_000], fasta[:200_000])
+    assert e.value.code == -5 and "3800" in str(e.value)
 
 
 def test_many_n_runs(hot, hotlib, oracle_cls):
@@ -387,3 +414,60 @@ def test_deep_coverage_sends_tests_to_the_host_walk(hot, hotlib, oracle_cls):
     ok, why = calls_equal(res.calls("calls_raw"), O.calls("calls_raw"))
     assert ok, why
     assert len(res.calls("calls")) > 0
+
+
+def _level_sums_numpy(T, status, Lmax):
+    """The reference's loop (rsi.cpp:967-976): per status level, a float accumulation in index order (np.cumsum is sequential)."""
+    sums = np.zeros(2 * Lmax + 1, dtype=np.float32)
+    counts = np.zeros(2 * Lmax + 1, dtype=np.int32)
+    for l in np.unique(status):
+        x = T[status == l].astype(np.float32)
+        sums[l + Lmax] = np.cumsum(x, dtype=np.float32)[-1]
+        counts[l + Lmax] = x.size
+    return sums, counts
+
+
+@pytest.mark.parametrize("case", ["nb_like", "magnitudes", "ties", "edges"])
+def test_filterstatus_level_sums_are_the_sequential_float_sums(hot, case):
+    """The device's parallel form of filterstatus' per-level float accumulation (kernels_fs.hip) against the sequential loop, bit
+    for bit: values of one magnitude (the real case: 25 binade crossings in 2.5 M bins), of wildly mixed magnitudes (a crossing
+    every few bins), values that tie exactly at every rounding (powers of two), and the corner shapes."""
+    rng = np.random.default_rng({"nb_like": 1, "magnitudes": 2, "ties": 3, "edges": 4}[case])
+    Lmax = 99
+    def marks(nb, frac):
+        st = np.zeros(nb, dtype=np.int32)
+        k = int(nb * frac)
+        idx = rng.choice(nb, size=k, replace=False)
+        st[idx] = rng.integers(1, Lmax + 1, size=k) * rng.choice([-1, 1], size=k)
+        return st
+    inputs = []
+    if case == "nb_like":
+        nb = 2_470_000
+        inputs.append((rng.gamma(90.0, 1.0 / 3.0, nb).astype(np.float32), marks(nb, 0.01)))
+        inputs.append((np.round(rng.gamma(30.0, 1.0, nb)).astype(np.float32), marks(nb, 0.05)))      # -MED: integer-valued floats
+    elif case == "magnitudes":
+        nb = 600_000
+        inputs.append(((10.0 ** rng.uniform(-2, 4, nb)).astype(np.float32), marks(nb, 0.02)))
+        t = (10.0 ** rng.uniform(-3, 1, nb)).astype(np.float32); t[rng.random(nb) < 0.3] = 0.0
+        inputs.append((t, marks(nb, 0.3)))
+    elif case == "ties":
+        nb = 1_500_000
+        inputs.append((rng.choice(np.array([0.5, 1, 2, 4, 8, 16, 3, 6, 12, 24, 1.5], dtype=np.float32), nb), marks(nb, 0.01)))
+        inputs.append((np.full(nb, 4.0, dtype=np.float32), np.zeros(nb, dtype=np.int32)))           # every add a tie from 2^26 on
+    else:
+        for nb in (1, 7, 2047, 2048, 2049, 5000):
+            inputs.append((rng.gamma(9.0, 3.0, nb).astype(np.float32), marks(nb, 0.2)))
+        nb = 10_000
+        inputs.append((rng.gamma(9.0, 3.0, nb).astype(np.float32), rng.integers(1, 5, nb).astype(np.int32)))   # nothing unmarked
+        st = np.zeros(nb, dtype=np.int32); st[:4000] = -3                                                       # the sum starts late
+        inputs.append((rng.gamma(9.0, 3.0, nb).astype(np.float32), st))
+    for T, st in inputs:
+        got_s, got_c = hot.debug_level_sums(T, st, Lmax)
+        exp_s, exp_c = _level_sums_numpy(T, st, Lmax)
+        assert np.array_equal(got_c, exp_c)
+        assert np.array_equal(got_s.view(np.uint32), exp_s.view(np.uint32)), \
+            [(l - Lmax, float(a), float(b)) for l, (a, b) in enumerate(zip(got_s, exp_s)) if a != b][:5]
+    # a negative value: the integer-step form does not apply, the device says so and the pipeline runs the loop itself
+    T = rng.gamma(9.0, 3.0, 5000).astype(np.float32); T[1234] = -1.0
+    _, c = hot.debug_level_sums(T, np.zeros(5000, dtype=np.int32), Lmax)
+    assert c[Lmax] == -1
