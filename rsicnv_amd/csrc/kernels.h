@@ -217,10 +217,12 @@ void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start,
 // out: [2 Lmax + 1] float sums then [2 Lmax + 1] int32 counts, index = level + Lmax: the sum of T over the bins of each
 // status level accumulated in FLOAT in index order, bit for bit what the sequential loop gives (an exact parallel form, see
 // the file).  A count of -1 at level 0: the device declined (negative / non-finite values, or more than clist_cap marked
-// bins) and the caller runs the loop itself.  ws: level_sums_workspace_bytes(); its first 16 bytes zero before the launch.
-// counter: one arrival counter, zero before and after.  host_copy: mapped host memory for `out` (2 (2 Lmax + 1) words).
-size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap);
-void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int32_t clist_cap, float* out,
+// bins) and the caller runs the loop itself.  ws: level_sums_workspace_bytes() laid out for scans up to Lmax_cap; its first
+// level_sums_head_bytes(Lmax_cap) bytes zero before the launch.  counter: one arrival counter, zero before and after.
+// host_copy: mapped host memory for `out` (2 (2 Lmax + 1) words).
+size_t level_sums_head_bytes(int Lmax_cap);
+size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap, int Lmax_cap);
+void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int Lmax_cap, int32_t clist_cap, float* out,
                        unsigned int* counter, void* host_copy, hipStream_t stream);
 
 // Dynamic LDS beyond 48 KB has to be allowed per kernel and per device.  Done once per (kernel, device) and for all the CU

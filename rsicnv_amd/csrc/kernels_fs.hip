@@ -112,9 +112,13 @@ struct ChunkFn { int ue0; StepFn f0, f1; };   // unit exponents ue0 and ue0 + 1
 __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
                                                            const double* __restrict__ cpre, const int32_t* __restrict__ mpre,
                                                            ChunkFn* __restrict__ fns, int32_t* __restrict__ clist_s,
-                                                           float* __restrict__ clist_t, int32_t clist_cap) {
+                                                           float* __restrict__ clist_t, int32_t clist_cap, int Lmax,
+                                                           unsigned int* __restrict__ level_count) {
   __shared__ StepFn s_f[2][kThreads];
   __shared__ int s_cnt[kThreads];
+  extern __shared__ unsigned int s_lev[];   // [2 Lmax + 1]: this chunk's marked bins per level
+  for (int e = threadIdx.x; e < 2 * Lmax + 1; e += kThreads) s_lev[e] = 0;
+  __syncthreads();
   // candidate binades: the float sum that reaches the chunk lies within 15 % of the exact prefix P (at most 2^22 terms, each
   // addition off by at most 2^-24 of the sum); the binade of 0.85 P and the one above it cover [0.85 P, 1.15 P]
   const double P = cpre[blockIdx.x];
@@ -132,7 +136,10 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
       const int st = status[i];
       const float x = T[i];
       if (st == 0) { f0 = fs_compose(f0, fs_step(x, ue0)); f1 = fs_compose(f1, fs_step(x, ue0 + 1)); }
-      else { ms[nm] = st; mt[nm] = x; ++nm; }
+      else {
+        ms[nm] = st; mt[nm] = x; ++nm;
+        if (st >= -Lmax && st <= Lmax) atomicAdd(&s_lev[st + Lmax], 1u);   // which levels exist at all
+      }
     }
   }
   s_f[0][threadIdx.x] = f0; s_f[1][threadIdx.x] = f1; s_cnt[threadIdx.x] = nm;
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
     for (int t = 0; t < kThreads; ++t) acc = fs_compose(acc, s_f[threadIdx.x][t]);
     if (threadIdx.x == 0) { fns[blockIdx.x].ue0 = ue0; fns[blockIdx.x].f0 = acc; } else fns[blockIdx.x].f1 = acc;
   }
+  for (int e = threadIdx.x; e < 2 * Lmax + 1; e += kThreads) { const unsigned int c = s_lev[e]; if (c) atomicAdd(&level_count[e], c); }
   int before = 0;
   for (int t = 0; t < (int)threadIdx.x; ++t) before += s_cnt[t];
   const int base = mpre[blockIdx.x] + before;
@@ -149,28 +157,45 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
   for (int k = 0; k < kPerThread; ++k) if (k < nm && base + k < clist_cap) { clist_s[base + k] = ms[k]; clist_t[base + k] = mt[k]; }
 }
 
-// Pass 4 (two workgroups).  Workgroup 0 carries the unmarked level's float sum over the chunks: the chunk records are staged
-// in LDS a batch at a time, lane 0 applies them one after the other and stops at the first chunk it cannot take in one step;
-// the whole workgroup then stages that chunk's bins in LDS and lane 0 adds them one by one.  Workgroup 1 takes the marked
-// levels, one level per thread (round robin), over the compact list.  out: [2 Lmax + 1] float sums then [2 Lmax + 1] int
-// counts (index = level + Lmax); the workgroup that finishes last copies them to mapped host memory.  A count of -1 at the
-// unmarked level tells the host to do the sums itself (more marked bins than the compact list holds, or a negative /
-// non-finite value: the integer-step argument needs x >= 0).
+// Pass 4, one launch.
+//  * Workgroups 0 .. ceil((2 Lmax + 1) / 4) - 1: one WAVE per marked level.  The wave streams the compact list, 64 entries a
+//    step, and keeps the values of ITS level in order without a barrier: ballot of the matches, a lane's slot is the number
+//    of matching lanes below it, values into the wave's LDS queue; lane 0 adds the queue to the level's float sum whenever
+//    it fills up.  A level no bin carries (most of them) returns at once.
+//  * The last workgroup carries the unmarked level's float sum over the chunks: the chunk records are staged in LDS a batch at
+//    a time, lane 0 applies them one after the other and stops at the first chunk it cannot take in one step (a binade
+//    crossing, or the start of the sum).  The workgroup then stages that chunk's bins in LDS, every thread composes the step
+//    functions of its eight bins for the sum's current binade and the next, and lane 0 walks those 256 functions, going bin by
+//    bin only through the eight where the sum actually crosses.
+// out: [2 Lmax + 1] float sums then [2 Lmax + 1] int counts (index = level + Lmax); the workgroup that finishes last copies
+// them to mapped host memory.  A count of -1 at the unmarked level tells the host to do the sums itself (more marked bins
+// than the compact list holds, or a negative / non-finite value: the integer-step argument needs x >= 0).
 constexpr int kFnBatch = 1024;
+__device__ inline bool fs_apply(float& s, int ue, StepFn f) {   // one step of a function valid for unit exponent ue; false: not applicable
+  const uint32_t bits = __float_as_uint(s);
+  const int ex = (int)((bits >> 23) & 0xff);
+  if (ex == 0 || ex == 255 || ex - 150 != ue) return false;
+  const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+  const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
+  if (S2 >= (1ll << 24)) return false;                          // the sum would leave the binade
+  s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S2 & 0x7fffffu));
+  return true;
+}
 __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
                                                             int nchunks, const ChunkFn* __restrict__ fns, const int32_t* __restrict__ clist_s,
                                                             const float* __restrict__ clist_t, const int32_t* __restrict__ total_marked,
-                                                            int32_t clist_cap, int Lmax, float* __restrict__ out,
-                                                            unsigned int* __restrict__ counter, void* host_copy) {
+                                                            const unsigned int* __restrict__ level_count, int32_t clist_cap, int Lmax,
+                                                            float* __restrict__ out, unsigned int* __restrict__ counter, void* host_copy) {
   __shared__ ChunkFn s_fn[kFnBatch];
   __shared__ float s_x[kChunk];
-  __shared__ int s_stop;
+  __shared__ StepFn s_ta[kThreads], s_tb[kThreads];
+  __shared__ int s_stop, s_ue;
   const int nlev = 2 * Lmax + 1;
   unsigned int* out_bits = reinterpret_cast<unsigned int*>(out);
   unsigned int* out_cnt = out_bits + nlev;
   const int M = total_marked[0];
   const bool bad = total_marked[1] != 0 || M > clist_cap;
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == gridDim.x - 1) {
     float s = 0.0f;
     for (int b0 = 0; b0 < nchunks; b0 += kFnBatch) {
       const int bn = nchunks - b0 < kFnBatch ? nchunks - b0 : kFnBatch;
@@ -180,45 +205,113 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
       int c = 0;
       while (c < bn) {
         if (threadIdx.x == 0) {
-          while (c < bn) {
-            const ChunkFn F = s_fn[c];
-            const uint32_t bits = __float_as_uint(s);
-            const int ex = (int)((bits >> 23) & 0xff);
-            const int ue = ex - 150;                           // s = S 2^ue with 2^23 <= S < 2^24 (normal s)
-            if (ex == 0 || ex == 255 || (ue != F.ue0 && ue != F.ue0 + 1)) break;
-            const StepFn f = ue == F.ue0 ? F.f0 : F.f1;
-            const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
-            const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
-            if (S2 >= (1ll << 24)) break;                      // the sum leaves the binade inside this chunk
-            s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S2 & 0x7fffffu));
-            ++c;
+          // the sum as (unit exponent, 24-bit integer) while it walks the chunk records: a handful of integer operations per chunk,
+          // the next record's LDS reads issued before this one's are used
+          const uint32_t bits = __float_as_uint(s);
+          const int ex = (int)((bits >> 23) & 0xff);
+          if (ex != 0 && ex != 255) {
+            const int ue = ex - 150;
+            long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+            ChunkFn F = s_fn[c];
+            while (c < bn) {
+              const ChunkFn Fn = s_fn[c + 1 < bn ? c + 1 : c];
+              const int d = ue - F.ue0;
+              if (d != 0 && d != 1) break;
+              const StepFn f = d == 0 ? F.f0 : F.f1;
+              const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
+              if (S2 >= (1ll << 24)) break;                    // the sum leaves the binade inside this chunk
+              S = S2;
+              F = Fn;
+              ++c;
+            }
+            s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S & 0x7fffffu));
           }
           s_stop = c;
+          s_ue = (int)((__float_as_uint(s) >> 23) & 0xff) - 150;
         }
         __syncthreads();
         c = s_stop;
         if (c >= bn) break;
-        // chunk b0 + c bin by bin: its unmarked values into LDS (marked ones as -1), lane 0 adds them in order
-        const int64_t i0 = (int64_t)(b0 + c) * kChunk;
-        for (int e = threadIdx.x; e < kChunk; e += kThreads) {
-          const int64_t i = i0 + e;
-          s_x[e] = (i < nb && status[i] == 0) ? T[i] : -1.0f;
+        // chunk b0 + c: its unmarked values into LDS (marked ones as -1), per-thread step functions for the sum's binade and
+        // the one above, lane 0 walks them
+        const int ue = s_ue;
+        const int64_t i0 = (int64_t)(b0 + c) * kChunk + (int64_t)threadIdx.x * kPerThread;
+        StepFn fa = {0, 0}, fb = {0, 0};
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+          const int64_t i = i0 + k;
+          const bool use = i < nb && status[i] == 0;
+          const float x = use ? T[i] : -1.0f;
+          s_x[threadIdx.x * kPerThread + k] = x;
+          if (use) { fa = fs_compose(fa, fs_step(x, ue)); fb = fs_compose(fb, fs_step(x, ue + 1)); }
         }
+        s_ta[threadIdx.x] = fa; s_tb[threadIdx.x] = fb;
         __syncthreads();
-        if (threadIdx.x == 0) for (int e = 0; e < kChunk; ++e) { const float x = s_x[e]; if (x >= 0.0f) s += x; }
+        if (threadIdx.x == 0) {
+          // the same walk over the 256 per-thread functions, the sum as (unit exponent, integer); the eight bins of a thread whose
+          // function does not apply (the crossing itself, or a sum still below the normal range) are added one by one
+          int t = 0;
+          while (t < kThreads) {
+            const uint32_t bits = __float_as_uint(s);
+            const int ex = (int)((bits >> 23) & 0xff);
+            const int d = ex - 150 - ue;
+            if (ex != 0 && ex != 255 && (d == 0 || d == 1)) {
+              long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+              const StepFn* fn = d == 0 ? s_ta : s_tb;
+              StepFn f = fn[t];
+              while (t < kThreads) {
+                const StepFn fnx = fn[t + 1 < kThreads ? t + 1 : t];
+                const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
+                if (S2 >= (1ll << 24)) break;
+                S = S2; f = fnx; ++t;
+              }
+              s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S & 0x7fffffu));
+              if (t >= kThreads) break;
+            }
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) { const float x = s_x[t * kPerThread + k]; s = x >= 0.0f ? s + x : s; }
+            ++t;
+          }
+        }
         ++c;
         __syncthreads();
       }
     }
     if (threadIdx.x == 0) { st_cg(&out_bits[Lmax], __float_as_uint(s)); st_cg(&out_cnt[Lmax], bad ? 0xffffffffu : (unsigned int)(nb - M)); }
-  } else if (!bad) {
-    for (int li = (int)threadIdx.x; li < nlev; li += kThreads) {
-      const int l = li - Lmax;
-      if (l == 0) continue;
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = (int)blockIdx.x * (kThreads / 64) + wave, l = li - Lmax;
+    if (li < nlev && l != 0) {
+      float* q = s_x + wave * (kChunk / (kThreads / 64));   // the wave's queue: 512 floats
+      constexpr int kQ = kChunk / (kThreads / 64);
       float s = 0.0f;
-      int c = 0;
-      for (int k = 0; k < M; ++k) if (clist_s[k] == l) { s += clist_t[k]; ++c; }
-      st_cg(&out_bits[li], __float_as_uint(s)); st_cg(&out_cnt[li], (unsigned int)c);
+      int cnt = 0, qn = 0;
+      if (!bad && level_count[li] != 0) {
+        for (int k0 = 0; k0 < M; k0 += 64 * 8) {   // eight loads in flight per lane, then the eight 64-entry steps in order
+          int key[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int e = k0 + 64 * j + lane; key[j] = e < M ? clist_s[e] : 0; }   // 0 is never a marked level
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool hit = key[j] == l;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+              if (qn + 64 > kQ) {   // drain: lane 0 adds the queued values in order
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) for (int jj = 0; jj < qn; ++jj) s += q[jj];
+                qn = 0;
+                __builtin_amdgcn_wave_barrier();
+              }
+              if (hit) q[qn + __popcll(mask & ((1ull << lane) - 1))] = clist_t[k0 + 64 * j + lane];
+              const int m = __popcll(mask);
+              qn += m; cnt += m;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) for (int j = 0; j < qn; ++j) s += q[j];
+      }
+      if (lane == 0) { st_cg(&out_bits[li], __float_as_uint(s)); st_cg(&out_cnt[li], (unsigned int)cnt); }
     }
   }
   if (!last_block_done(counter)) return;
@@ -227,15 +320,18 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
 
 }  // namespace
 
-size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap) {
+size_t level_sums_head_bytes(int Lmax) { return (16 + (size_t)(2 * Lmax + 1) * 4 + 15) & ~size_t(15); }   // what must be zero before a launch
+size_t level_sums_workspace_bytes(int64_t nb, int32_t clist_cap, int Lmax_cap) {
   const size_t nchunks = (size_t)((nb + kChunk - 1) / kChunk);
-  return nchunks * (8 + sizeof(ChunkFn)) + ((nchunks * 4 + 15) & ~size_t(15)) + 16 + (size_t)clist_cap * 8 + 256;
+  return level_sums_head_bytes(Lmax_cap) + nchunks * (8 + sizeof(ChunkFn)) + ((nchunks * 4 + 15) & ~size_t(15)) + (size_t)clist_cap * 8 + 256;
 }
-void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int32_t clist_cap, float* out,
+void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lmax, void* ws, int Lmax_cap, int32_t clist_cap, float* out,
                        unsigned int* counter, void* host_copy, hipStream_t stream) {
   const int nchunks = (int)((nb + kChunk - 1) / kChunk);
   unsigned char* p = static_cast<unsigned char*>(ws);
-  int32_t* total = reinterpret_cast<int32_t*>(p); p += 16;   // [0] marked bins, [1] flag; cleared by the caller's fill list
+  int32_t* total = reinterpret_cast<int32_t*>(p);            // [0] marked bins, [1] flag
+  unsigned int* level_count = reinterpret_cast<unsigned int*>(p + 16);
+  p += level_sums_head_bytes(Lmax_cap);
   double* csum = reinterpret_cast<double*>(p); p += (size_t)nchunks * 8;
   ChunkFn* fns = reinterpret_cast<ChunkFn*>(p); p += (size_t)nchunks * sizeof(ChunkFn);
   int32_t* cmark = reinterpret_cast<int32_t*>(p); p += ((size_t)nchunks * 4 + 15) & ~size_t(15);
@@ -243,9 +339,9 @@ void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lm
   float* clist_t = reinterpret_cast<float*>(p);
   hipLaunchKernelGGL(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
   hipLaunchKernelGGL(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
-  hipLaunchKernelGGL(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap);
-  hipLaunchKernelGGL(k_fs_level_sums, dim3(2), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, clist_cap, Lmax, out,
-                     counter, host_copy);
+  hipLaunchKernelGGL(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), (size_t)(2 * Lmax + 1) * 4, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap, Lmax, level_count);
+  hipLaunchKernelGGL(k_fs_level_sums, dim3((2 * Lmax + 1 + kThreads / 64 - 1) / (kThreads / 64) + 1), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, level_count,
+                     clist_cap, Lmax, out, counter, host_copy);
 }
 
 }  // namespace rsik

@@ -103,7 +103,7 @@ void scan_fill_list(rsi_ctx* ctx, int pass, int64_t nb, FillList& fl) {
   fill_add(fl, d_first_del, (size_t)(nbpad + nb) * 4, 0xffffffffu);
   fill_add(fl, small + kOffScanPass + (size_t)pass * kScanPassBytes, kScanPassBytes, 0u);
   fill_add(fl, small + kOffCounters, 32, 0u);
-  if (pass == 0 && ctx->fs_ws.p) fill_add(fl, ctx->fs_ws.p, 16, 0u);   // filterstatus' level sums: marked count, flag
+  if (pass == 0 && ctx->fs_ws.p) fill_add(fl, ctx->fs_ws.p, level_sums_head_bytes(kMaxL), 0u);   // filterstatus' level sums: marked count, flag, level counts
 }
 // Issues the (median, MAD) pair of the selection (mask == 0 where given).  planned: the first link's min/max + plan has been
 // done by the kernel that produced x (launch_nb_scale_minmax).  with_median = false: only the MAD around `center`
@@ -551,7 +551,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   {
     GateShared gs(ctx);
     Timer t(ctx, "level_sums");
-    launch_level_sums(d_T, d_st1, nb, Lmax, ctx->fs_ws.p, kFsListCap, ctx->fs_out.as<float>(),
+    launch_level_sums(d_T, d_st1, nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(),
                       reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4, fs_slot, ctx->stream);
   }
   { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
@@ -1047,7 +1047,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
     HIPCHK(ctx->status2.ensure((size_t)nb * 4));
     HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
-    HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap)));
+    HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap, kMaxL)));
     HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
 
     // ---- A10: NB transform (K5), always computed as the reference does (Q10).  The raw minimum stays on the device: the
@@ -1348,17 +1348,17 @@ int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status
   HIPCHK(ctx->small.ensure(kSmallBytes));
   HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
   HIPCHK(ctx->status1.ensure((size_t)nb * 4));
-  HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap)));
+  HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap, kMaxL)));
   HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
   HIPCHK(hipMemcpyAsync(ctx->tnb.p, T, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->status1.p, status, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
   unsigned int* counter = reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4;
-  HIPCHK(hipMemsetAsync(ctx->fs_ws.p, 0, 16, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->fs_ws.p, 0, level_sums_head_bytes(kMaxL), ctx->stream));
   HIPCHK(hipMemsetAsync(counter, 0, 4, ctx->stream));
   const int nlev = 2 * Lmax + 1;
   uint32_t* slot = static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
   if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
-  launch_level_sums(ctx->tnb.as<float>(), ctx->status1.as<int32_t>(), nb, Lmax, ctx->fs_ws.p, kFsListCap, ctx->fs_out.as<float>(), counter, slot, ctx->stream);
+  launch_level_sums(ctx->tnb.as<float>(), ctx->status1.as<int32_t>(), nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(), counter, slot, ctx->stream);
   HIPCHK(CTX_SYNC());
   memcpy(sums, slot, (size_t)nlev * 4);
   memcpy(counts, slot + nlev, (size_t)nlev * 4);
