@@ -51,7 +51,8 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
 // ---- K3: GC rescale + value histogram (adjustgccontent, gccontent.cpp:43-92; feeds apply_cap) ----
 // table[202] and rdmean as computed on the host from GcAccum.  out may be NULL (histogram only);
 // adjust=0 copies depth through unchanged (the -NOGC path only needs the histogram).
-// hist[kHistValues] counts output values < kHistValues; *big counts the rest, *vmax their maximum.
+// hist[kHistValues] counts output values < kHistValues; *big counts the rest; *vmax: the largest value of 256 and more seen
+// (0: none) -- counters beyond it are zero, which bounds the median walk.
 struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int negatives; };
 // Median walk of partition_stat_tp (wufunctions.cpp:398-420, dy = 1) over hist[kHistValues] for `total` values, on the device:
 // inrange = sum of the counters, lo / hi = smallest / largest value present (lo > hi: none), med = the bucket where the

@@ -19,6 +19,7 @@ constexpr int kGcWords = kTileBases / 64;  // 64 words per tile
 constexpr int kGcLeft = 4;                 // margin words left of the tile (256 bits >= 201)
 constexpr int kGcRight = 2;                // margin words right of the tile (128 bits >= 101)
 constexpr int kGcLds = kGcLeft + kGcWords + kGcRight;   // 70
+constexpr int kValLds = 256;               // K3 / K3': values below this are counted in LDS, [value][32 lane phases]
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 
@@ -443,7 +444,7 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
   const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
   auto hist_add = [&](int to) {
     if (!ghist) return;
-    if (to >= 0 && to < kHistValues) atomicAdd(&ghist[to], 1u);
+    if (to >= 0 && to < kHistValues) { atomicAdd(&ghist[to], 1u); if (to >= kValLds) atomicMax(&aux->vmax, (unsigned int)to); }
     else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
     else atomicOr(&aux->negatives, 1u);
   };
@@ -492,11 +493,13 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
 
 // Median walk of partition_stat_tp (wufunctions.cpp:398-420, dy = 1) over hist[kHistValues] for `total` values by one
 // workgroup of NT threads (kHistValues / NT consecutive counters each); the counters were written by other workgroups.
+// `range`: counters at and beyond it are known to be zero (the kernels keep the largest value that went past the LDS range
+// in ValueHistAux::vmax), a multiple of NT.
 template <int NT>
-__device__ inline void value_median_block(const uint32_t* __restrict__ hist, unsigned long long total, ValueMedian* __restrict__ out) {
+__device__ inline void value_median_block(const uint32_t* __restrict__ hist, unsigned long long total, ValueMedian* __restrict__ out, int range) {
   __shared__ unsigned long long s_w[NT / 64];
   __shared__ int s_lo[NT / 64], s_hi[NT / 64], s_med;
-  constexpr int kPer = kHistValues / NT;
+  const int kPer = range / NT;
   const int v0 = threadIdx.x * kPer;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long local = 0;
@@ -535,15 +538,21 @@ __device__ inline void value_median_block(const uint32_t* __restrict__ hist, uns
   }
 }
 
-constexpr int kValLds = 256;   // values below this are counted in LDS, [value][32 lane phases]
 
 // rare path (values outside the LDS range): kept out of line so the unrolled callers stay small
 __device__ __attribute__((noinline)) void value_hist_add(unsigned int* s_hist, uint32_t* __restrict__ ghist, ValueHistAux* aux, int v,
                                       int phase) {
   if (v >= 0 && v < kValLds) atomicAdd(&s_hist[v * 32 + phase], 1u);
-  else if (v >= 0 && v < kHistValues) atomicAdd(&ghist[v], 1u);
+  else if (v >= 0 && v < kHistValues) atomicAdd(&ghist[v], 1u);   // the caller keeps the largest such value (lane register -> ValueHistAux::vmax)
   else if (v < 0) atomicOr(&aux->negatives, 1u);
-  else { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)v); }
+  else atomicAdd(&aux->big, 1ull);
+}
+
+// The largest value a workgroup's lanes counted outside the LDS range -> ValueHistAux::vmax: one atomic per wave that has
+// one (a same-address atomic per VALUE serialises: a chromosome with ten thousand such values lost a millisecond to it).
+__device__ inline void publish_hist_hi(int lane_hi, ValueHistAux* __restrict__ aux) {
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(lane_hi, d); lane_hi = o > lane_hi ? o : lane_hi; }
+  if (lane_id() == 0 && lane_hi >= kValLds) atomicMax(&aux->vmax, (unsigned int)lane_hi);
 }
 
 // What the last workgroup of a value-histogram kernel (K3, K3') does once every workgroup's LDS histogram s_hist
@@ -569,7 +578,13 @@ __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __
   sync_drained();
   if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
   sync_drained();
-  value_median_block<kThreads>(ghist, (unsigned long long)n, vm);
+  {
+    const unsigned int hi = ld_cg(&aux->vmax);                       // largest value counted outside the LDS range (0: none)
+    int range = hi >= (unsigned int)kHistValues ? kHistValues : (int)hi + 1;
+    range = range < kValLds ? kValLds : range;
+    range = (range + kThreads - 1) / kThreads * kThreads;
+    value_median_block<kThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
+  }
   sync_drained();
   export_words(head_dst, head_src, head_bytes);
 }
@@ -594,6 +609,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   if (ADJUST) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
   const double rdmean = ADJUST ? table[kGcLevels] : 0.0;
   const int phase = threadIdx.x & 31;
+  int lane_hi = 0;   // largest value this lane sent past the LDS range
   const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
   auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
     const int64_t base = tile * kTileBases;
@@ -631,6 +647,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
       } else {
         value_hist_add(s_hist, ghist, aux, v0, phase); value_hist_add(s_hist, ghist, aux, v1, phase);
         value_hist_add(s_hist, ghist, aux, v2, phase); value_hist_add(s_hist, ghist, aux, v3, phase);
+        const int h01 = v0 > v1 ? v0 : v1, h23 = v2 > v3 ? v2 : v3, h = h01 > h23 ? h01 : h23;
+        lane_hi = h > lane_hi ? h : lane_hi;
       }
       if (out) *reinterpret_cast<int4*>(out + q) = make_int4(v0, v1, v2, v3);
     }
@@ -651,6 +669,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   }
   __syncthreads();
   if (materialize) return;   // the tail quirks are applied to out[] by a launch of their own (k_gc_tail_fixup_out)
+  publish_hist_hi(lane_hi, aux);
   value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
 }
 
@@ -704,6 +723,7 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   WaveGc& G = s_gc[wave];
   const int phase = lane & 31;
+  int lane_hi = 0;   // largest value this lane sent past the LDS range
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
   const int64_t whole = n & ~(int64_t)3;   // the ragged last n % 4 bases belong to the tail fixup, as in K3
@@ -762,7 +782,7 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
         for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * 32 + phase], 1u);
       } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) value_hist_add(s_hist, ghist, aux, v[j], phase);
+        for (int j = 0; j < 16; ++j) { value_hist_add(s_hist, ghist, aux, v[j], phase); lane_hi = v[j] > lane_hi ? v[j] : lane_hi; }
       }
     } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only, straight from the int32 array
       for (int j = 0; j < 16; ++j) {
@@ -772,7 +792,9 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
         if (lo < 0) lo = 0;
         if (lo > n - 202) lo = n - 202;
         const uint32_t rel = (uint32_t)(lo - first_bit);
-        value_hist_add(s_hist, ghist, aux, rescale(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel)), phase);
+        const int ve = rescale(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+        value_hist_add(s_hist, ghist, aux, ve, phase);
+        lane_hi = ve > lane_hi ? ve : lane_hi;
       }
     }
     __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
@@ -789,6 +811,7 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
     sub += stride;
   }
   __syncthreads();
+  publish_hist_hi(lane_hi, aux);
   value_hist_finish<true>(s_hist, depth, gcbits, n, table, nullptr, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
 }
 
@@ -1056,7 +1079,7 @@ __device__ inline int gc_count201(const uint64_t* __restrict__ gcbits, int64_t l
 
 struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t x, y, z, w; };   // 16 bytes at any byte address (gfx950 loads them in one go)
 
-template <int MAXC, int EPT>
+template <int MAXC, int EPT, bool SW7>
 __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
     const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
     const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
@@ -1242,10 +1265,49 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
     // ---- request the next tile now: its loads fly during the median phase ----
     const int64_t cur_tile = tile;
     if (tile + gridDim.x < ntiles) { geometry(tile + gridDim.x, P0, P1, fast, soff); if (fast) request(soff); }
-    // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin, values in registers ----
+    // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin ----
     const int b_local = threadIdx.x / parts, part = threadIdx.x % parts;
     const int64_t b = cur_tile * TB + b_local;
     const bool active = b < nb;
+    if (SW7) {
+      // Values below 128 (the cap is): four to a register, straight from the LDS bytes.  A bin is the bytes [B, B + m) of the
+      // tile; its (up to 27) dwords go round robin to the bin's four threads, bytes outside the bin masked -- to 0 for the
+      // sum (v_sad_u8 adds four bytes in one instruction), to 0xff for the counts.  #{x > mid} of four values is one
+      // subtraction and one popcount: with the top bit of every byte set, (x | 0x80) - (mid + 1) keeps that bit exactly
+      // where x > mid, and no byte borrows from its neighbour.  Bisection from [0, cap]: the same seven steps for every bin.
+      const int B = b_local * m;
+      const int d0 = B >> 2, d1 = (B + m - 1) >> 2;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(s_val);
+      uint32_t xo[7];
+      uint32_t ssum = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int d = d0 + part + 4 * i;
+        const uint32_t v = w[d <= d1 ? d : d1];
+        const int lo_cut = B - 4 * d, hi_cut = 4 * d + 4 - (B + m);          // bytes of the dword before / after the bin
+        uint32_t keep = 0xffffffffu;
+        keep = lo_cut > 0 ? keep << (8 * lo_cut) : keep;
+        keep = hi_cut > 0 ? keep & (0xffffffffu >> (8 * hi_cut)) : keep;
+        keep = (d <= d1 && active) ? keep : 0u;
+        ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
+        xo[i] = (v | ~keep) | 0x80808080u;
+      }
+      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      int lo = 0, hi = capval;
+#pragma unroll 1
+      for (int it = 0; it < 7; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t sub = (uint32_t)(mid + 1) * 0x01010101u;
+        int gt = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gt += __popc((xo[i] - sub) & 0x80808080u);
+        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        // masked bytes (0xff) always count as "> mid" (mid <= 126): 28 dword slots x 4 bytes - m of them per bin
+        const int le = 4 * 7 * parts - gt;
+        if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
+      }
+      if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+    } else {
     const unsigned char* x = s_val + b_local * m;
     int lo = 0x7fffffff, hi = (int)0x80000000;
     int ssum = 0;
@@ -1271,6 +1333,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
       if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
     }
     if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+    }
   }
   __syncthreads();
   // ---- per-workgroup histogram slab; the last workgroup folds them into res_hist (every value is below vr: overwrite)
@@ -1417,14 +1480,16 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
   const int ept = (m + 3) / 4;
-#define RSI_K48(MC, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP>));                                                          \
-    hipLaunchKernelGGL((k_cap_compact_bin8<MC, EP>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
+#define RSI_K48(MC, EP, SW) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP, SW>));                                                  \
+    hipLaunchKernelGGL((k_cap_compact_bin8<MC, EP, SW>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
                        cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
                        exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
-  if (maxc == 1 && ept <= 13) RSI_K48(1, 13);
-  else if (ept <= 13) RSI_K48(2, 13);
-  else if (maxc == 1) RSI_K48(1, 26);
-  else RSI_K48(2, 26);
+  const bool sw7 = capval <= 127;   // four values to a register in the median phase (k_cap_compact_bin8, SW7)
+  if (sw7) { if (maxc == 1) RSI_K48(1, 1, true); else RSI_K48(2, 1, true); }
+  else if (maxc == 1 && ept <= 13) RSI_K48(1, 13, false);
+  else if (ept <= 13) RSI_K48(2, 13, false);
+  else if (maxc == 1) RSI_K48(1, 26, false);
+  else RSI_K48(2, 26, false);
 #undef RSI_K48
 }
 int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact) {
