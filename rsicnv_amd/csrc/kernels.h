@@ -39,6 +39,9 @@ struct GcAccum {
 // K2 leaves a byte copy of the depth behind (depth8[i] = min(depth[i], kByteEscape)): the later per-base passes stream one
 // byte per base instead of four and turn to the int32 array only where a byte says kByteEscape.
 constexpr int kByteEscape = 255;
+// K3' leaves a byte copy of the GC-RESCALED depth behind, saturated at kByteSat ("this much or more"): K4' streams it when
+// the cap is below that (a saturated value is capped either way).
+constexpr int kByteSat = 254;
 // packed = 1: one LDS atomic per base (count and sum in one 64-bit word), valid for depths < 2^21;
 // when the result carries flag bit 1 the caller zeroes acc and launches again with packed = 0.
 // slabs: scratch of gc_hist_slab_bytes(n) bytes (per-workgroup partial results, folded by a second tiny kernel).
@@ -76,7 +79,7 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
 size_t value_hist8_slab_bytes(int64_t n);
 void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                         uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
-                        const void* head_src, void* head_dst, size_t head_bytes, hipStream_t stream);
+                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8 /* n + 2048 bytes */, hipStream_t stream);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
 // (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;
@@ -104,12 +107,13 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
                             uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
                             const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
 
-// K4 fed from the byte copy of the RAW depth: the GC rescale happens inside, the rescaled int32 array is never needed.
-// Applies when cap_compact8_applies(): 1 <= capval < kByteEscape (every value fits a byte, res_hist is overwritten) and
-// m <= 104.  table: K2's [kGcLevels] level means + the mean of the positive depths.
+// K4 fed from K3''s byte copy of the rescaled depth (rescaled8): the rescaled int32 array is never needed.  Applies when
+// cap_compact8_applies(): 1 <= capval < kByteSat (every capped value fits a byte, res_hist is overwritten) and m <= 104.
+// depth / gcbits / table (K2's [kGcLevels] level means + the mean of the positive depths): for the tiles at the chromosome's
+// ends and across removed regions, which recompute the rescale per element.
 int cap_compact8_applies(int m, int32_t capval);
 size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact);
-void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+void launch_cap_compact_bin8(const uint8_t* rescaled8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                              const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
                              int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);

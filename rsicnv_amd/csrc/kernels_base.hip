@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
                                                           ValueHistAux* __restrict__ aux, unsigned int* __restrict__ hist_slabs,
                                                           unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters,
                                                           ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
-                                                          unsigned int head_bytes) {
+                                                          unsigned int head_bytes, uint8_t* __restrict__ out8) {
   __shared__ WaveGc s_gc[kThreads / 64];
   __shared__ double s_table[kGcLevels];
   __shared__ float s_ratio[kGcLevels];
@@ -777,6 +777,16 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
       unsigned ored = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) ored |= (unsigned)v[j];
+      {   // the rescaled values as bytes, saturated at kByteSat ("this much or more"), for the kernel that caps them anyway
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = v[4 * q] > kByteSat ? kByteSat : v[4 * q], b = v[4 * q + 1] > kByteSat ? kByteSat : v[4 * q + 1];
+          const int c = v[4 * q + 2] > kByteSat ? kByteSat : v[4 * q + 2], d = v[4 * q + 3] > kByteSat ? kByteSat : v[4 * q + 3];
+          pk[q] = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+        }
+        *reinterpret_cast<uint4*>(out8 + i0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      }
       if (ored < (unsigned)kValLds) {   // the common case, branch-free: sixteen LDS atomics into [value][lane phase]
 #pragma unroll
         for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * 32 + phase], 1u);
@@ -795,6 +805,7 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
         const int ve = rescale(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel));
         value_hist_add(s_hist, ghist, aux, ve, phase);
         lane_hi = ve > lane_hi ? ve : lane_hi;
+        out8[i] = (uint8_t)(ve > kByteSat ? kByteSat : ve);
       }
     }
     __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
@@ -1034,31 +1045,17 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
 
 
 // ------------------------------------------------------------------------------------------
-// K4'  cap_compact_bin8: K4 fed from the byte copy of the RAW depth.  The GC rescale (gccontent.cpp:89) happens here, so
-// the rescaled int32 array is never written or read: per base this kernel reads 1 byte + 1 mask bit and writes the 4 bytes
-// of the capped, compacted depth -- 5.2 B/base against 8.4 for K4 behind a K3 that writes 4 more.
+// K4'  cap_compact_bin8: K4 fed from the byte copy of the GC-RESCALED depth that K3' leaves behind (values saturated at
+// kByteSat: the kernel is used when the cap is lower, so a saturated value is capped either way).  The rescaled int32 array is
+// never written or read: per base this kernel reads 1 byte and writes the 4 bytes of the capped, compacted depth -- 5 B/base
+// against 8.4 for K4 behind a K3 that writes 4 more -- and its per-base work is unpack, cap, one LDS atomic, pack.
 //
-// A plain tile (no removed region cuts it) is a contiguous SOURCE range; it is covered by 16-byte chunks aligned in the
-// source, thread t owning chunk t (and t + 256): 16 consecutive bases = one 16-byte load, requested one tile ahead.
-// The window GC counts of 16 consecutive bases are two rank queries and one leaving / entering bit pair each (as in K2);
-// the tile's GC words sit in LDS with their popcount prefix.  Values are capped below 255 (the kernel is used when the
-// cap is), so the tile's values live in LDS as BYTES, chunk-aligned (ds_write_b128, conflict-free), and the per-bin
-// median phase reads its bin's bytes at whatever offset they have.  A chunk with an escape byte fetches its 16 values
-// from the int32 array.  Tiles that touch the chromosome's ends (clamped windows, App. A Q1; the tail quirks of the
-// 20-slice write-back, Q2/Q3) or are cut by a removed region take a per-element path that works from the int32 array.
-constexpr int kGc4Words = 112;   // staged GC words of a tile: 4 margin + up to 105 + 2 margin
-struct Gc4Tile { uint64_t word[kGc4Words]; uint32_t pre[kGc4Words + 1]; };
-__device__ inline uint32_t g4_rank(const Gc4Tile& t, uint32_t rel) {
-  const uint32_t k = rel >> 6, b = rel & 63;
-  const uint64_t m = b ? (t.word[k] & ((1ull << b) - 1)) : 0;
-  return t.pre[k] + (uint32_t)__popcll(m);
-}
-__device__ inline uint32_t g4_field16(const Gc4Tile& t, uint32_t rel) {
-  const uint32_t k = rel >> 6, b = rel & 63;
-  uint64_t v = t.word[k] >> b;
-  if (b > 48) v |= t.word[k + 1] << (64 - b);
-  return (uint32_t)v & 0xffffu;
-}
+// A plain tile (no removed region cuts it) is a contiguous SOURCE range.  Chunks of 16 values are aligned in the COMPACTED
+// array (64 aligned bytes of rdc, 16 aligned bytes of the LDS tile); in the source they start at any byte, which a 16-byte
+// load does not mind; thread t owns chunk t (and t + 256), requested one tile ahead.  The tile's values live in LDS as BYTES
+// (ds_write_b128, conflict-free) and the per-bin median phase works on them four to a register.  Tiles that touch the
+// chromosome's ends (clamped windows, App. A Q1; the tail quirks of the 20-slice write-back, Q2/Q3) or are cut by a removed
+// region take a per-element path that recomputes the rescale from the int32 array.
 // #GC in [lo, lo + 201) straight from the mask in HBM (per-element path only)
 __device__ inline int gc_count201(const uint64_t* __restrict__ gcbits, int64_t lo) {
   int c = 0;
@@ -1081,20 +1078,19 @@ struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t x, y, z, w; };   /
 
 template <int MAXC, int EPT, bool SW7>
 __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
-    const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
-    const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
-    int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, int32_t* __restrict__ rdc, int32_t* __restrict__ binmed,
+    const uint8_t* __restrict__ r8 /* rescaled, saturated bytes */, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
+    int64_t n, int64_t nwords, const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak,
+    const int64_t* __restrict__ cum, int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, int32_t* __restrict__ rdc,
+    int32_t* __restrict__ binmed,
     int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
     int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
-  __shared__ Gc4Tile gt;
-  __shared__ double s_table[kGcLevels];
-  __shared__ float s_ratio[kGcLevels];
+  __shared__ double s_table[kGcLevels];   // the per-element path's rescale
   __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
-  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(table[kGcLevels] / t); }
+  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
   if (nreg <= kRegInline) {
     for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
     for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
@@ -1142,18 +1138,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   // Chunks are aligned in the COMPACTED array (16 values = 64 aligned bytes of rdc, 16 aligned bytes of the LDS tile); in the
   // source they start at any byte, which a 16-byte load of the byte copy does not mind.
   uint4 regs[MAXC];
-  uint64_t gwa = 0, gwb = 0;
   auto request = [&](int64_t soff) {   // branch-free: chunks beyond the tile re-read chunk 0 (ignored later)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int kc = c * kThreads + (int)threadIdx.x;
-      const Bytes16 b = *reinterpret_cast<const Bytes16*>(d8 + soff + 16 * (kc < nchunks ? kc : 0));
+      const Bytes16 b = *reinterpret_cast<const Bytes16*>(r8 + soff + 16 * (kc < nchunks ? kc : 0));
       regs[c] = make_uint4(b.x, b.y, b.z, b.w);
-    }
-    if (threadIdx.x < 64) {
-      const int64_t w0 = (soff >> 6) - 4 + (int)threadIdx.x, w1 = w0 + 64;
-      gwa = gcbits[(w0 >= 0 && w0 < nwords) ? w0 : 0];
-      gwb = gcbits[((int)threadIdx.x < kGc4Words - 64 && w1 >= 0 && w1 < nwords) ? w1 : 0];
     }
   };
 
@@ -1161,66 +1151,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   int64_t tile = blockIdx.x;
   if (tile < ntiles) { geometry(tile, P0, P1, fast, soff); if (fast) request(soff); }
   for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();   // s_val and the GC tile are free (and s_hist zeroed on the first trip)
+    __syncthreads();   // s_val is free (and s_hist zeroed on the first trip)
     if (fast) {
-      if (threadIdx.x < 64) {   // wave 0 commits the tile's GC words with their popcount prefix
-        const int l = threadIdx.x;
-        const int64_t w0 = (soff >> 6) - 4 + l, w1 = w0 + 64;
-        const uint64_t a = (w0 >= 0 && w0 < nwords) ? gwa : 0;
-        const uint64_t b = (l < kGc4Words - 64 && w1 >= 0 && w1 < nwords) ? gwb : 0;
-        gt.word[l] = a;
-        uint32_t c = __popcll(a), incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (l >= d) incl += up; }
-        gt.pre[l] = incl - c;
-        const uint32_t total = __shfl(incl, 63);
-        if (l < kGc4Words - 64) gt.word[64 + l] = b;
-        uint32_t c2 = __popcll(b), incl2 = c2;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl2, d); if (l >= d) incl2 += up; }
-        if (l < kGc4Words - 64) gt.pre[64 + l] = total + incl2 - c2;
-        if (l == kGc4Words - 64 - 1) gt.pre[kGc4Words] = total + incl2;
-      }
-      __syncthreads();
-      const int64_t first_bit = ((soff >> 6) - 4) * 64;
-      const uint32_t rel0 = (uint32_t)(soff - 100 - first_bit);   // staged bit of the window start of the tile's first base
       const uint32_t p0mod = (uint32_t)(P0 % 31);
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
         const int kc = c * kThreads + (int)threadIdx.x;
         if (kc >= nchunks) continue;
         const uint32_t w4[4] = {regs[c].x, regs[c].y, regs[c].z, regs[c].w};
-        const bool esc = has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3]);
-        const uint32_t rel = rel0 + 16u * (uint32_t)kc;
-        const uint32_t g0 = g4_rank(gt, rel + 201) - g4_rank(gt, rel);
-        const uint32_t leave = g4_field16(gt, rel), enter = g4_field16(gt, rel + 201);
-        uint32_t g = g0;
-        bool redo = esc;
         int v[16];
-        if (!esc) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            v[j] = (int)rescale_f32((float)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu), s_ratio[g], redo);
-            g = g - ((leave >> j) & 1u) + ((enter >> j) & 1u);
-          }
-        }
-        if (redo) {   // rare: an escape byte (the chunk's values come from the int32 array) or a rescaled value too close to
-                      // an integer boundary for the ratio form: the reference's own expression for the chunk's sixteen bases
-          g = g0;
-          const int64_t i0 = soff + 16 * (int64_t)kc;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int4 x;
-            if (esc) { const Quad4 y = *reinterpret_cast<const Quad4*>(depth + i0 + 4 * q); x = make_int4(y.x, y.y, y.z, y.w); }
-            else x = make_int4((int)(w4[q] & 0xffu), (int)((w4[q] >> 8) & 0xffu), (int)((w4[q] >> 16) & 0xffu), (int)(w4[q] >> 24));
-            v[4 * q] = rescale(x.x, g); g = g - ((leave >> (4 * q)) & 1u) + ((enter >> (4 * q)) & 1u);
-            v[4 * q + 1] = rescale(x.y, g); g = g - ((leave >> (4 * q + 1)) & 1u) + ((enter >> (4 * q + 1)) & 1u);
-            v[4 * q + 2] = rescale(x.z, g); g = g - ((leave >> (4 * q + 2)) & 1u) + ((enter >> (4 * q + 2)) & 1u);
-            v[4 * q + 3] = rescale(x.w, g); g = g - ((leave >> (4 * q + 3)) & 1u) + ((enter >> (4 * q + 3)) & 1u);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = v[j] > capval ? capval : v[j];
+        for (int j = 0; j < 16; ++j) { const int x = (int)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu); v[j] = x > capval ? capval : x; }
         uint32_t pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
@@ -1433,11 +1374,11 @@ static int value_hist8_grid(int64_t n) {
 size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }
 void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                         uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
-                        const void* head_src, void* head_dst, size_t head_bytes, hipStream_t stream) {
+                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8, hipStream_t stream) {
   const int grid = value_hist8_grid(n);
   hipLaunchKernelGGL(k_value_hist8, dim3(grid), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, n / 64 + 1, table, hist, aux,
                      static_cast<unsigned int*>(slabs), static_cast<unsigned int*>(gsum), fold_per_group(grid), counters, vm, head_src, head_dst,
-                     (unsigned int)head_bytes);
+                     (unsigned int)head_bytes, rescaled8);
 }
 
 static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {
@@ -1454,7 +1395,7 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact) {
   return (size_t)grid * vr * kResClasses * 4;
 }
 // K4' applies when the cap keeps every value in a byte below the escape code and the bin fits the register median phase.
-int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteEscape && m <= 104 ? 1 : 0; }
+int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteSat && m <= 104 ? 1 : 0; }
 static void k48_geometry(int m, int32_t capval, int64_t ncompact, int& vr, int& grid, int& maxc) {
   vr = 64;
   while (vr < 256 && vr <= capval) vr <<= 1;

@@ -832,8 +832,9 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     if (P.gcadjust) {
       // K2 leaves a byte copy of the depth; K3' streams that copy (1 byte per base instead of 4) and writes nothing per base
       HIPCHK(ctx->depth8.ensure((size_t)n + 2048));
+      HIPCHK(ctx->rescaled8.ensure((size_t)n + 2048));
       { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, ctx->depth8.as<uint8_t>(), st); }
-      { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+      { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, ctx->rescaled8.as<uint8_t>(), st); }
     } else if (want_cap) {
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
       { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
@@ -961,7 +962,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     // K4': from the byte copy of the raw depth, rescaling on the way -- the rescaled int32 array is never written or read
     HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
     Timer t(ctx, "cap_compact_bin", true);
-    launch_cap_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+    launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                             ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                             ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
   } else {

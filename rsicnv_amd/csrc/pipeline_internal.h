@@ -151,7 +151,7 @@ struct rsi_ctx {
   size_t text_pin_cap = 0;
   int64_t n_in = 0;                          // length of the depth currently in in_depth
   DevBuf gcbits, nbits, rd_gc, rdc, binmed, binsum, tnb, tmed, first_del;
-  DevBuf depth8;              // byte copy of the depth (K2 writes it, K3' and K4' stream it)
+  DevBuf depth8, rescaled8;   // byte copies: the raw depth (K2 writes it, K3' streams it), the rescaled depth (K3' -> K4')
   DevBuf slabs;   // per-workgroup partial results of the streaming kernels
   DevBuf gsum;    // group sums of the in-kernel slab folds (device_util.h)
   DevBuf status1, status1f, status2, hist_val, hist_res, hist_f, small, thr, runs, run_se, scratch, items, best;
