@@ -94,23 +94,12 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  // four columns per thread and trip, eight members each: 32 loads in flight (one workgroup folds half a megabyte here, and
-  // every other workgroup of the launch has already gone home: this is latency, not bandwidth)
-  for (int e0 = threadIdx.x; e0 < width; e0 += 4 * blockDim.x) {
-    T s[4] = {0, 0, 0, 0};
-    const T* col = slabs + (size_t)g * per_group * width;
-    for (int k0 = 0; k0 < members; k0 += 8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = e0 + q * (int)blockDim.x;
-          if (k0 + k < members && e < width) s[q] += ld_cg(col + (size_t)(k0 + k) * width + e);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = e0 + q * (int)blockDim.x; if (e < width) st_cg(gsum + (size_t)g * width + e, s[q]); }
+  for (int e = threadIdx.x; e < width; e += blockDim.x) {
+    T s = 0;
+    const T* col = slabs + (size_t)g * per_group * width + e;
+#pragma unroll 8
+    for (int k = 0; k < members; ++k) s += ld_cg(col + (size_t)k * width);
+    st_cg(gsum + (size_t)g * width + e, s);
   }
   drain();
   __syncthreads();
@@ -122,20 +111,11 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  for (int e0 = threadIdx.x; e0 < width; e0 += 4 * blockDim.x) {
-    T s[4] = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < ngroups; k0 += 8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = e0 + q * (int)blockDim.x;
-          if (k0 + k < ngroups && e < width) s[q] += ld_cg(gsum + (size_t)(k0 + k) * width + e);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = e0 + q * (int)blockDim.x; if (e < width) total[e] = s[q]; }
+  for (int e = threadIdx.x; e < width; e += blockDim.x) {
+    T s = 0;
+#pragma unroll 8
+    for (int k = 0; k < ngroups; ++k) s += ld_cg(gsum + (size_t)k * width + e);
+    total[e] = s;
   }
   __syncthreads();
   return true;
