@@ -150,6 +150,8 @@ int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0);
 #define RSI_SUMMARY_CALL 8
 int rsi_result_summary(const rsi_result* r, int chrom_id, double* out, int max_calls);
 int rsi_summary_format_row(const double* block, int i, const char* chrom, char* buf, int cap);
+/* every stored call of the block, one row per line (each ended by '\n'); returns the bytes written, < 0 if buf is too small */
+int rsi_summary_format_rows(const double* block, const char* chrom, char* buf, int cap);
 /* The per-L lines rsistatus writes to the log (rsi.cpp:1221-1224 "DEL-", 1251-1254 "DUP+": L, bins marked so far, bins,
  * portion) for the four sweeps of the chromosome's (last) scan, first pass first: line i (0-based) into buf; returns i + 1,
  * or 0 when there is no such line. */

@@ -25,7 +25,7 @@ STATUS_NAMES = {0: "RSI_OK", -1: "RSI_ERR_NO_DEVICE", -2: "RSI_ERR_BAD_ARG", -3:
 
 # every symbol include/rsi_hot.h and include/rsi_synth.h declare
 EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_last_error", "rsi_hot_run",
-           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
+           "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_summary_format_rows", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
            "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
@@ -124,6 +124,8 @@ def load_library():
     L.rsi_result_summary.restype = C.c_int
     L.rsi_summary_format_row.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.rsi_summary_format_row.restype = C.c_int
+    L.rsi_summary_format_rows.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.rsi_summary_format_rows.restype = C.c_int
     L.rsi_result_log_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     L.rsi_result_log_line.restype = C.c_int
     L.rsi_result_format_row.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]

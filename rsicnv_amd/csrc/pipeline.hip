@@ -1442,6 +1442,22 @@ int rsi_summary_format_row(const double* block, int i, const char* chrom, char* 
                   block[1], block[2], -1, -1.0);
 }
 
+// All rows of a block at once, each ended by a newline; returns the number of bytes written (0: no calls), < 0 on error
+// (also when buf is too small).
+int rsi_summary_format_rows(const double* block, const char* chrom, char* buf, int cap) {
+  if (!block || !chrom || !buf || cap <= 0) return RSI_ERR_BAD_ARG;
+  const int stored = (int)block[4];
+  int used = 0;
+  for (int i = 0; i < stored; ++i) {
+    const int k = rsi_summary_format_row(block, i, chrom, buf + used, cap - used - 1);
+    if (k < 0 || k >= cap - used - 1) return RSI_ERR_BAD_ARG;
+    used += k;
+    buf[used++] = '\n';
+  }
+  buf[used < cap ? used : cap - 1] = 0;
+  return used;
+}
+
 int rsi_result_pairs(const rsi_result* r, int i, int32_t* rp, double* q0) {
   if (!r || i < 0 || i >= (int)r->lists[0].size()) return RSI_ERR_BAD_ARG;
   if (rp) *rp = (size_t)i < r->rp.size() ? r->rp[(size_t)i] : -1;

@@ -56,7 +56,8 @@ def unpack_blocks(blocks):
             k, stored = int(row[3]), int(row[4])
             if stored < k:
                 raise OverflowError(f"chromosome {cid}: summary block truncated ({stored} of {k} calls)")
-            calls = [tuple(int(x) for x in row[SUMMARY_HEAD + SUMMARY_CALL * j: SUMMARY_HEAD + SUMMARY_CALL * j + 4]) for j in range(k)]
+            table = row[SUMMARY_HEAD: SUMMARY_HEAD + SUMMARY_CALL * k].reshape(k, SUMMARY_CALL)
+            calls = [tuple(c) for c in table[:, :4].astype(np.int64).tolist()]
             out[cid] = dict(RDmedian=float(row[1]), RDsd=float(row[2]), ncalls=k, calls=calls, block=np.ascontiguousarray(row))
     return out
 
@@ -64,13 +65,15 @@ def unpack_blocks(blocks):
 def format_rows(lib, merged, names):
     """The output rows of a gathered genome in chromosome order (names[cid] = chromosome name):
     rsi_summary_format_row on every stored call -- the text the producing rank's rsi_result_format_row gives."""
-    rows, buf = [], C.create_string_buffer(1024)
+    rows, cap = [], 512 * MAX_CALLS
+    buf = C.create_string_buffer(cap)
     for cid in sorted(merged):
         blk = merged[cid]["block"]
-        for i in range(merged[cid]["ncalls"]):
-            if lib.rsi_summary_format_row(blk.ctypes.data, i, names[cid].encode(), buf, 1024) < 0:
-                raise RuntimeError("rsi_summary_format_row failed")
-            rows.append(buf.value.decode())
+        k = lib.rsi_summary_format_rows(blk.ctypes.data, names[cid].encode(), buf, cap)
+        if k < 0:
+            raise RuntimeError("rsi_summary_format_rows failed")
+        if k:
+            rows.extend(buf.raw[:k].decode().splitlines())
     return rows
 
 

@@ -47,7 +47,7 @@ def main():
             pools[key] = api.RsiPool(0, w)
             pools[key].set_timing(True)
         variants.append((name, pools[key], kv))
-    keys = sorted({k for _, _, kv in variants for k in kv})
+    keys = sorted({k for _, _, kv in variants for k in kv if k not in ("timing", "rows")})
     times = {name: [] for name, _, _ in variants}
     tables = {name: api.RsiBatchTimes() for name, _, _ in variants}
     calls = {}
@@ -64,13 +64,18 @@ def main():
     def run(name, pool, kv, timed):
         for k in keys:
             os.environ[k] = kv.get(k, "0")
-        pool.set_timing(kv.get("timing", "1") != "0")   # HIP events around every launch (what bench.py runs with)
+        pool.set_timing(int(kv.get("timing", "1")))   # 1: HIP events around every launch; 3: around the dominant kernel only (bench.py's timed steps)
         timed = timed and kv.get("timing", "1") != "0"
         pool.times = tables[name]
         torch.cuda.synchronize()
         th0 = throttled()
         t0 = time.perf_counter()
         res = pool.run(params, chrom_args, collect_times=timed)
+        if kv.get("rows", "0") != "0":   # rank 0's share of a bench.py step: blocks -> ordered rows
+            from rsicnv_amd import dist as rd
+            ids = list(range(len(res)))
+            merged = rd.unpack_blocks([rd.pack_results(ids, res, len(res))])
+            rd.format_rows(lib, merged, [f"chr{c + 1}" for c in ids])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         th1 = throttled()
