@@ -81,6 +81,20 @@ def _properties(hot, res, m, cap, plan):
     return rdc, missed
 
 
+def test_config1_60mb_against_reference_golden(hot, hotlib):
+    """configs[1]: the 60 Mb Poisson chromosome, -m 101 -NB (the reference's own CPU-runnable size)."""
+    from rsicnv_amd import api
+    g, plan, flags = _golden("cfg2_60mb")
+    plan = _plan(plan)
+    assert plan["n"] == 60_000_000
+    d_rd, d_fa = _device_case(hotlib, plan)
+    res = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
+    _check_against_golden(res, g, "60 Mb")
+    rdc, missed = _properties(hot, res, 101, 4.0, plan)
+    assert gu.sha(rdc) == str(g["rd_concat_sha"])
+    assert len(missed) <= 1, missed
+
+
 def test_config2_250mb_against_reference_golden(hot, hotlib):
     """configs[2]: the 250 Mb gamma-Poisson chromosome with GC adjustment, -m 101 -NB."""
     from rsicnv_amd import api

@@ -2,6 +2,7 @@
 """Full-size golden call tables from the REAL reference (oracle/_ref/libref.so) for the BASELINE.json configurations the
 GPU suite checks at their stated sizes (tests/test_full_size.py):
 
+  cfg2_60mb           configs[1]: the 60 Mb Poisson chromosome, -m 101 -NB
   cfg3_250mb          configs[2]: the 250 Mb gamma-Poisson chromosome, -m 101 -NB
   cfg4_chr19/21/22    configs[3]: three chromosomes (<= 60 Mb) of the 24-chromosome 3 Gb genome, -m 101 -NB
   cfg5_chr13          configs[4]: one 60x chromosome of 112 Mb, -m 51 -MED -cap 4
@@ -24,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CALL_KEYS = ("start", "end", "type", "geno", "status", "length", "qscore", "score", "p1", "cnvmed", "cnvsd", "cnviqr",
              "refmed", "refsd", "refiqr")
-CASES = {"cfg3_250mb": (3, 0), "cfg4_chr19": (4, 18), "cfg4_chr21": (4, 20), "cfg4_chr22": (4, 21), "cfg5_chr13": (5, 12)}
+CASES = {"cfg2_60mb": (2, 0), "cfg3_250mb": (3, 0), "cfg4_chr19": (4, 18), "cfg4_chr21": (4, 20), "cfg4_chr22": (4, 21), "cfg5_chr13": (5, 12)}
 
 
 def sha(a):
