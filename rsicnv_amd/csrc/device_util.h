@@ -77,6 +77,59 @@ __device__ inline bool last_block_done(unsigned int* counter) {
 // obvious alternative, serialise on the memory side and cost more than a whole streaming pass.
 constexpr int kFoldGroups = 32;   // upper bound on the number of groups
 inline int fold_per_group(int nblocks) { return (nblocks + kFoldGroups - 1) / kFoldGroups; }
+
+// Sixteen bytes from each of eight slabs with agent-scope coherence (the sc1 bit an agent-scope atomic load carries), all
+// eight in flight at once.  The slab bases are wave-uniform (scalar registers), the thread's offset is one VGPR.  An atomic
+// load is a dword, and sixteen of them per thread and slab, eight in flight, made the fold the longest part of K4's tail.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline unsigned long long uniform_address(const void* p) {   // the same in every lane: make the compiler keep it in scalar registers
+  const unsigned long long a = (unsigned long long)p;
+  return (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a) |
+         ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32)) << 32);
+}
+__device__ inline void ld_cg_x8(u32x4 (&v)[8], unsigned int voff, const unsigned long long (&b)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, %9 sc1\n\t"
+      "global_load_dwordx4 %1, %8, %10 sc1\n\t"
+      "global_load_dwordx4 %2, %8, %11 sc1\n\t"
+      "global_load_dwordx4 %3, %8, %12 sc1\n\t"
+      "global_load_dwordx4 %4, %8, %13 sc1\n\t"
+      "global_load_dwordx4 %5, %8, %14 sc1\n\t"
+      "global_load_dwordx4 %6, %8, %15 sc1\n\t"
+      "global_load_dwordx4 %7, %8, %16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(voff), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "s"(b[4]), "s"(b[5]), "s"(b[6]), "s"(b[7])
+      : "memory");
+}
+__device__ inline void fold_add(unsigned int (&s)[4], u32x4 v) { s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w; }
+__device__ inline void fold_add(unsigned long long (&s)[2], u32x4 v) {
+  s[0] += (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+  s[1] += (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+}
+// dst[e] = sum over k < members of src[k * stride + e], e < width; width a multiple of 16 / sizeof(T), src 16-byte aligned
+template <typename T, bool CG>
+__device__ inline void fold_columns(const T* src, size_t stride, int members, int width, T* dst) {
+  constexpr int kPer = 16 / (int)sizeof(T);
+  const int last = __builtin_amdgcn_readfirstlane(members - 1);
+  for (int q = threadIdx.x; q < width / kPer; q += blockDim.x) {
+    T s[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) s[j] = 0;
+    for (int k0 = 0; k0 <= last; k0 += 8) {
+      unsigned long long b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = uniform_address(src + (size_t)(k0 + j < last ? k0 + j : last) * stride);
+      u32x4 v[8];
+      ld_cg_x8(v, (unsigned int)q * 16u, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (k0 + j <= last) fold_add(s, v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { if (CG) st_cg(dst + q * kPer + j, s[j]); else dst[q * kPer + j] = s[j]; }
+  }
+}
+
 template <typename T>
 __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, int per_group, unsigned int* counters) {
   __shared__ unsigned int s_flag__;
@@ -94,13 +147,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  for (int e = threadIdx.x; e < width; e += blockDim.x) {
-    T s = 0;
-    const T* col = slabs + (size_t)g * per_group * width + e;
-#pragma unroll 8
-    for (int k = 0; k < members; ++k) s += ld_cg(col + (size_t)k * width);
-    st_cg(gsum + (size_t)g * width + e, s);
-  }
+  fold_columns<T, true>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, gsum + (size_t)g * width);
   drain();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -111,12 +158,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  for (int e = threadIdx.x; e < width; e += blockDim.x) {
-    T s = 0;
-#pragma unroll 8
-    for (int k = 0; k < ngroups; ++k) s += ld_cg(gsum + (size_t)k * width + e);
-    total[e] = s;
-  }
+  fold_columns<T, false>(gsum, (size_t)width, ngroups, width, total);
   __syncthreads();
   return true;
 }

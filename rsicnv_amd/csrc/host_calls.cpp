@@ -125,11 +125,11 @@ void DepthPager::prefetch(int64_t lo, int64_t hi) {
 namespace {
 
 struct VecView {   // bin-space arrays
-  const std::vector<int>* v;
-  int64_t size() const { return (int64_t)v->size(); }
-  int operator[](int64_t i) const { return (*v)[(size_t)i]; }
+  IntSpan v;
+  int64_t size() const { return v.n; }
+  int operator[](int64_t i) const { return v.p[i]; }
   void prefetch(int64_t, int64_t) const {}
-  const int* raw() const { return v->data(); }   // whole array
+  const int* raw() const { return v.p; }   // whole array
 };
 struct PagedView {
   DepthPager* p;
@@ -402,7 +402,7 @@ void marked_runs(const std::vector<int>& marks, std::vector<Candidate>& out) {
 }
 
 // ---- multisegments (rsi.cpp:368-410): nested level sets of a rejected segment ----
-void nested_levels(const Candidate& seg, const std::vector<int>& status, std::vector<Candidate>& out) {
+void nested_levels(const Candidate& seg, IntSpan status, std::vector<Candidate>& out) {
   out.clear();
   const int len = seg.end - seg.start + 1;
   int lo = status[seg.start], hi = status[seg.start];
@@ -599,7 +599,7 @@ int to_reference(const std::vector<Region>& noncode, int p) {
 }  // namespace
 
 // ---- areblockscnv (rsi.cpp:415-546) ----
-void test_block_segments(const CallerInput& in, const std::vector<int>& status, std::vector<Candidate>& segs) {
+void test_block_segments(const CallerInput& in, IntSpan status, std::vector<Candidate>& segs) {
   const VecView bins{in.binmedint};
   std::vector<Candidate> T = segs;
   for (int i = 0; i < (int)T.size(); ++i) test_candidate(in, bins, T, i);

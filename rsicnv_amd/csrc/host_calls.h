@@ -96,6 +96,17 @@ class NeighbourTester {
   virtual bool range_sums(const std::vector<std::pair<int, int>>& ranges, std::vector<int64_t>& sums) = 0;
 };
 
+// A bin-space int array the caller keeps alive (the pinned host copy of a device array, or a vector): read in place.
+struct IntSpan {
+  const int* p = nullptr;
+  int64_t n = 0;
+  IntSpan() {}
+  IntSpan(const int* p_, int64_t n_) : p(p_), n(n_) {}
+  IntSpan(const std::vector<int>& v) : p(v.data()), n((int64_t)v.size()) {}
+  int operator[](int64_t i) const { return p[i]; }
+  int64_t size() const { return n; }
+};
+
 struct CallerInput {
   rsi_params P;
   CallProfile* prof = nullptr;
@@ -103,11 +114,11 @@ struct CallerInput {
   double RDmedian, RDsd;
   int64_t ncompact;                 // rsi::end with rsi::start = 1
   const std::vector<Region>* noncode;
-  const std::vector<int>* binmedint;
+  IntSpan binmedint;
 };
 
 // areblockscnv on one scan's segments (rsi.cpp:415-546); segs are updated in place.
-void test_block_segments(const CallerInput& in, const std::vector<int>& status, std::vector<Candidate>& segs);
+void test_block_segments(const CallerInput& in, IntSpan status, std::vector<Candidate>& segs);
 
 // Everything detectcnv does after the block tests (rsi.cpp:1860-1931) plus sd_filters
 // (rsi.cpp:1753-1792).  `blocks` receives the sorted bin-space list, `raw` the calls before

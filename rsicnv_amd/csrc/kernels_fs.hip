@@ -26,10 +26,15 @@ constexpr int kPerThread = 8;
 constexpr int kChunk = kThreads * kPerThread;   // bins per chunk
 
 struct StepFn { long long a0, a1; };            // S -> S + (S even ? a0 : a1)
+// An increment of 2^24 units or more takes the sum out of its binade whatever it is exactly: increments saturate at 2^40, so
+// that no chain of compositions can overflow (the parity of a saturated increment is never used).
+constexpr long long kStepSat = 1ll << 40;
 __device__ inline StepFn fs_compose(StepFn f, StepFn g) {   // first f, then g
   StepFn h;
   h.a0 = f.a0 + ((f.a0 & 1) ? g.a1 : g.a0);                 // S even: S + f.a0 has the parity of f.a0
   h.a1 = f.a1 + (((1 + f.a1) & 1) ? g.a1 : g.a0);           // S odd
+  h.a0 = h.a0 < kStepSat ? h.a0 : kStepSat;
+  h.a1 = h.a1 < kStepSat ? h.a1 : kStepSat;
   return h;
 }
 // the step of adding x (a non-negative finite float) while the sum is in the binade with unit 2^ue
@@ -42,7 +47,7 @@ __device__ inline StepFn fs_step(float x, int ue) {
   const int sh = e - ue;
   StepFn f;
   if (m == 0) { f.a0 = f.a1 = 0; return f; }
-  if (sh >= 0) { const long long X = (long long)(m << (sh > 39 ? 39 : sh)); f.a0 = f.a1 = X; return f; }   // a multiple of the unit
+  if (sh >= 0) { const long long X = (long long)(m << (sh > 16 ? 16 : sh)); f.a0 = f.a1 = X; return f; }   // a multiple of the unit (2^24 units and more: out of the binade anyway)
   const int d = -sh;                                        // X = m >> d, r = low d bits
   if (d > 25) { f.a0 = f.a1 = 0; return f; }                // less than a quarter of the unit: rounds away (m < 2^24)
   const long long X = (long long)(m >> d);
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
 // out: [2 Lmax + 1] float sums then [2 Lmax + 1] int counts (index = level + Lmax); the workgroup that finishes last copies
 // them to mapped host memory.  A count of -1 at the unmarked level tells the host to do the sums itself (more marked bins
 // than the compact list holds, or a negative / non-finite value: the integer-step argument needs x >= 0).
-constexpr int kFnBatch = 1024;
+constexpr int kFnBatch = 768;
 __device__ inline bool fs_apply(float& s, int ue, StepFn f) {   // one step of a function valid for unit exponent ue; false: not applicable
   const uint32_t bits = __float_as_uint(s);
   const int ex = (int)((bits >> 23) & 0xff);
@@ -189,7 +194,9 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
   __shared__ ChunkFn s_fn[kFnBatch];
   __shared__ float s_x[kChunk];
   __shared__ StepFn s_ta[kThreads], s_tb[kThreads];
-  __shared__ int s_stop, s_ue;
+  __shared__ int s_stop, s_ue, s_t0, s_wcnt[kThreads / 64];
+  __shared__ unsigned int s_sbits;
+  __shared__ StepFn s_sc[2][kThreads];
   const int nlev = 2 * Lmax + 1;
   unsigned int* out_bits = reinterpret_cast<unsigned int*>(out);
   unsigned int* out_cnt = out_bits + nlev;
@@ -232,47 +239,85 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
         __syncthreads();
         c = s_stop;
         if (c >= bn) break;
-        // chunk b0 + c: its unmarked values into LDS (marked ones as -1), per-thread step functions for the sum's binade and
-        // the one above, lane 0 walks them
-        const int ue = s_ue;
+        // chunk b0 + c crosses a binade (or starts the sum): its unmarked values into LDS (marked ones as -1), per-thread
+        // step functions for the sum's binade and the one above.  Then, in rounds: an ordered parallel composition (scan) of
+        // the 256 functions from the first thread not yet consumed gives every thread the sum AFTER its bins as an integer; the
+        // results are monotone, so the first thread whose result leaves the binade is a count; lane 0 adds that thread's eight
+        // bins one by one in float (the crossing itself), and the next round continues behind it in the new binade.
+        int ue = s_ue;
         const int64_t i0 = (int64_t)(b0 + c) * kChunk + (int64_t)threadIdx.x * kPerThread;
-        StepFn fa = {0, 0}, fb = {0, 0};
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
           const int64_t i = i0 + k;
           const bool use = i < nb && status[i] == 0;
-          const float x = use ? T[i] : -1.0f;
-          s_x[threadIdx.x * kPerThread + k] = x;
-          if (use) { fa = fs_compose(fa, fs_step(x, ue)); fb = fs_compose(fb, fs_step(x, ue + 1)); }
+          s_x[threadIdx.x * kPerThread + k] = use ? T[i] : -1.0f;
         }
-        s_ta[threadIdx.x] = fa; s_tb[threadIdx.x] = fb;
+        bool staged = false;
+        if (threadIdx.x == 0) { s_sbits = __float_as_uint(s); s_t0 = 0; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-          // the same walk over the 256 per-thread functions, the sum as (unit exponent, integer); the eight bins of a thread whose
-          // function does not apply (the crossing itself, or a sum still below the normal range) are added one by one
-          int t = 0;
-          while (t < kThreads) {
-            const uint32_t bits = __float_as_uint(s);
-            const int ex = (int)((bits >> 23) & 0xff);
-            const int d = ex - 150 - ue;
-            if (ex != 0 && ex != 255 && (d == 0 || d == 1)) {
-              long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
-              const StepFn* fn = d == 0 ? s_ta : s_tb;
-              StepFn f = fn[t];
-              while (t < kThreads) {
-                const StepFn fnx = fn[t + 1 < kThreads ? t + 1 : t];
-                const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
-                if (S2 >= (1ll << 24)) break;
-                S = S2; f = fnx; ++t;
-              }
-              s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S & 0x7fffffu));
-              if (t >= kThreads) break;
-            }
+        while (true) {
+          if (threadIdx.x == 0) {   // a sum that is not a normal number yet (the start: zeros) takes bins one by one
+            float sv = __uint_as_float(s_sbits);
+            int t0 = s_t0;
+            while (t0 < kThreads) {
+              const int ex = (int)((__float_as_uint(sv) >> 23) & 0xff);
+              if (ex != 0 && ex != 255) break;
 #pragma unroll
-            for (int k = 0; k < kPerThread; ++k) { const float x = s_x[t * kPerThread + k]; s = x >= 0.0f ? s + x : s; }
-            ++t;
+              for (int k = 0; k < kPerThread; ++k) { const float x = s_x[t0 * kPerThread + k]; sv = x >= 0.0f ? sv + x : sv; }
+              ++t0;
+            }
+            s_sbits = __float_as_uint(sv); s_t0 = t0;
           }
+          __syncthreads();
+          const int t0 = s_t0;
+          if (t0 >= kThreads) break;
+          const uint32_t bits = s_sbits;
+          const int ex = (int)((bits >> 23) & 0xff);
+          if (!staged || (ex - 150 != ue && ex - 150 != ue + 1)) {   // (re)build the functions for the binade the sum is in now
+            ue = ex - 150;
+            StepFn fa = {0, 0}, fb = {0, 0};
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+              const float x = s_x[threadIdx.x * kPerThread + k];
+              if (x >= 0.0f) { fa = fs_compose(fa, fs_step(x, ue)); fb = fs_compose(fb, fs_step(x, ue + 1)); }
+            }
+            s_ta[threadIdx.x] = fa; s_tb[threadIdx.x] = fb;
+            staged = true;
+          }
+          const StepFn* fn = ex - 150 == ue ? s_ta : s_tb;
+          StepFn F = {0, 0};
+          if ((int)threadIdx.x >= t0) F = fn[threadIdx.x];   // own entry: no barrier needed before reading it
+          int cur = 0;
+          s_sc[0][threadIdx.x] = F;
+          __syncthreads();
+          for (int dd = 1; dd < kThreads; dd <<= 1) {
+            StepFn G = s_sc[cur][threadIdx.x];
+            if ((int)threadIdx.x >= dd) G = fs_compose(s_sc[cur][threadIdx.x - dd], G);
+            s_sc[cur ^ 1][threadIdx.x] = G;
+            cur ^= 1;
+            __syncthreads();
+          }
+          F = s_sc[cur][threadIdx.x];
+          const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+          const long long St = S + ((S & 1) ? F.a1 : F.a0);
+          const bool ok = St < (1ll << 24);
+          const unsigned long long okm = __ballot(ok);
+          if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = __popcll(okm);
+          __syncthreads();
+          int tfail = 0;
+          for (int w = 0; w < kThreads / 64; ++w) tfail += s_wcnt[w];
+          if ((int)threadIdx.x == tfail - 1) s_sbits = ((uint32_t)ex << 23) | ((uint32_t)St & 0x7fffffu);   // threads below t0 carry S itself
+          __syncthreads();
+          if (tfail >= kThreads) break;
+          if (threadIdx.x == 0) {
+            float sv = __uint_as_float(s_sbits);
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) { const float x = s_x[tfail * kPerThread + k]; sv = x >= 0.0f ? sv + x : sv; }
+            s_sbits = __float_as_uint(sv); s_t0 = tfail + 1;
+          }
+          __syncthreads();
         }
+        if (threadIdx.x == 0) s = __uint_as_float(s_sbits);
         ++c;
         __syncthreads();
       }

@@ -18,7 +18,7 @@ struct ScanPassOut { uint32_t escapes, inexact, ldel, ldup; };   // what one rsi
 struct ScanOut {
   double tmedian1 = 0, tsigma1 = 0, tlamda1 = 0, tmedian2 = 0, tsigma2 = 0, tlamda2 = 0;
   int Lmax = 0;
-  std::vector<int> status2;
+  rsih::IntSpan status2;            // the context's pinned host copy, valid until the context's next scan
   std::vector<Candidate> segs;
   uint32_t escapes = 0, inexact = 0;
   // per-L counts of newly marked bins of the four sweeps (pass 1 DEL, DUP, pass 2 DEL, DUP) and the L each stopped at:
@@ -285,8 +285,10 @@ class DeviceTester : public rsih::NeighbourTester {
     // chromosome gets its tests back 40 % sooner from the second; in a pool the first is better (35.3 against 38.1 ms per
     // genome): a few long-lived workgroups cost the per-base kernels of the other chromosomes next to nothing, hundreds of
     // full ones take their CUs.  RSI_HOT_CAND_SPLIT=0 / 1 overrides.
-    static const int split_env = getenv("RSI_HOT_CAND_SPLIT") ? atoi(getenv("RSI_HOT_CAND_SPLIT")) : -1;
-    const bool split = split_env >= 0 ? split_env != 0 : ctx->gate == nullptr;
+    // several workgroups per test when the chip has room for them: a stand-alone context, or a pool run over a few
+    // chromosomes only (a rank's share of a sharded genome); one workgroup per test when a dozen chromosomes share the chip
+    const char* split_env = getenv("RSI_HOT_CAND_SPLIT");
+    const bool split = split_env ? atoi(split_env) != 0 : (ctx->gate == nullptr || ctx->gate->few_chromosomes);
     size_t first = 0;
     while (first < n) {
       std::vector<CandJob> jobs;
@@ -651,7 +653,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[3].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
   out.stop_levels[2] = wslot[2]; out.stop_levels[3] = wslot[3];
-  out.status2.assign(ctx->h_status2.as<int>(), ctx->h_status2.as<int>() + nb);
+  out.status2 = rsih::IntSpan(ctx->h_status2.as<int>(), nb);
   out.segs.clear();
   if (runs.empty()) return RSI_OK;
   std::vector<int64_t> poff(runs.size() + 1, 0);
@@ -714,7 +716,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     double sc = per_run[r].score;
     if (sc > 0) { c.start = runs[r].start + per_run[r].start; c.end = c.start + per_run[r].len - 1; }
     else { c.start = runs[r].start; c.end = runs[r].start + len - 1; sc = 0; }
-    const rsih::Quantiles q = rsih::grid_quantiles(out.status2.data() + c.start, (size_t)(c.end - c.start + 1));
+    const rsih::Quantiles q = rsih::grid_quantiles(out.status2.p + c.start, (size_t)(c.end - c.start + 1));
     if (q.med > 0) { c.type = rsih::kDup; c.score = sc; } else { c.type = rsih::kDel; c.score = -sc; }
     if (fabs(c.score) < tlamda * 0.5) continue;   // rsi.cpp:1343-1346
     out.segs.push_back(c);
@@ -1074,8 +1076,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     HIPCHK(ctx->h_medint.ensure((size_t)nb * 4));
     HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));   // complete at the scan's first wait
-    std::vector<int> medint;
-    in.binmedint = &medint;
+    in.binmedint = rsih::IntSpan(ctx->h_medint.as<int>(), nb);   // read in place, after the scan's first wait
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
       ScanOut so;
@@ -1102,7 +1103,6 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
         { const uint32_t bb = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; memcpy(&tminf, &bb, 4); }
         S.nb_tmin = tminf;
       }
-      if (medint.empty()) medint.assign(ctx->h_medint.as<int>(), ctx->h_medint.as<int>() + nb);
       ctx->last_scan_med = use_med;
       S.tmedian1 = so.tmedian1; S.tsigma1 = so.tsigma1; S.tlamda1 = so.tlamda1;
       S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;

@@ -97,6 +97,7 @@ struct GpuGate {
   std::mutex m;
   std::condition_variable cv;
   int sharers = 0, streamers_waiting = 0, streaming = 0;
+  bool few_chromosomes = false;   // set per rsi_pool_run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
   int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
   void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
   void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }

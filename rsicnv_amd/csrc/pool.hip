@@ -12,6 +12,8 @@ extern "C" {
 // Pool: `nworkers` host threads, each with its own context (stream + workspace) on one GPU.
 // Chromosomes are independent iterations of the reference's loop (rsi.cpp:2189-2217); the pool
 // hands them out longest first.
+constexpr int kFewChromosomes = 4;   // up to here a run's candidate tests use the multi-workgroup form
+
 struct rsi_pool {
   int device = 0;
   std::vector<rsi_ctx*> workers;
@@ -76,6 +78,7 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
     for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
+  pool->gate.few_chromosomes = nchrom <= kFewChromosomes;
   std::atomic<int> next(std::min<int>(nchrom, (int)pool->workers.size()));
   std::vector<int> rcs((size_t)nchrom, RSI_OK);
   std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());

@@ -114,7 +114,7 @@ static void candidate_stage_case(uint64_t seed, int n, int model, const orc_para
   for (size_t i = 0; i + 1 < noncode.size(); i += 2) regions.push_back({noncode[i], noncode[i + 1]});
   in.noncode = &regions;
   std::vector<int> mi(medint.begin(), medint.end()), status(st2.begin(), st2.end());
-  in.binmedint = &mi;
+  in.binmedint = rsih::IntSpan(mi);
   std::vector<rsih::Candidate> segs;
   for (const orc_call& c : segs_o) { rsih::Candidate k; k.start = c.start; k.end = c.end; k.type = c.type; k.score = c.score; segs.push_back(k); }
   rsih::test_block_segments(in, status, segs);                        // areblockscnv, rsi.cpp:1847
