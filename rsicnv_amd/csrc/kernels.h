@@ -79,7 +79,11 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
 size_t value_hist8_slab_bytes(int64_t n);
 void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                         uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
-                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8 /* n + 2048 bytes */, hipStream_t stream);
+                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8 /* n + 2048 bytes */,
+                        const unsigned int* escapes /* K2's count of bases that did not fit a byte (GcAccum::escapes) */, hipStream_t stream);
+// Above this many escaped bases (n / 8) the byte path is not worth taking: K3' only hands the header over and the host
+// runs the int32 kernels (deep coverage, 250x and more).
+unsigned int byte_escape_limit(int64_t n);
 
 // ---- K4: cap + N-region compaction + per-bin median/sum + chromosome statistics ----
 // (apply_cap loaddata.cpp:229; concatenate_data loaddata.cpp:48; _median/variance rsi.cpp:2202;
@@ -100,12 +104,18 @@ struct BinAccum {
 // entries travel in `inl` with the kernel arguments (cbreak / cum may then be NULL).
 constexpr int kRegInline = 48;
 struct K4Regions { long long brk[kRegInline]; long long cum[kRegInline + 1]; };
-size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact);
-int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact);
+size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact, int vbase);
+int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact, int vbase);
+// First value of the window the LDS histograms of the int32 kernels cover: 0 unless the distribution's centre (mean / median
+// depth) is 160 and more, then centre - 3/8 width; values outside the window are counted with global atomics, slowly but
+// exactly.  K3 derives its window on the device (1024 values); K4's (kK4Window = 512 values) comes from the host.
+constexpr int kK4Window = 512;
+int hist_window_base(double center, int width);
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
                             uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
-                            const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
+                            const void* exp_src, void* exp_dst, size_t exp_bytes, int vbase /* hist_window_base(cap median), or 0 */,
+                            hipStream_t stream);
 
 // K4 fed from K3''s byte copy of the rescaled depth (rescaled8): the rescaled int32 array is never needed.  Applies when
 // cap_compact8_applies(): 1 <= capval < kByteSat (every capped value fits a byte, res_hist is overwritten) and m <= 104.

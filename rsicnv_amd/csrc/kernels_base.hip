@@ -19,6 +19,7 @@ constexpr int kGcWords = kTileBases / 64;  // 64 words per tile
 constexpr int kGcLeft = 4;                 // margin words left of the tile (256 bits >= 201)
 constexpr int kGcRight = 2;                // margin words right of the tile (128 bits >= 101)
 constexpr int kGcLds = kGcLeft + kGcWords + kGcRight;   // 70
+
 constexpr int kValLds = 256;               // K3 / K3': values below this are counted in LDS, [value][32 lane phases]
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
@@ -539,10 +540,21 @@ __device__ inline void value_median_block(const uint32_t* __restrict__ hist, uns
 }
 
 
+// The LDS value histogram of K3 holds 8192 counters: [256 values][32 lane phases] from 0 for ordinary coverage; for a mean
+// depth of 160 and more [1024 values][8 lane phases] from mean - 384 (hist_window_base below): deep distributions are wide,
+// so lanes seldom meet on one value, and every value outside the window is a global atomic on one of a few hundred words --
+// with 4 % of the bases outside, that alone took 60 times the streaming pass.  Every workgroup derives the same window
+// from the GC table's mean depth.
+constexpr int kDeepWidth = 1024, kDeepPhaseShift = 3;
+__device__ inline int hist_window_base_dev(double center, int width) {
+  if (!(center >= 160.0)) return 0;
+  const double b = center - (double)(3 * width / 8);
+  return b > (double)(kHistValues - width) ? kHistValues - width : (b < 0.0 ? 0 : (int)b);
+}
 // rare path (values outside the LDS range): kept out of line so the unrolled callers stay small
 __device__ __attribute__((noinline)) void value_hist_add(unsigned int* s_hist, uint32_t* __restrict__ ghist, ValueHistAux* aux, int v,
-                                      int phase) {
-  if (v >= 0 && v < kValLds) atomicAdd(&s_hist[v * 32 + phase], 1u);
+                                      int phase, int vb = 0 /* first value of the LDS window */, int width = kValLds, int phsh = 5) {
+  if (v >= vb && v - vb < width) atomicAdd(&s_hist[((v - vb) << phsh) + phase], 1u);
   else if (v >= 0 && v < kHistValues) atomicAdd(&ghist[v], 1u);   // the caller keeps the largest such value (lane register -> ValueHistAux::vmax)
   else if (v < 0) atomicOr(&aux->negatives, 1u);
   else atomicAdd(&aux->big, 1ull);
@@ -566,22 +578,34 @@ __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __
                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
                                          unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum, int per_group,
                                          unsigned int* __restrict__ counters, ValueMedian* __restrict__ vm, const void* head_src,
-                                         void* head_dst, unsigned int head_bytes) {
-  for (int v = threadIdx.x; v < kValLds; v += kThreads) {
+                                         void* head_dst, unsigned int head_bytes, int vb = 0 /* first value of the LDS window */,
+                                         int width = kValLds, int phsh = 5) {
+  const int phases = 1 << phsh;
+  unsigned int mine[kDeepWidth / kThreads];   // all reads of the [value][phase] counters come before the first write of a total
+#pragma unroll
+  for (int k = 0; k < kDeepWidth / kThreads; ++k) {
+    const int v = k * kThreads + (int)threadIdx.x;
     unsigned int c = 0;
-    for (int p = 0; p < 32; ++p) c += s_hist[v * 32 + ((p + v) & 31)];
-    st_cg(&hist_slabs[(size_t)blockIdx.x * kValLds + v], c);
+    if (v < width) for (int p = 0; p < phases; ++p) c += s_hist[(v << phsh) + ((p + v) & (phases - 1))];
+    mine[k] = c;
+  }
+#pragma unroll
+  for (int k = 0; k < kDeepWidth / kThreads; ++k) {
+    const int v = k * kThreads + (int)threadIdx.x;
+    if (v < width) st_cg(&hist_slabs[(size_t)blockIdx.x * width + v], mine[k]);
   }
   unsigned int* total = s_hist;
-  if (!fold_slabs(hist_slabs, gsum, total, kValLds, per_group, counters)) return;
-  for (int v = threadIdx.x; v < kValLds; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[v], c); }
+  if (!fold_slabs(hist_slabs, gsum, total, width, per_group, counters)) return;
+  for (int v = threadIdx.x; v < width; v += kThreads) { const unsigned int c = total[v]; if (c) atomicAdd(&ghist[vb + v], c); }
   sync_drained();
-  if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, out, ghist, aux);
+  // histogram side of the tail quirks only: out[]'s tail cells were stored by other workgroups of this launch, and a second
+  // store from here would race with them (no defined order between XCDs); the launcher rewrites them in a launch of their own
+  if (threadIdx.x < 64 && (ADJUST || (n & 3) != 0)) gc_tail_fixup(depth, gcbits, n, table, ADJUST ? 1 : 0, nullptr, ghist, aux);
   sync_drained();
   {
     const unsigned int hi = ld_cg(&aux->vmax);                       // largest value counted outside the LDS range (0: none)
     int range = hi >= (unsigned int)kHistValues ? kHistValues : (int)hi + 1;
-    range = range < kValLds ? kValLds : range;
+    range = range < vb + width ? vb + width : range;
     range = (range + kThreads - 1) / kThreads * kThreads;
     value_median_block<kThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
   }
@@ -608,7 +632,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
   if (ADJUST) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_table[e] = table[e];
   const double rdmean = ADJUST ? table[kGcLevels] : 0.0;
-  const int phase = threadIdx.x & 31;
+  const bool deep = ADJUST && rdmean >= 160.0;                // deep coverage: the LDS histogram follows the distribution
+  const int width = deep ? kDeepWidth : kValLds, phsh = deep ? kDeepPhaseShift : 5;
+  const int vb = deep ? hist_window_base_dev(rdmean, width) : 0;
+  const int phase = threadIdx.x & ((1 << phsh) - 1);
   int lane_hi = 0;   // largest value this lane sent past the LDS range
   const int64_t ntiles = (n + kTileBases - 1) / kTileBases;
   auto trip = [&](const TileRegs& cur, const GcRegs& gcur, TileRegs& nxt, GcRegs& gnxt, int64_t tile) {
@@ -641,12 +668,12 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
       const int v2 = one(cur.q[k].z, (g4 >> 16) & 0xffu);
       const int v3 = one(cur.q[k].w, g4 >> 24);
       if (materialize) {
-      } else if (((unsigned)v0 | (unsigned)v1 | (unsigned)v2 | (unsigned)v3) < (unsigned)kValLds) {   // the common case, branch-free
-        atomicAdd(&s_hist[v0 * 32 + phase], 1u); atomicAdd(&s_hist[v1 * 32 + phase], 1u);
-        atomicAdd(&s_hist[v2 * 32 + phase], 1u); atomicAdd(&s_hist[v3 * 32 + phase], 1u);
+      } else if (((unsigned)(v0 - vb) | (unsigned)(v1 - vb) | (unsigned)(v2 - vb) | (unsigned)(v3 - vb)) < (unsigned)width) {   // the common case, branch-free
+        atomicAdd(&s_hist[((v0 - vb) << phsh) + phase], 1u); atomicAdd(&s_hist[((v1 - vb) << phsh) + phase], 1u);
+        atomicAdd(&s_hist[((v2 - vb) << phsh) + phase], 1u); atomicAdd(&s_hist[((v3 - vb) << phsh) + phase], 1u);
       } else {
-        value_hist_add(s_hist, ghist, aux, v0, phase); value_hist_add(s_hist, ghist, aux, v1, phase);
-        value_hist_add(s_hist, ghist, aux, v2, phase); value_hist_add(s_hist, ghist, aux, v3, phase);
+        value_hist_add(s_hist, ghist, aux, v0, phase, vb, width, phsh); value_hist_add(s_hist, ghist, aux, v1, phase, vb, width, phsh);
+        value_hist_add(s_hist, ghist, aux, v2, phase, vb, width, phsh); value_hist_add(s_hist, ghist, aux, v3, phase, vb, width, phsh);
         const int h01 = v0 > v1 ? v0 : v1, h23 = v2 > v3 ? v2 : v3, h = h01 > h23 ? h01 : h23;
         lane_hi = h > lane_hi ? h : lane_hi;
       }
@@ -670,7 +697,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   __syncthreads();
   if (materialize) return;   // the tail quirks are applied to out[] by a launch of their own (k_gc_tail_fixup_out)
   publish_hist_hi(lane_hi, aux);
-  value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
+  value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, vb, width, phsh);
 }
 
 // The GC rescale without a division -- or any double arithmetic -- per base (f64 runs at half rate on gfx950, its
@@ -711,11 +738,18 @@ __global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restr
                                                           ValueHistAux* __restrict__ aux, unsigned int* __restrict__ hist_slabs,
                                                           unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters,
                                                           ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
-                                                          unsigned int head_bytes, uint8_t* __restrict__ out8) {
+                                                          unsigned int head_bytes, uint8_t* __restrict__ out8,
+                                                          const unsigned int* __restrict__ escapes, unsigned int escape_limit) {
   __shared__ WaveGc s_gc[kThreads / 64];
   __shared__ double s_table[kGcLevels];
   __shared__ float s_ratio[kGcLevels];
   __shared__ unsigned int s_hist[kValLds * 32];
+  // Deep coverage: most bases did not fit K2's byte copy.  Nothing to do here but hand the header (with that count) to the
+  // host, which sends the chromosome through the int32 kernels instead (per_base_phase).
+  if (escapes[0] > escape_limit) {
+    if (blockIdx.x == 0) export_words(head_dst, head_src, head_bytes);
+    return;
+  }
   const double rdmean = table[kGcLevels];
   for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
   for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(rdmean / t); }
@@ -849,8 +883,8 @@ struct RegionTable {
 };
 
 // rare path (values outside the LDS range, partial quads): kept out of line
-__device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int x, int cls) {
-  if (x >= 0 && x < vr) atomicAdd(&s_hist[x * kResClasses + cls], 1u);
+__device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int vb, int x, int cls) {
+  if (x >= vb && x - vb < vr) atomicAdd(&s_hist[(x - vb) * kResClasses + cls], 1u);
   else if (x >= 0 && x < kHistValues) atomicAdd(&res_hist[(size_t)x * kResClasses + cls], 1u);
   else { atomicAdd(&acc->big, 1ull); atomicMax(&acc->vmax, (unsigned int)x); }
 }
@@ -861,7 +895,7 @@ template <int MAXV, int EPT>
 __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_bin(
     const int32_t* __restrict__ src, int64_t n, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum,
     int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr /* LDS histogram value range, power of two */,
-    int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
+    int vb /* first value of the LDS histogram's window: 0 unless the coverage is deep (k4_window_base) */, int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
     uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc, unsigned int* __restrict__ hist_slabs,
     unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters, int overwrite,
     const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
@@ -936,13 +970,14 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
         else { rdc[P0 + e0] = d.x; if (e0 + 1 < cnt) rdc[P0 + e0 + 1] = d.y; if (e0 + 2 < cnt) rdc[P0 + e0 + 2] = d.z; }
         uint32_t c0 = (p0mod + (uint32_t)e0) % 31u;            // (P0 + e0) mod 31
         const uint32_t c1 = c0 == 30u ? 0u : c0 + 1u, c2 = c1 == 30u ? 0u : c1 + 1u, c3 = c2 == 30u ? 0u : c2 + 1u;
-        if (whole && P0 + e0 + 3 < lim31 && ((unsigned)d.x | (unsigned)d.y | (unsigned)d.z | (unsigned)d.w) < (unsigned)vr) {
+        const int wx = d.x - vb, wy = d.y - vb, wz = d.z - vb, ww = d.w - vb;   // positions in the histogram's window
+        if (whole && P0 + e0 + 3 < lim31 && ((unsigned)wx | (unsigned)wy | (unsigned)wz | (unsigned)ww) < (unsigned)vr) {
           // the common case, branch-free: four LDS atomics into [value][residue class]
-          atomicAdd(&s_hist[d.x * kResClasses + c0], 1u); atomicAdd(&s_hist[d.y * kResClasses + c1], 1u);
-          atomicAdd(&s_hist[d.z * kResClasses + c2], 1u); atomicAdd(&s_hist[d.w * kResClasses + c3], 1u);
+          atomicAdd(&s_hist[wx * kResClasses + c0], 1u); atomicAdd(&s_hist[wy * kResClasses + c1], 1u);
+          atomicAdd(&s_hist[wz * kResClasses + c2], 1u); atomicAdd(&s_hist[ww * kResClasses + c3], 1u);
         } else {
           auto count = [&](int x, int e, uint32_t cls) {
-            if (e < cnt) hist_value(s_hist, res_hist, acc, vr, x, (P0 + e) < lim31 ? (int)cls : 31);
+            if (e < cnt) hist_value(s_hist, res_hist, acc, vr, vb, x, (P0 + e) < lim31 ? (int)cls : 31);
           };
           count(d.x, e0, c0); count(d.y, e0 + 1, c1); count(d.z, e0 + 2, c2); count(d.w, e0 + 3, c3);
         }
@@ -963,7 +998,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
             s_val[dst + e] = x;
             rdc[seg + e] = x;
             const int64_t p = seg + e;
-            hist_value(s_hist, res_hist, acc, vr, x, p < lim31 ? (int)((uint32_t)p % 31u) : 31);
+            hist_value(s_hist, res_hist, acc, vr, vb, x, p < lim31 ? (int)((uint32_t)p % 31u) : 31);
           }
         }
         seg = nxt;
@@ -1037,7 +1072,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
     const unsigned int c = s_hist[e];
-    if (overwrite) st_cg(&res_hist[e], c); else if (c) atomicAdd(&res_hist[e], c);
+    if (overwrite) st_cg(&res_hist[e], c); else if (c) atomicAdd(&res_hist[(size_t)vb * kResClasses + e], c);
   }
   sync_drained();
   export_words(exp_dst, exp_src, exp_bytes);
@@ -1325,7 +1360,7 @@ static int gc_hist_grid(int64_t n) {
   return (int)(grid < 1 ? 1 : grid);
 }
 size_t gc_hist_slab_bytes(int64_t n) { return (size_t)gc_hist_grid(n) * kGcSlab * 8; }
-size_t fold_scratch_bytes() { return (size_t)kFoldGroups * 256 * kResClasses * 4; }   // the widest slab (K4 at vr = 256)
+size_t fold_scratch_bytes() { return (size_t)kFoldGroups * kK4Window * kResClasses * 4; }   // the widest slab (K4 at vr = 512)
 void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, int packed, void* slabs,
                     void* gsum, unsigned int* counters, uint8_t* depth8, hipStream_t stream) {
   const int grid = gc_hist_grid(n);
@@ -1335,8 +1370,10 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
   if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
   else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
 }
-size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kValLds * 4; }
+size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kDeepWidth * 4; }   // the wider of K3's two windows
 
+__global__ void k_gc_tail_fixup_out(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                                    const double* __restrict__ table, int32_t* __restrict__ out);
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
@@ -1346,11 +1383,12 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
-  // adjust = 1 is not issued by the pipeline any more (K3' builds the histogram from the byte copy, launch_gc_materialize the
-  // array): in one launch the tail cells of out[] would be stored twice, by the streaming loop and by the last workgroup,
-  // from different XCDs -- no defined order.  Kept for the -NOGC histogram (adjust = 0, out = NULL).
-  if (adjust) hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
-  else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+  // adjust = 1 (rescaled array + histogram in one pass) is the deep-coverage path; adjust = 0, out = NULL the -NOGC histogram.
+  // The tail cells of out[] get their quirks from a launch of their own (see k_gc_tail_fixup_out).
+  if (adjust) {
+    hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+    if (out) hipLaunchKernelGGL(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
+  } else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
 }
 // The tail quirks in out[] as a launch of its own: the cells it rewrites were written by other workgroups of the streaming
 // launch, and two stores to one address from different XCDs within one launch have no defined order.
@@ -1374,24 +1412,26 @@ static int value_hist8_grid(int64_t n) {
 size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }
 void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                         uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
-                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8, hipStream_t stream) {
+                        const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8, const unsigned int* escapes,
+                        hipStream_t stream) {
   const int grid = value_hist8_grid(n);
   hipLaunchKernelGGL(k_value_hist8, dim3(grid), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, n / 64 + 1, table, hist, aux,
                      static_cast<unsigned int*>(slabs), static_cast<unsigned int*>(gsum), fold_per_group(grid), counters, vm, head_src, head_dst,
-                     (unsigned int)head_bytes, rescaled8);
+                     (unsigned int)head_bytes, rescaled8, escapes, byte_escape_limit(n));
 }
 
-static void k4_geometry(int m, int32_t capval, int64_t ncompact, int& TB, int& vr, int& grid) {
+static void k4_geometry(int m, int32_t capval, int64_t ncompact, int vbase, int& TB, int& vr, int& grid) {
   TB = 64;   // bins per tile: as many as fit ~48 KB of values, 4..64, power of two
   while (TB > 4 && (size_t)TB * m * 4 > 48 * 1024) TB >>= 1;
   vr = 64;   // LDS histogram range: covers the capped values when the cap is active, 64..256
   while (vr < 256 && vr <= capval) vr <<= 1;
+  if (vbase > 0) vr = kK4Window;   // deep coverage: a window of 512 values around the median (64 KB of LDS, one workgroup per CU)
   const int64_t ntiles = (ncompact + (int64_t)TB * m - 1) / ((int64_t)TB * m);
   grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
 }
-size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact) {
+size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact, int vbase) {
   int TB, vr, grid;
-  k4_geometry(m, capval, ncompact, TB, vr, grid);
+  k4_geometry(m, capval, ncompact, vbase, TB, vr, grid);
   return (size_t)grid * vr * kResClasses * 4;
 }
 // K4' applies when the cap keeps every value in a byte below the escape code and the bin fits the register median phase.
@@ -1433,17 +1473,23 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
   else RSI_K48(2, 26, false);
 #undef RSI_K48
 }
-int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact) {
+unsigned int byte_escape_limit(int64_t n) { return (unsigned int)(n >> 3 > 0xffffffffll ? 0xffffffffll : n >> 3); }
+int hist_window_base(double center, int width) {   // [base, base + width) around the centre of the distribution; 0 up to ~160x
+  if (!(center >= 160.0)) return 0;
+  const double b = center - (double)(3 * width / 8);
+  return b > (double)(kHistValues - width) ? kHistValues - width : (b < 0.0 ? 0 : (int)b);
+}
+int cap_compact_overwrites(int m, int32_t capval, int64_t ncompact, int vbase) {
   int TB, vr, grid;
-  k4_geometry(m, capval, ncompact, TB, vr, grid);
-  return capval < vr ? 1 : 0;
+  k4_geometry(m, capval, ncompact, vbase, TB, vr, grid);
+  return vbase == 0 && capval < vr ? 1 : 0;
 }
 void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg,
                             int64_t ncompact, int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum,
                             uint32_t* res_hist, BinAccum* acc, void* slabs, void* gsum, unsigned int* counters,
-                            const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
+                            const void* exp_src, void* exp_dst, size_t exp_bytes, int vbase, hipStream_t stream) {
   int TB, vr, grid;
-  k4_geometry(m, capval, ncompact, TB, vr, grid);
+  k4_geometry(m, capval, ncompact, vbase, TB, vr, grid);
   const size_t tile_pad = ((size_t)TB * m + 3) & ~(size_t)3;
   const size_t lds = tile_pad * 4 + (size_t)vr * kResClasses * 4;
   const int quads = (int)(tile_pad / 4);
@@ -1452,10 +1498,10 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
-  const int overwrite = capval < vr ? 1 : 0;
+  const int overwrite = vbase == 0 && capval < vr ? 1 : 0;
 #define RSI_K4(MV, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin<MV, EP>));                                                            \
     hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
-                       ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, acc, sl, gs, pg, counters, overwrite,              \
+                       ncompact, capval, m, TB, vr, vbase, rdc, binmed, binsum, res_hist, acc, sl, gs, pg, counters, overwrite,              \
                        exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
   else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)

@@ -836,7 +836,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       HIPCHK(ctx->depth8.ensure((size_t)n + 2048));
       HIPCHK(ctx->rescaled8.ensure((size_t)n + 2048));
       { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, ctx->depth8.as<uint8_t>(), st); }
-      { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, ctx->rescaled8.as<uint8_t>(), st); }
+      { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, ctx->rescaled8.as<uint8_t>(), &d_acc->escapes, st); }
     } else if (want_cap) {
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
       { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
@@ -869,6 +869,21 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     if ((rc = issue_gc_chain(0)) != RSI_OK) return rc;
     HIPCHK(CTX_SYNC());
     unpack_head();
+  }
+
+  // Deep coverage: more than an eighth of the bases did not fit K2's byte copy, and K3' only handed the header over.  The
+  // rescale, the value histogram and the cap median come from the int32 kernel instead (its LDS histogram follows the mean
+  // depth, kernels.h: hist_window_base), which also leaves the rescaled int32 array for K4.
+  bool deep = false;
+  if (P.gcadjust && (uint64_t)acc.escapes > (uint64_t)byte_escape_limit(n)) {
+    Phase ph_d(ctx, "a2-3.deep coverage");
+    deep = true;
+    HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
+    HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
+    { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+    HIPCHK(CTX_SYNC());
+    unpack_head();
+    ctx->rd_gc_valid = true;
   }
 
   // ---- N runs -> padded, merged regions (get_noseq_regions, loaddata.cpp:243-273) ----
@@ -960,7 +975,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // of 256 and more) stray values reach res_hist through global atomics and it is cleared first.
   const size_t exp_bytes = kResHead + res_vals * kResClasses * 4;
   uint32_t* exp_slot = exp_bytes <= kMailboxMaxCopy ? static_cast<uint32_t*>(mb_alloc(ctx, exp_bytes)) : nullptr;
-  if (P.gcadjust && want_cap && cap_compact8_applies(P.m, capval)) {
+  if (P.gcadjust && want_cap && !deep && cap_compact8_applies(P.m, capval)) {
     // K4': from the byte copy of the raw depth, rescaling on the way -- the rescaled int32 array is never written or read
     HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
     Timer t(ctx, "cap_compact_bin", true);
@@ -973,11 +988,12 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       if (rcm != RSI_OK) return rcm;
       d_src = ctx->rd_gc.as<int32_t>();
     }
-    const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact) != 0;
+    const int vbase = want_cap ? hist_window_base(S.cap_median, kK4Window) : (P.gcadjust ? hist_window_base(S.gc_rdmean, kK4Window) : 0);
+    const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact, vbase) != 0;
     if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
-    HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact)));
+    HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact, vbase)));
     Timer t(ctx, "cap_compact_bin", true);
-    launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
+    launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, vbase, st);
   }
   BinAccum bacc;
   std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);

@@ -416,6 +416,67 @@ def test_deep_coverage_sends_tests_to_the_host_walk(hot, hotlib, oracle_cls):
     assert len(res.calls("calls")) > 0
 
 
+@pytest.mark.parametrize("model", [0, 1])
+def test_300x_coverage_takes_the_int32_kernels(hot, hotlib, oracle_cls, model):
+    """At 300x hardly a base fits K2's byte copy: K3' hands over, the int32 rescale (LDS histogram anchored at the mean depth)
+    and the int32 K4 (anchored at the cap median) run instead.  Same bars as everywhere: arrays bit for bit, calls equal."""
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=2_000_003, seed=0x300 + model, model=model, n_events=8, gaps=1,
+                                             max_len=40000, end_n=4000, gap_len=9000))
+    fill = np.random.default_rng(0x300).integers(0, 10, size=depth.size, dtype=np.int32)
+    depth = np.where(depth > 0, depth * 10 + fill, 0).astype(np.int32)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert res.stats["byte_escapes"] > depth.size // 8
+    assert "a2-3.deep coverage" in dict(hot.phase_times())
+    assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    assert res.stats["RDmedian"] == O.f64("chrom")[0] and res.stats["RDsd"] == pytest.approx(O.f64("chrom")[1], rel=1e-12)
+    ok, why = calls_equal(res.calls("calls_raw"), O.calls("calls_raw"))
+    assert ok, why
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
+    assert len(res.calls("calls")) > 0
+
+
+def test_300x_coverage_is_not_a_cliff(hot, hotlib):
+    """The same 60 Mb chromosome at 30x and scaled to 300x (depth * 10 + comb): the deep path streams 4-byte intermediates and
+    runs one more pass, so it is slower -- but by a small factor, not by the order of magnitude that value histograms fed with
+    global atomics cost before their LDS windows followed the depth."""
+    import time
+    import torch
+    from rsicnv_amd import api, synth
+    plan = synth.config_plan(2)
+    n = plan["n"]
+    d_fa = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    d_rd = torch.empty(n + 16, dtype=torch.int32, device="cuda")
+    synth.generate_device(hotlib, plan, d_fa.data_ptr(), d_rd.data_ptr())
+    g = torch.Generator(device="cuda").manual_seed(300)
+    d_deep = torch.where(d_rd > 0, d_rd * 10 + torch.randint(0, 10, d_rd.shape, device="cuda", dtype=torch.int32, generator=g), torch.zeros_like(d_rd))
+    p = api.make_params()
+
+    def best_of(buf, k=4):
+        ts = []
+        for _ in range(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = hot.run_device(p, buf.data_ptr(), d_fa.data_ptr(), n)
+            ts.append(time.perf_counter() - t0)
+        return min(ts[1:]), r
+    t30, r30 = best_of(d_rd)
+    t300, r300 = best_of(d_deep)
+    assert r300.stats["byte_escapes"] > n // 8 and r30.stats["byte_escapes"] == 0
+    assert r300.stats["RDmedian"] > 250
+    calls30 = [(c["start"], c["end"], c["type"]) for c in r30.calls("calls")]
+    calls300 = [(c["start"], c["end"], c["type"]) for c in r300.calls("calls")]
+    assert len(calls300) >= len(calls30) - 1          # the same events are there at ten times the depth
+    print(f"60 Mb: {t30*1e3:.2f} ms at 30x, {t300*1e3:.2f} ms at 300x")
+    assert t300 < 3.0 * t30, (t30, t300)
+
+
 def _level_sums_numpy(T, status, Lmax):
     """The reference's loop (rsi.cpp:967-976): per status level, a float accumulation in index order (np.cumsum is sequential)."""
     sums = np.zeros(2 * Lmax + 1, dtype=np.float32)

@@ -1,0 +1,23 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import torch
+from rsicnv_amd import api, synth
+lib = api.load_library()
+hot = api.RsiHot(0)
+plan = synth.config_plan(2); n = plan["n"]
+d_fa = torch.empty(n + 64, dtype=torch.uint8, device="cuda"); d_rd = torch.empty(n + 16, dtype=torch.int32, device="cuda")
+synth.generate_device(lib, plan, d_fa.data_ptr(), d_rd.data_ptr())
+g = torch.Generator(device="cuda").manual_seed(300)
+d_deep = torch.where(d_rd > 0, d_rd * 10 + torch.randint(0, 10, d_rd.shape, device="cuda", dtype=torch.int32, generator=g), torch.zeros_like(d_rd))
+p = api.make_params()
+for name, buf in (("30x", d_rd), ("300x", d_deep)):
+    for timing in (0, 1):
+        hot.set_timing(timing)
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = hot.run_device(p, buf.data_ptr(), d_fa.data_ptr(), n)
+            dt = time.perf_counter() - t0
+        if timing == 0:
+            print(name, f"{dt*1e3:.2f} ms", [(k, round(v, 2)) for k, v in hot.phase_times() if v > 0.05])
+        else:
+            print(name, "kernels", sorted([(k, round(v, 3)) for k, v in hot.kernel_times()], key=lambda kv: -kv[1])[:14])
