@@ -125,7 +125,8 @@ int cap_compact8_applies(int m, int32_t capval);
 size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact);
 void launch_cap_compact_bin8(const uint8_t* rescaled8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                              const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
-                             int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                             int m, uint8_t* rdc8 /* ncompact + 64 bytes: the capped, compacted depth as bytes */, int32_t* binmed, int64_t* binsum,
+                             uint32_t* res_hist, void* slabs, void* gsum,
                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
@@ -290,11 +291,14 @@ struct CandOut {
   double body_q[3], body_s1, body_s2;   // lower quartile / median / upper quartile (partition_stat_tp), sum, sum of squares
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means
 };
-void launch_range_sums(const int32_t* rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
+// The capped, compacted depth as the candidate kernels see it: int32 (bytes = 4) or, behind K4', one byte per base (bytes = 1).
+struct DepthRef { const void* p; int bytes; };
+void launch_widen_u8(const uint8_t* src, int64_t n, int32_t* dst, hipStream_t stream);   // the int32 form of a byte array
+void launch_range_sums(DepthRef rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
 // one launch = one call of optimize_with_derivative for every job; ws: sharpen_workspace_bytes(ws_jobs) bytes laid out for
 // ws_jobs >= njobs jobs, whose first sharpen_workspace_zero_bytes(ws_jobs) are zero before the first launch (each launch
 // leaves them zero again, so a workspace is cleared once, when it is allocated).  jobs may be mapped host memory.
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream);
+void launch_sharpen_edges(DepthRef rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream);
 size_t sharpen_workspace_bytes(int njobs);
 size_t sharpen_workspace_zero_bytes(int njobs);
 // The same test spread over several workgroups (four launches: the two walks side by side; chunked prefix + the candidate's
@@ -311,10 +315,10 @@ struct CandMid {
   int32_t body_min, body_max;
   double body_q[3], body_s1, body_s2;
 };
-void launch_candidate_test_split(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+void launch_candidate_test_split(DepthRef rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                                  int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,
                                  CandOut* outs, hipStream_t stream);
-void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+void launch_candidate_test(DepthRef rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream);
 
 // ---- depth text ingestion (kernels_io.hip; load_data_from_text's parse loop, loaddata.cpp:496-517) ----

@@ -1115,7 +1115,7 @@ template <int MAXC, int EPT, bool SW7>
 __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
     const uint8_t* __restrict__ r8 /* rescaled, saturated bytes */, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
     int64_t n, int64_t nwords, const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak,
-    const int64_t* __restrict__ cum, int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, int32_t* __restrict__ rdc,
+    const int64_t* __restrict__ cum, int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, uint8_t* __restrict__ rdc8 /* capped + compacted depth, one byte per base */,
     int32_t* __restrict__ binmed,
     int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
     int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
@@ -1201,9 +1201,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
 #pragma unroll
         for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
         *reinterpret_cast<uint4*>(s_val + 16 * kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        int32_t* out = rdc + P0 + 16 * (int64_t)kc;   // 64-byte aligned
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<int4*>(out + 4 * q) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        *reinterpret_cast<uint4*>(rdc8 + P0 + 16 * (int64_t)kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);   // 16-byte aligned: P0 is a multiple of 64 m
         // sixteen LDS atomics into [value][MAD residue class]: the class of element j is cls0 + j, minus 31 from the lane's
         // wrap point on; the element index rides in the instruction's offset field
         const uint32_t cls0 = (p0mod + 16u * (uint32_t)kc) % 31u;
@@ -1228,7 +1226,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
             if (x > capval) x = capval;
             if (x < 0) x = 0;   // negative depth is refused by the caller (K2's flag); keep the byte store in range
             s_val[dst + e] = (unsigned char)x;
-            rdc[seg + e] = x;
+            rdc8[seg + e] = (unsigned char)x;
             const int64_t p = seg + e;
             atomicAdd(&s_hist[x * kResClasses + (p < lim31 ? (int)((uint32_t)p % 31u) : 31)], 1u);
           }
@@ -1406,7 +1404,7 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
 static int value_hist8_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   int64_t grid = (nsub + 3) / 4;
-  if (grid > 256 * 4) grid = 256 * 4;
+  if (grid > 256 * 3) grid = 256 * 3;   // 131 registers: three workgroups per CU are resident, a fourth would run as a tail (7 % slower)
   return (int)(grid < 1 ? 1 : grid);
 }
 size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }
@@ -1441,7 +1439,7 @@ static void k48_geometry(int m, int32_t capval, int64_t ncompact, int& vr, int& 
   while (vr < 256 && vr <= capval) vr <<= 1;
   const int64_t tile = (int64_t)64 * m;
   const int64_t ntiles = (ncompact + tile - 1) / tile;
-  grid = (int)(ntiles < 256 * 4 ? (ntiles < 1 ? 1 : ntiles) : 256 * 4);
+  grid = (int)(ntiles < 256 * 4 ? (ntiles < 1 ? 1 : ntiles) : 256 * 4);   // 3, 5 or 6 per CU: 2-5 % slower
   maxc = tile / 16 <= kThreads ? 1 : 2;
 }
 size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact) {
@@ -1451,7 +1449,7 @@ size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact) {
 }
 void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                              const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
-                             int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                             int m, uint8_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
   int vr, grid, maxc;
   k48_geometry(m, capval, ncompact, vr, grid, maxc);

@@ -123,7 +123,8 @@ __host__ __device__ inline SharpenWs sharpen_views(void* ws, int njobs) {
   return w;
 }
 
-__global__ __launch_bounds__(kThreads) void k_sharpen_edges(const int32_t* __restrict__ rdc, int64_t ncompact,
+template <typename TD>
+__global__ __launch_bounds__(kThreads) void k_sharpen_edges(const TD* __restrict__ rdc, int64_t ncompact,
                                                             EdgeJob* __restrict__ jobs, int njobs /* capacity the workspace is laid out for */,
                                                             void* __restrict__ ws) {
   __shared__ long long s_l[kMaxWaves];
@@ -219,7 +220,8 @@ struct WalkShared { int s_scan[kMaxWaves]; int cnt[2][kMaxWaves]; int trg[2][kMa
 // steps into that neighbour (the trigger, rsi.cpp:222-228 / 246-252: everything after it is dropped
 // and the walk jumps).  One barrier per trip: the waves exchange their taken-counts and triggers; a
 // second one only when there is a trigger, a third when the slots run out.
-__device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int dir, int pos, int room /* slots left */,
+template <typename TD>
+__device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, int pos, int room /* slots left */,
                                   int32_t* __restrict__ dst, int first_slot, const int2* __restrict__ chain, int nchain,
                                   int kind, double too_high, double too_low, WalkShared& W, int* reach, int* chain_used) {
   constexpr int kNone = 0x7fffffff;
@@ -233,7 +235,7 @@ __device__ inline int gather_side(const int32_t* __restrict__ A, int64_t N, int 
     for (int j = 0; j < 4; ++j) {
       long long p = (long long)from + (long long)dir * (1 + 4 * (int)threadIdx.x + j);
       p = p < 0 ? 0 : (p > N - 1 ? N - 1 : p);
-      out[j] = A[p];
+      out[j] = (int)A[p];
     }
   };
   int vnext[4];
@@ -340,7 +342,8 @@ __device__ inline void hist_ranks(const unsigned int* hist, unsigned nbk, size_t
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* __restrict__ A, int64_t N,
+template <typename TD>
+__global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __restrict__ A, int64_t N,
                                                              const CandJob* __restrict__ jobs, const int2* __restrict__ chains,
                                                              int32_t* __restrict__ iscratch, long long* __restrict__ lscratch,
                                                              double RDmedian, CandOut* __restrict__ outs) {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const int32_t* 
     R = thin; nref = tref; thin_body = true; nbody_eff = tbody;
   }
   auto body_at = [&](int q) -> int {
-    return thin_body ? A[J.start + (int)((double)q / (double)nbody_eff * (double)body_len)] : A[J.start + q];
+    return (int)(thin_body ? A[J.start + (int)((double)q / (double)nbody_eff * (double)body_len)] : A[J.start + q]);
   };
   const int width = nbody_eff;
   const int nwin = nref - width;
@@ -601,7 +604,8 @@ __device__ inline int cand_value(const CandJob& J, const CandGeom& g, const Cand
 __device__ inline int cand_chunk_len(int n) { return (((n + kCandChunks - 1) / kCandChunks) + 3) & ~3; }
 
 // launch 1: grid (2, njobs) -- the left and the right walk of every test side by side
-__global__ __launch_bounds__(kTestThreads) void k_cand_gather(const int32_t* __restrict__ A, int64_t N, const CandJob* __restrict__ jobs,
+template <typename TD>
+__global__ __launch_bounds__(kTestThreads) void k_cand_gather(const TD* __restrict__ A, int64_t N, const CandJob* __restrict__ jobs,
                                                           const int2* __restrict__ chains, int32_t* __restrict__ iscratch,
                                                           long long* __restrict__ lscratch, double RDmedian, CandMid* __restrict__ mid) {
   __shared__ WalkShared W;
@@ -628,7 +632,8 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_gather(const int32_t* __r
 
 // launch 2: grid (kCandChunks + 1, njobs) -- chunk-local exact prefix of the neighbourhood (+ chunk totals); the last
 // workgroup of a job computes the candidate's own statistics meanwhile
-__global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const int32_t* __restrict__ A, const CandJob* __restrict__ jobs,
+template <typename TD>
+__global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restrict__ A, const CandJob* __restrict__ jobs,
                                                           int32_t* __restrict__ iscratch, long long* __restrict__ lscratch,
                                                           CandMid* __restrict__ mid) {
   extern __shared__ unsigned int s_hist[];   // kCandHistBins counters (candidate statistics only)
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const int32_t* __r
   // ---- candidate statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
   const int width = g.width;
   auto body_at = [&](int q) -> int {
-    return g.thin ? A[J.start + (int)((double)q / (double)g.nbody_eff * (double)g.nbody)] : A[J.start + q];
+    return (int)(g.thin ? A[J.start + (int)((double)q / (double)g.nbody_eff * (double)g.nbody)] : A[J.start + q]);
   };
   int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
   for (int q = threadIdx.x; q < width; q += kTestThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
@@ -811,7 +816,8 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_hist(const CandJob* __res
 }
 
 // Sums of depth over inclusive ranges (mean_tp of mergesegments, rsi.cpp:775-779): exact integers.
-__global__ __launch_bounds__(kThreads) void k_range_sums(const int32_t* __restrict__ A, const int2* __restrict__ ranges,
+template <typename TD>
+__global__ __launch_bounds__(kThreads) void k_range_sums(const TD* __restrict__ A, const int2* __restrict__ ranges,
                                                          long long* __restrict__ sums) {
   __shared__ long long s_l[kThreads / 64 + 1];
   const int2 r = ranges[blockIdx.x];
@@ -823,37 +829,72 @@ __global__ __launch_bounds__(kThreads) void k_range_sums(const int32_t* __restri
 
 }  // namespace
 
-void launch_range_sums(const int32_t* rdc, const void* ranges, int nranges, long long* sums, hipStream_t stream) {
+// The capped, compacted depth is an int32 array or, behind K4', a byte array (DepthRef): every kernel exists for both.
+#define RSI_DEPTH_DISPATCH(D, CALL32, CALL8) do { if ((D).bytes == 1) { const uint8_t* rdc = static_cast<const uint8_t*>((D).p); CALL8; } \
+                                                 else { const int32_t* rdc = static_cast<const int32_t*>((D).p); CALL32; } } while (0)
+
+void launch_range_sums(DepthRef d, const void* ranges, int nranges, long long* sums, hipStream_t stream) {
   if (nranges <= 0) return;
-  hipLaunchKernelGGL(k_range_sums, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums);
+  RSI_DEPTH_DISPATCH(d,
+    hipLaunchKernelGGL(k_range_sums<int32_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums),
+    hipLaunchKernelGGL(k_range_sums<uint8_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums));
 }
 
-void launch_sharpen_edges(const int32_t* rdc, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream) {
+void launch_sharpen_edges(DepthRef d, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_sharpen_edges, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws);
+  RSI_DEPTH_DISPATCH(d,
+    hipLaunchKernelGGL(k_sharpen_edges<int32_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws),
+    hipLaunchKernelGGL(k_sharpen_edges<uint8_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws));
 }
-void launch_candidate_test_split(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+void launch_candidate_test_split(DepthRef d, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                                  int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,
                                  CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;
   const size_t lds = (size_t)kCandHistBins * 4;
-  RSI_ALLOW_FULL_LDS(k_cand_prefix);
+  RSI_ALLOW_FULL_LDS(k_cand_prefix<int32_t>);
+  RSI_ALLOW_FULL_LDS(k_cand_prefix<uint8_t>);
   RSI_ALLOW_FULL_LDS(k_cand_hist);
   const int2* ch = static_cast<const int2*>(chains);
-  hipLaunchKernelGGL(k_cand_gather, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid);
-  hipLaunchKernelGGL(k_cand_prefix, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid);
+  RSI_DEPTH_DISPATCH(d,
+    hipLaunchKernelGGL(k_cand_gather<int32_t>, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid),
+    hipLaunchKernelGGL(k_cand_gather<uint8_t>, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid));
+  RSI_DEPTH_DISPATCH(d,
+    hipLaunchKernelGGL(k_cand_prefix<int32_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid),
+    hipLaunchKernelGGL(k_cand_prefix<uint8_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid));
   hipLaunchKernelGGL(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid);
   hipLaunchKernelGGL(k_cand_hist, dim3(kCandChunks, njobs), dim3(kTestThreads), lds, stream, jobs, iscratch, lscratch, mid, ghist, outs);
 }
 size_t sharpen_workspace_bytes(int njobs) { return sharpen_zero_bytes(njobs) + (size_t)njobs * 2 * kEdgeChunks * (8 + 8 + 4); }
 size_t sharpen_workspace_zero_bytes(int njobs) { return sharpen_zero_bytes(njobs); }
-void launch_candidate_test(const int32_t* rdc, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
+void launch_candidate_test(DepthRef d, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                            int32_t* iscratch, long long* lscratch, double RDmedian, CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;
   const size_t lds = (size_t)kCandHistBins * 4;
-  RSI_ALLOW_FULL_LDS(k_candidate_test);
-  hipLaunchKernelGGL(k_candidate_test, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch,
-                     lscratch, RDmedian, outs);
+  RSI_ALLOW_FULL_LDS(k_candidate_test<int32_t>);
+  RSI_ALLOW_FULL_LDS(k_candidate_test<uint8_t>);
+  RSI_DEPTH_DISPATCH(d,
+    hipLaunchKernelGGL(k_candidate_test<int32_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs),
+    hipLaunchKernelGGL(k_candidate_test<uint8_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs));
+}
+#undef RSI_DEPTH_DISPATCH
+
+// The int32 form of a byte array (rsi_hot_fetch("rd_concat"), the host's page fetches): 16 values per thread.
+__global__ __launch_bounds__(256) void k_widen_u8(const uint8_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i0 + 16 <= n) {
+    const uint4 b = *reinterpret_cast<const uint4*>(src + i0);
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<int4*>(dst + i0 + 4 * q) = make_int4((int)(w[q] & 0xffu), (int)((w[q] >> 8) & 0xffu), (int)((w[q] >> 16) & 0xffu), (int)(w[q] >> 24));
+  } else {
+    for (int64_t i = i0; i < n; ++i) dst[i] = (int)src[i];
+  }
+}
+void launch_widen_u8(const uint8_t* src, int64_t n, int32_t* dst, hipStream_t stream) {
+  if (n <= 0) return;
+  const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(k_widen_u8, dim3((unsigned int)blocks), dim3(256), 0, stream, src, n, dst);
 }
 
 }  // namespace rsik

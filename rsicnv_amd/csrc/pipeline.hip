@@ -235,7 +235,7 @@ int prepare_runs(rsi_ctx* ctx, const std::vector<Region>& runs, RunArgs& ra) {
 constexpr size_t kCandScratchBytes = size_t(512) << 20;
 class DeviceTester : public rsih::NeighbourTester {
  public:
-  DeviceTester(rsi_ctx* c, const int32_t* rdc, int64_t n, double RDmedian) : ctx(c), d_rdc(rdc), N(n), median(RDmedian) {}
+  DeviceTester(rsi_ctx* c, DepthRef rdc, int64_t n, double RDmedian) : ctx(c), d_rdc(rdc), N(n), median(RDmedian) {}
   double kernel_wait_ms = 0;
   int launches = 0;
 
@@ -408,7 +408,7 @@ class DeviceTester : public rsih::NeighbourTester {
 
  private:
   rsi_ctx* ctx;
-  const int32_t* d_rdc;
+  DepthRef d_rdc;
   int64_t N;
   double median;
   bool ok(hipError_t e) {
@@ -756,6 +756,16 @@ int materialize_rd_gc(rsi_ctx* ctx) {
   return RSI_OK;
 }
 
+// The capped, compacted depth as int32 (the reference's RD after concatenate_data): K4' leaves it as bytes, which is what the
+// candidate kernels read; the int32 form is built when somebody asks -- rsi_hot_fetch("rd_concat"), the host's page fetches.
+int materialize_rdc(rsi_ctx* ctx) {
+  if (!ctx->rdc_is_bytes || ctx->rdc_valid) return RSI_OK;
+  HIPCHK(ctx->rdc.ensure((size_t)(ctx->ncompact + 4) * 4));
+  { Timer t(ctx, "rdc_widen", true); launch_widen_u8(ctx->rdc8.as<uint8_t>(), ctx->ncompact, ctx->rdc.as<int32_t>(), ctx->stream); }
+  ctx->rdc_valid = true;
+  return RSI_OK;
+}
+
 // A1-A9: GC mask and N runs, GC table and rescale, cap, compaction, bins, chromosome statistics (K1-K4).  The kernels are
 // HBM-bound: workers of a pool take turns through this phase (GpuGate, held until the function returns).
 int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, const uint8_t* d_fasta, int64_t n, rsi_result* res,
@@ -774,7 +784,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   }
   Phase ph_a1(ctx, "a1.classify+nruns");
   ctx->n = n; ctx->ncompact = 0; ctx->nb = 0; ctx->have_gc = ctx->have_nb = ctx->have_med = false;
-  ctx->rd_gc_valid = false; ctx->last_depth = d_depth;
+  ctx->rd_gc_valid = false; ctx->last_depth = d_depth; ctx->rdc_is_bytes = false; ctx->rdc_valid = false;
   rsi_chrom_stats& S = res->stats;
   memset(&S, 0, sizeof(S));
   S.n = n;
@@ -978,9 +988,11 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   if (P.gcadjust && want_cap && !deep && cap_compact8_applies(P.m, capval)) {
     // K4': from the byte copy of the raw depth, rescaling on the way -- the rescaled int32 array is never written or read
     HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
+    HIPCHK(ctx->rdc8.ensure((size_t)ncompact + 64));
+    ctx->rdc_is_bytes = true;
     Timer t(ctx, "cap_compact_bin", true);
     launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
-                            ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
+                            ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                             ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
   } else {
     if (P.gcadjust) {   // no cap, a cap of 255 and more, or a wide bin: K4 from the rescaled int32 array, built first
@@ -1138,6 +1150,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       tested.insert(tested.end(), more.begin(), more.end());
     }
     auto mirror_source = [ctx, ncompact]() -> int32_t* {   // grow-only pinned host mirror: transfers land in it directly
+      if (materialize_rdc(ctx) != RSI_OK) return nullptr;   // the pages are int32: widen the byte array first (same stream as the copies)
       if (ctx->mirror_cap < (size_t)ncompact) {
         if (ctx->mirror) (void)hipHostFree(ctx->mirror);
         ctx->mirror = nullptr;
@@ -1151,7 +1164,8 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     rsih::DepthPager pager(ctx->rdc.as<int32_t>(), ncompact, st, mirror_source, nullptr, 0, ctx->sync_ev);
     rsih::CallProfile prof;
     in.prof = &prof;
-    DeviceTester tester(ctx, ctx->rdc.as<int32_t>(), ncompact, RDmedian);
+    const DepthRef depth_ref = ctx->rdc_is_bytes ? DepthRef{ctx->rdc8.p, 1} : DepthRef{ctx->rdc.p, 4};
+    DeviceTester tester(ctx, depth_ref, ncompact, RDmedian);
     const char* host_env = getenv("RSI_HOT_HOST_CANDIDATES");   // debugging switch: candidate stages on the host
     const bool host_tests = host_env && atoi(host_env) != 0;
     in.tester = host_tests ? nullptr : &tester;
@@ -1314,7 +1328,10 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
     if (out) { HIPCHK(hipSetDevice(ctx->device)); const int rcm = materialize_rd_gc(ctx); if (rcm != RSI_OK) return rcm; }
     src = out ? ctx->rd_gc.p : static_cast<const void*>(ctx); cnt = ctx->n;
   }
-  else if (s == "rd_concat") { src = ctx->rdc.p; cnt = ctx->ncompact; }
+  else if (s == "rd_concat") {
+    if (out) { HIPCHK(hipSetDevice(ctx->device)); const int rcm = materialize_rdc(ctx); if (rcm != RSI_OK) return rcm; }
+    src = ctx->rdc.p ? ctx->rdc.p : static_cast<const void*>(ctx); cnt = ctx->ncompact;
+  }
   else if (s == "depth_in" && ctx->in_depth.p) { src = ctx->in_depth.p; cnt = ctx->n_in; }
   else if (s == "binmedint") { src = ctx->binmed.p; cnt = ctx->nb; }
   else if (s == "status1") { src = ctx->status1.p; cnt = ctx->nb; }

@@ -163,6 +163,8 @@ struct rsi_ctx {
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
   bool have_gc = false, have_nb = false, have_med = false;
+  DevBuf rdc8;                               // the capped, compacted depth as bytes (what K4' writes; the candidate kernels read it in place)
+  bool rdc_is_bytes = false, rdc_valid = false;   // rdc8 is the last run's array / the int32 rdc holds it too (materialize_rdc)
   bool rd_gc_valid = false;                  // rd_gc holds the rescaled depth of the last run (else rsi_hot_fetch builds it on demand)
   const int32_t* last_depth = nullptr;       // device input of the last run (borrowed; needed to build rd_gc on demand)
   int last_scan_med = 0;
