@@ -732,7 +732,7 @@ __device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
   return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_value_hist8(const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth,
+__global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth,
                                                           const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
                                                           const double* __restrict__ table, uint32_t* __restrict__ ghist,
                                                           ValueHistAux* __restrict__ aux, unsigned int* __restrict__ hist_slabs,
@@ -1404,7 +1404,7 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
 static int value_hist8_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   int64_t grid = (nsub + 3) / 4;
-  if (grid > 256 * 3) grid = 256 * 3;   // 131 registers: three workgroups per CU are resident, a fourth would run as a tail (7 % slower)
+  if (grid > 256 * 4) grid = 256 * 4;
   return (int)(grid < 1 ? 1 : grid);
 }
 size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }

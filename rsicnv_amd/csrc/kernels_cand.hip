@@ -207,15 +207,45 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const TD* __restrict
 
 // ------------------------------------------------------------------------------------------
 // Neighbourhood test.  See CandJob in kernels.h for what the host prepares.
-constexpr int kWalkBlock = 4 * kTestThreads;   // positions examined per trip of a walk
+constexpr int kWalkPer = 16;                          // consecutive positions per thread and trip: ONE 16-byte load of the byte array
+constexpr int kWalkBlock = kWalkPer * kTestThreads;   // positions examined per trip of a walk
 
 // s_scan doubles as scratch of hist_ranks; the rest is the walk's per-trip exchange, double-buffered by trip parity
 struct WalkShared { int s_scan[kMaxWaves]; int cnt[2][kMaxWaves]; int trg[2][kMaxWaves]; int kept[2]; int lastt[2]; };
 
+// Sixteen consecutive values in walk order from `first` (first, first + dir, ...): one or four 16-byte loads where the
+// block lies inside the array, clamped single loads at the chromosome's ends (those positions are masked by the caller).
+struct __attribute__((packed, aligned(1))) WalkBytes16 { uint32_t w[4]; };
+struct __attribute__((packed, aligned(4))) WalkInts4 { int x, y, z, w; };
+__device__ inline void walk_load16(const uint8_t* __restrict__ A, int64_t N, long long first, int dir, int* out) {
+  const long long lo = dir > 0 ? first : first - 15;
+  if (lo >= 0 && lo + 15 <= N - 1) {
+    const WalkBytes16 b = *reinterpret_cast<const WalkBytes16*>(A + lo);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int k = dir > 0 ? j : 15 - j; out[j] = (int)((b.w[k >> 2] >> (8 * (k & 3))) & 0xffu); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { long long p = first + (long long)dir * j; p = p < 0 ? 0 : (p > N - 1 ? N - 1 : p); out[j] = (int)A[p]; }
+  }
+}
+__device__ inline void walk_load16(const int32_t* __restrict__ A, int64_t N, long long first, int dir, int* out) {
+  const long long lo = dir > 0 ? first : first - 15;
+  if (lo >= 0 && lo + 15 <= N - 1) {
+    int v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const WalkInts4 b = *reinterpret_cast<const WalkInts4*>(A + lo + 4 * q); v[4 * q] = b.x; v[4 * q + 1] = b.y; v[4 * q + 2] = b.z; v[4 * q + 3] = b.w; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[j] = v[dir > 0 ? j : 15 - j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { long long p = first + (long long)dir * j; p = p < 0 ? 0 : (p > N - 1 ? N - 1 : p); out[j] = A[p]; }
+  }
+}
+
 // One side of the reference gather (rsi.cpp:206-257).  dir = -1: left of the candidate, values land
 // in dst[fill], dst[fill-1], ...; dir = +1: right, values land in dst[used], dst[used+1], ...
 // Returns the number of values stored; *reach = last position examined.
-// A trip examines kWalkBlock positions in walk order (four consecutive ones per thread): which are
+// A trip examines kWalkBlock positions in walk order (sixteen consecutive ones per thread): which are
 // taken (not extreme, not inside the neighbour the walk is about to meet), and where the walk first
 // steps into that neighbour (the trigger, rsi.cpp:222-228 / 246-252: everything after it is dropped
 // and the walk jumps).  One barrier per trip: the waves exchange their taken-counts and triggers; a
@@ -228,18 +258,17 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
   int stored = 0, ci = 0, trip = 0;
   int last = pos;
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // "extreme" for integer values: (double)v > too_high <=> v > floor(too_high), (double)v < too_low <=> v < ceil(too_low)
+  // (rsi.cpp:213, 237); the limits are clamped into the int range first, which changes no comparison with an int
+  const double th = too_high > 2147483646.0 ? 2147483646.0 : (too_high < -2147483647.0 ? -2147483647.0 : floor(too_high));
+  const double tl = too_low > 2147483646.0 ? 2147483646.0 : (too_low < -2147483647.0 ? -2147483647.0 : ceil(too_low));
+  const int hi_lim = kind == 0 && too_high == too_high ? (too_high > 2147483646.0 ? 0x7fffffff : (int)th) : 0x7fffffff;   // extreme: v > hi_lim (never for a NaN limit)
+  const int lo_lim = kind == 1 && too_low == too_low ? (too_low < -2147483647.0 ? (int)0x80000000 : (int)tl) : (int)0x80000000;   // extreme: v < lo_lim
   // the values of a trip are loaded one trip ahead (the walk continues straight on unless it meets a
-  // neighbour, which is rare): addresses are clamped, positions beyond the trip are masked when used
-  auto load4 = [&](int from, int* out) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      long long p = (long long)from + (long long)dir * (1 + 4 * (int)threadIdx.x + j);
-      p = p < 0 ? 0 : (p > N - 1 ? N - 1 : p);
-      out[j] = (int)A[p];
-    }
-  };
-  int vnext[4];
-  load4(pos, vnext);
+  // neighbour, which is rare)
+  auto load16 = [&](int from, int* out) { walk_load16(A, N, (long long)from + (long long)dir * (1 + kWalkPer * (int)threadIdx.x), dir, out); };
+  int vnext[kWalkPer];
+  load16(pos, vnext);
   // the neighbour the walk may meet next: read when it changes, not per trip (the list may sit in mapped host memory)
   int2 cur = ci < nchain ? chain[ci] : make_int2(1, 0);   // empty interval when the chain is used up
   while (room > 0 && (dir < 0 ? pos > 2 : (int64_t)pos < N - 2)) {
@@ -248,21 +277,20 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
     // positions of this trip in walk order: p_t = pos + dir*(1+t)
     const int avail = dir < 0 ? pos - 2 : (int)(N - 2 - pos);     // how many positions the walk may still visit
     const int cnt = avail < kWalkBlock ? avail : kWalkBlock;
-    int v[4]; bool acc[4]; int nacc = 0; int trig = kNone;
+    int v[kWalkPer]; unsigned accm = 0; int nacc = 0; int trig = kNone;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = vnext[j];
-    load4(pos + dir * cnt, vnext);                                 // next trip, if the walk goes straight on
+    for (int j = 0; j < kWalkPer; ++j) v[j] = vnext[j];
+    load16(pos + dir * cnt, vnext);                                // next trip, if the walk goes straight on
+    const int t0 = kWalkPer * (int)threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = 4 * threadIdx.x + j;
-      acc[j] = false;
+    for (int j = 0; j < kWalkPer; ++j) {
+      const int t = t0 + j;
       if (t < cnt) {
         const int p = pos + dir * (1 + t);
-        const bool ext = kind == 0 ? ((double)v[j] > too_high) : (kind == 1 ? ((double)v[j] < too_low) : false);
+        const bool ext = v[j] > hi_lim || v[j] < lo_lim;
         const bool inside = p >= cur.x && p <= cur.y;
         if (!ext && inside && t < trig) trig = t;
-        acc[j] = !ext && !inside;
-        nacc += acc[j];
+        if (!ext && !inside) { accm |= 1u << j; ++nacc; }
       }
     }
     int incl = nacc, wtrig = trig;
@@ -276,10 +304,10 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
     int rank = base + incl - nacc;             // rank of this thread's first taken value if nothing were dropped
     int total = all;
     if (tstar != kNone) {                       // values taken before the trigger = the trigger position's rank
-      if ((int)threadIdx.x == (tstar >> 2)) {
+      if ((int)threadIdx.x == tstar / kWalkPer) {
         int k = rank;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (acc[j] && 4 * (int)threadIdx.x + j < tstar) ++k;
+        for (int j = 0; j < kWalkPer; ++j) if (((accm >> j) & 1u) && t0 + j < tstar) ++k;
         W.kept[par] = k;
       }
       __syncthreads();
@@ -287,9 +315,9 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
     }
     const bool fills = total >= room;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = 4 * (int)threadIdx.x + j;
-      if (acc[j] && t < tstar) {
+    for (int j = 0; j < kWalkPer; ++j) {
+      const int t = t0 + j;
+      if (((accm >> j) & 1u) && t < tstar) {
         if (rank < room) dst[first_slot + dir * (stored + rank)] = v[j];
         if (fills && rank == room - 1) W.lastt[par] = t;      // the value that fills the last slot
         ++rank;
@@ -307,7 +335,7 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
       pos = dir < 0 ? cur.x - 1 : cur.y + 1;
       ++ci;
       cur = ci < nchain ? chain[ci] : make_int2(1, 0);
-      load4(pos, vnext);       // the prefetch was for the straight continuation
+      load16(pos, vnext);      // the prefetch was for the straight continuation
     } else {
       pos += dir * cnt;
       last = pos;
