@@ -100,10 +100,23 @@ class NeighbourTester {
 struct IntSpan {
   const int* p = nullptr;
   int64_t n = 0;
+  // sparse form: only the values inside some index ranges are present (the status array inside the marked runs, which is
+  // all the host reads of it): ranges[k] = (first index, last index, position of the first value in p), sorted by index
+  struct Range { int64_t first, last, at; };
+  const std::vector<Range>* ranges = nullptr;
   IntSpan() {}
   IntSpan(const int* p_, int64_t n_) : p(p_), n(n_) {}
   IntSpan(const std::vector<int>& v) : p(v.data()), n((int64_t)v.size()) {}
-  int operator[](int64_t i) const { return p[i]; }
+  IntSpan(const int* values, int64_t n_, const std::vector<Range>* r) : p(values), n(n_), ranges(r) {}
+  const int* at(int64_t i) const {   // the value of index i (and of the indices behind it up to the end of its range)
+    if (!ranges) return p + i;
+    size_t lo = 0, hi = ranges->size();
+    while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if ((*ranges)[mid].first <= i) lo = mid; else hi = mid; }
+    const Range& r = (*ranges)[lo];
+    if (i < r.first || i > r.last) { static const int zero = 0; return &zero; }   // outside the runs the status is 0
+    return p + r.at + (i - r.first);
+  }
+  int operator[](int64_t i) const { return ranges ? *at(i) : p[i]; }
   int64_t size() const { return n; }
 };
 

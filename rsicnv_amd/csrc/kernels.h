@@ -219,8 +219,9 @@ constexpr int kRunsInline = 200, kItemsInline = 150;
 struct RunsInline { int32_t se[2 * kRunsInline]; int32_t off[kRunsInline]; };     // (start, end) pairs; prefix offsets
 struct ItemsInline { SegItem it[kItemsInline]; int32_t off[kRunsInline]; };
 // exact double prefix of every run into scratch + poff[run] (len+1 entries), one workgroup per run
+// status_out (may be NULL; may be mapped host memory): the runs' status values, run after run, value e of run r at poff[r] - r + e
 void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns,
-                       const int64_t* poff, double* scratch, hipStream_t stream);
+                       const int64_t* poff, double* scratch, const int32_t* status, int32_t* status_out, hipStream_t stream);
 // one workgroup per work item; out[item] = best (score, offset, L) of that item under the
 // reference's visiting order (larger score, then smaller L, then smaller offset); out may be mapped host memory
 void launch_best_items(const void* items, const ItemsInline* inl, int nitems, const int64_t* poff, const double* scratch,

@@ -783,12 +783,17 @@ __global__ __launch_bounds__(kThreads) void k_trim_runs(const float* __restrict_
 // Step 1: exact double prefix of the run's values into scratch (one workgroup per run).
 __global__ __launch_bounds__(kThreads) void k_run_prefix(const float* __restrict__ T, const int32_t* __restrict__ run_start,
                                                          const int32_t* __restrict__ run_end,
-                                                         const int64_t* __restrict__ poff, double* __restrict__ scratch, RunsInline inl) {
+                                                         const int64_t* __restrict__ poff, double* __restrict__ scratch, RunsInline inl,
+                                                         const int32_t* __restrict__ status, int32_t* __restrict__ status_out) {
   __shared__ double s_tot[kThreads];
   const int r = blockIdx.x;
   const int s = run_start ? run_start[r] : inl.se[2 * r];
   const int len = (run_start ? run_end[r] : inl.se[2 * r + 1]) - s + 1;
-  double* P = scratch + (poff ? poff[r] : (int64_t)inl.off[r]);
+  const int64_t off = poff ? poff[r] : (int64_t)inl.off[r];
+  double* P = scratch + off;
+  // the run's status values, run after run (the prefixes take len + 1 slots per run, the values len): the host needs the
+  // status array inside the runs only (type of a segment, nested levels), so this replaces a copy of the whole array
+  if (status_out) for (int e = threadIdx.x; e < len; e += kThreads) status_out[off - r + e] = status[s + e];
   const int chunk = (len + kThreads - 1) / kThreads;
   const int c0 = threadIdx.x * chunk;
   double run = 0.0;
@@ -941,10 +946,10 @@ void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start,
 
 // best_subsegment is driven from the host side in two launches (see pipeline.hip)
 void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns, const int64_t* poff,
-                       double* scratch, hipStream_t stream) {
+                       double* scratch, const int32_t* status, int32_t* status_out, hipStream_t stream) {
   if (nruns <= 0) return;
   static const RunsInline none{};
-  hipLaunchKernelGGL(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch, inl ? *inl : none);
+  hipLaunchKernelGGL(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch, inl ? *inl : none, status, status_out);
 }
 void launch_best_items(const void* items, const ItemsInline* inl, int nitems, const int64_t* poff, const double* scratch, double tmedian,
                        BestSeg* out, hipStream_t stream) {

@@ -18,7 +18,9 @@ struct ScanPassOut { uint32_t escapes, inexact, ldel, ldup; };   // what one rsi
 struct ScanOut {
   double tmedian1 = 0, tsigma1 = 0, tlamda1 = 0, tmedian2 = 0, tsigma2 = 0, tlamda2 = 0;
   int Lmax = 0;
-  rsih::IntSpan status2;            // the context's pinned host copy, valid until the context's next scan
+  rsih::IntSpan status2;            // status after pass 2: the values inside the runs (run_status / run_ranges), or the context's pinned copy of the whole array
+  std::vector<int> run_status;
+  std::vector<rsih::IntSpan::Range> run_ranges;
   std::vector<Candidate> segs;
   uint32_t escapes = 0, inexact = 0;
   // per-L counts of newly marked bins of the four sweeps (pass 1 DEL, DUP, pass 2 DEL, DUP) and the L each stopped at:
@@ -644,8 +646,6 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   GateShared gs_seg(ctx);
 
   // ---- get_rsi_segments (rsi.cpp:1060-1117) ----
-  HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
-  HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));   // into out.status2 after the next sync
   HIPCHK(CTX_SYNC());
   std::vector<Region> runs;
   if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
@@ -653,7 +653,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[3].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
   out.stop_levels[2] = wslot[2]; out.stop_levels[3] = wslot[3];
-  out.status2 = rsih::IntSpan(ctx->h_status2.as<int>(), nb);
+  out.status2 = rsih::IntSpan();
   out.segs.clear();
   if (runs.empty()) return RSI_OK;
   std::vector<int64_t> poff(runs.size() + 1, 0);
@@ -684,10 +684,26 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     for (size_t i = 0; i < items.size(); ++i) ii.it[i] = items[i];
     BestSeg* slot = static_cast<BestSeg*>(mb_alloc(ctx, items.size() * sizeof(BestSeg)));
     if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
-    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, nullptr, nullptr, &ra.inl, (int)runs.size(), nullptr, d_scratch, ctx->stream); }
+    // The host reads the status array inside the runs only (a segment's type, the nested levels of the block tests): the
+    // prefix kernel writes those values, run after run, into the mailbox -- 2 % of the array instead of a copy of all of it.
+    const size_t run_bins = (size_t)(poff.back() - (int64_t)runs.size());
+    int32_t* sslot = run_bins * 4 <= kMailboxMaxCopy ? static_cast<int32_t*>(mb_alloc(ctx, std::max<size_t>(run_bins, 1) * 4)) : nullptr;
+    if (!sslot) {
+      HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
+      HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, nullptr, nullptr, &ra.inl, (int)runs.size(), nullptr, d_scratch, d_st2, sslot, ctx->stream); }
     { Timer t(ctx, "best_subsegment"); launch_best_items(nullptr, &ii, (int)items.size(), nullptr, d_scratch, tmedian, slot, ctx->stream); }
     HIPCHK(CTX_SYNC());
     memcpy(best.data(), slot, items.size() * sizeof(BestSeg));
+    if (sslot) {
+      out.run_status.assign(sslot, sslot + run_bins);
+      out.run_ranges.clear();
+      for (size_t r = 0; r < runs.size(); ++r) out.run_ranges.push_back({runs[r].start, runs[r].end, poff[r] - (int64_t)r});
+      out.status2 = rsih::IntSpan(out.run_status.data(), nb, &out.run_ranges);
+    } else {
+      out.status2 = rsih::IntSpan(ctx->h_status2.as<int>(), nb);
+    }
   } else {
     RunArgs ra;
     const size_t kr = runs.size();
@@ -700,7 +716,10 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     HIPCHK(ctx->best.ensure(items.size() * sizeof(BestSeg)));
     HIPCHK(copy_h2d(ctx, d_poff, poff.data(), poff.size() * 8));
     HIPCHK(copy_h2d(ctx, ctx->items.p, items.data(), items.size() * sizeof(SegItem)));
-    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, ctx->run_se.as<int32_t>(), ctx->run_se.as<int32_t>() + kr, nullptr, (int)kr, d_poff, d_scratch, ctx->stream); }
+    HIPCHK(ctx->h_status2.ensure((size_t)nb * 4));
+    HIPCHK(hipMemcpyAsync(ctx->h_status2.p, d_st2, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    out.status2 = rsih::IntSpan(ctx->h_status2.as<int>(), nb);   // complete at the sync below
+    { Timer t(ctx, "run_prefix"); launch_run_prefix(d_T, ctx->run_se.as<int32_t>(), ctx->run_se.as<int32_t>() + kr, nullptr, (int)kr, d_poff, d_scratch, nullptr, nullptr, ctx->stream); }
     { Timer t(ctx, "best_subsegment"); launch_best_items(ctx->items.p, nullptr, (int)items.size(), d_poff, d_scratch, tmedian, ctx->best.as<BestSeg>(), ctx->stream); }
     HIPCHK(copy_d2h(ctx, best.data(), ctx->best.p, items.size() * sizeof(BestSeg)));
     HIPCHK(CTX_SYNC());
@@ -716,7 +735,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     double sc = per_run[r].score;
     if (sc > 0) { c.start = runs[r].start + per_run[r].start; c.end = c.start + per_run[r].len - 1; }
     else { c.start = runs[r].start; c.end = runs[r].start + len - 1; sc = 0; }
-    const rsih::Quantiles q = rsih::grid_quantiles(out.status2.p + c.start, (size_t)(c.end - c.start + 1));
+    const rsih::Quantiles q = rsih::grid_quantiles(out.status2.at(c.start), (size_t)(c.end - c.start + 1));
     if (q.med > 0) { c.type = rsih::kDup; c.score = sc; } else { c.type = rsih::kDel; c.score = -sc; }
     if (fabs(c.score) < tlamda * 0.5) continue;   // rsi.cpp:1343-1346
     out.segs.push_back(c);
