@@ -152,9 +152,11 @@ int rsi_result_summary(const rsi_result* r, int chrom_id, double* out, int max_c
 int rsi_summary_format_row(const double* block, int i, const char* chrom, char* buf, int cap);
 /* every stored call of the block, one row per line (each ended by '\n'); returns the bytes written, < 0 if buf is too small */
 int rsi_summary_format_rows(const double* block, const char* chrom, char* buf, int cap);
-/* The per-L lines rsistatus writes to the log (rsi.cpp:1221-1224 "DEL-", 1251-1254 "DUP+": L, bins marked so far, bins,
- * portion) for the four sweeps of the chromosome's (last) scan, first pass first: line i (0-based) into buf; returns i + 1,
- * or 0 when there is no such line. */
+/* The diagnostic lines of the chromosome's (last) scan as the reference writes them to its log, in its order: the NB
+ * transform's "RD median : " / "RD median absolute deviation : " (rsi.cpp:1140-1141), the first pass' per-L lines
+ * (rsi.cpp:1221-1224 "DEL-", 1251-1254 "DUP+": L, bins marked so far, bins, portion), filterstatus' level table (level, bins,
+ * float mean; then the two chosen levels; rsi.cpp:991-1002), the second pass' per-L lines.  This is the log sink of SURVEY
+ * 8(b) as a pull interface: line i (0-based) into buf; returns i + 1, or 0 when there is no such line. */
 int rsi_result_log_line(const rsi_result* r, int i, char* buf, int cap);
 /* Reference sequences of the BAM header: names as one '\n'-separated string into names[names_cap], lengths into
  * lengths[max_refs]; returns their number (also when the buffers are too small or NULL), < 0 on error. */

@@ -205,8 +205,8 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
   if (o.P.gcadjust) info << "RD mean before GC adjust = " << S->gc_rdmean << "\n";
   if (o.P.cap > 1) info << "applying cap " << o.P.cap << " times of mean " << S->cap_median << "\ncap = " << o.P.cap * S->cap_median << "\n";
   info << "region  : " << chr << ":1-" << S->n_compact << "\nmedian  : " << S->RDmedian << "\nrs::m   : " << o.P.m << "\nrs::cap : " << o.P.cap << "\n";
-  info << "RD median absolute deviation : " << S->nb_mad << "\n";
-  {   // the reference's per-L lines of the two rsistatus passes (rsi.cpp:1221-1224, 1251-1254): L, newly marked bins, running total
+  {   // the scan's diagnostic lines as the reference logs them: the NB transform's median / MAD (rsi.cpp:1140-1141), the per-L
+      // lines of the two rsistatus passes (rsi.cpp:1221-1224, 1251-1254), filterstatus' level table between them (rsi.cpp:991-1002)
     char line[256];
     int n = 0;
     while ((n = rsi_result_log_line(res, n, line, (int)sizeof(line))) > 0) info << line << "\n";

@@ -27,6 +27,7 @@ struct ScanOut {
   // what the reference logs per L (rsi.cpp:1221-1224, 1251-1254)
   std::vector<uint32_t> level_log[4];
   uint32_t stop_levels[4] = {0, 0, 0, 0};
+  std::vector<std::string> fs_lines;   // filterstatus' level table as the reference logs it (rsi.cpp:991-1002)
 };
 
 // partition_stat_tp's early return (wufunctions.cpp:371-381): when the selection spans less than the grid step its "median"
@@ -604,6 +605,14 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
       int leveldel = lo, leveladd = hi;
       for (int l = 0; l < nl; ++l) if (lsum[l] < m0 - dev) { leveldel = l + lo; break; }
       for (int l = nl - 1; l >= 0; --l) if (lsum[l] > m0 + dev) { leveladd = l + lo; break; }
+      {   // the table the reference writes to its log: level, bins, mean; then the two chosen levels (rsi.cpp:991-997)
+        char line[128];
+        out.fs_lines.clear();
+        for (int l = 0; l < nl; ++l) if (lcnt[l] != 0) { snprintf(line, sizeof(line), "%d\t%d\t%g", l + lo, lcnt[l], (double)lsum[l]); out.fs_lines.push_back(line); }
+        snprintf(line, sizeof(line), "%d\t%g", leveldel, (double)lsum[leveldel - lo]); out.fs_lines.push_back(line);
+        snprintf(line, sizeof(line), "%d\t%g", leveladd, (double)lsum[leveladd - lo]); out.fs_lines.push_back(line);
+        if (leveldel > 0 || leveladd < 0 || leveldel > leveladd) out.fs_lines.push_back("warning level error, status not filtered");
+      }
       if (!(leveldel > 0 || leveladd < 0 || leveldel > leveladd)) {
         std::vector<Region> runs;
         GateShared gs(ctx);
@@ -1155,6 +1164,8 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;
       S.Lmax = so.Lmax; S.trim_escapes += (int)so.escapes; S.inexact_sums = (int)so.inexact;
       for (int w = 0; w < 4; ++w) { res->level_log[w] = so.level_log[w]; res->stop_levels[w] = so.stop_levels[w]; }
+      res->fs_lines = so.fs_lines;
+      res->log_nb = !use_med;
       for (const Candidate& c : so.segs) segs_all.push_back(c);
       segs = so.segs;
       { Phase ph(ctx, "a15.blocks"); rsih::test_block_segments(in, so.status2, segs); }   // areblockscnv, rsi.cpp:1847
@@ -1451,9 +1462,21 @@ int rsi_result_format_row(const rsi_result* r, int i, const char* chrom, char* b
 // The reference's per-L lines of rsistatus (rsi.cpp:1221-1224, 1251-1254), "DEL-\tL\tmarked so far\tbins\tportion", for the
 // four sweeps in the order the reference runs them; line i into buf, returns i + 1, or 0 when there is no line i.
 int rsi_result_log_line(const rsi_result* r, int i, char* buf, int cap) {
+  // The (last) scan's diagnostic lines in the reference's order: the NB transform's two lines (rsi.cpp:1140-1141), the first
+  // pass' DEL- / DUP+ lines per L (rsi.cpp:1221-1224, 1251-1254), filterstatus' level table (rsi.cpp:991-1002), the second
+  // pass' per-L lines.
   if (!r || i < 0 || !buf || cap <= 0) return 0;
   int left = i;
+  if (r->log_nb) {
+    if (left == 0) { snprintf(buf, (size_t)cap, "RD median : %g", r->stats.RDmedian); return i + 1; }
+    if (left == 1) { snprintf(buf, (size_t)cap, "RD median absolute deviation : %g", r->stats.nb_mad); return i + 1; }
+    left -= 2;
+  }
   for (int w = 0; w < 4; ++w) {
+    if (w == 2) {
+      if (left < (int)r->fs_lines.size()) { snprintf(buf, (size_t)cap, "%s", r->fs_lines[(size_t)left].c_str()); return i + 1; }
+      left -= (int)r->fs_lines.size();
+    }
     const int stop = (int)r->stop_levels[w];
     const std::vector<uint32_t>& h = r->level_log[w];
     if (stop <= 0 || h.empty()) continue;

@@ -132,6 +132,8 @@ struct rsi_result {
   // each sweep stopped at: the reference's "DEL-" / "DUP+" log lines (rsi.cpp:1221-1224, 1251-1254)
   std::vector<uint32_t> level_log[4];
   uint32_t stop_levels[4] = {0, 0, 0, 0};
+  std::vector<std::string> fs_lines;   // filterstatus' level table of that scan, as logged (rsi.cpp:991-1002)
+  bool log_nb = false;                 // that scan ran on the NB transform: its two log lines come first (rsi.cpp:1140-1141)
   rsi_chrom_stats stats;
   rsi_params params;
 };

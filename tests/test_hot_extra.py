@@ -102,6 +102,19 @@ def test_cli_output_file_matches_reference_binary(hotlib, tmp_path, extra):
     la, lb = sweep(ours), sweep(theirs)
     assert la == lb and len(la) >= 4 * 20, f"{len(la)} vs {len(lb)} sweep lines; first difference: " + \
         str(next(((x, y) for x, y in zip(la, lb) if x != y), None))
+    # filterstatus' level table between the two passes (rsi.cpp:991-1002): level, bins, float mean of the level; then the two
+    # chosen levels -- the same lines, in one piece, in the reference's log
+    mine, ref = open(ours + ".log").read().splitlines(), open(theirs + ".log").read().splitlines()
+    is_sweep = [l.startswith(("DEL-\t", "DUP+\t")) for l in mine]
+    first = is_sweep.index(True)
+    gap0 = next(i for i in range(first, len(mine)) if not is_sweep[i])          # first line behind the first pass
+    gap1 = next(i for i in range(gap0, len(mine)) if is_sweep[i])               # the second pass begins
+    table = mine[gap0:gap1]
+    assert len(table) >= 3 and all(l.count("\t") in (1, 2) or l.startswith("warning") for l in table), table
+    assert any(ref[i:i + len(table)] == table for i in range(len(ref))), "level table not in the reference log:\n" + "\n".join(table)
+    if "-MED" not in extra:   # the NB transform's two lines (rsi.cpp:1140-1141)
+        nbl = [l for l in mine if l.startswith("RD median")]
+        assert len(nbl) == 2 and all(l in ref for l in nbl), nbl
 
 
 def test_error_behaviour(hot, hotlib):
