@@ -1,5 +1,7 @@
+"""The same 60 Mb chromosome at 30x and scaled to 300x through one context: wall time, host phases and per-kernel times
+(the deep-coverage path).  python tools/deep_probe.py"""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rsicnv_amd import api, synth
 lib = api.load_library()
