@@ -62,8 +62,12 @@ def main():
     notes = {name: [] for name, _, _ in variants}
 
     def run(name, pool, kv, timed):
-        for k in keys:
-            os.environ[k] = kv.get(k, "0")
+        for k in keys:   # a switch a variant does not name is "0" for it; the value "-" removes it from the environment
+            v = kv.get(k, "0")
+            if v == "-":
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         pool.set_timing(int(kv.get("timing", "1")))   # 1: HIP events around every launch; 3: around the dominant kernel only (bench.py's timed steps)
         timed = timed and kv.get("timing", "1") != "0"
         pool.times = tables[name]
