@@ -108,7 +108,7 @@ __device__ inline void fold_add(unsigned long long (&s)[2], u32x4 v) {
   s[1] += (unsigned long long)v.z | ((unsigned long long)v.w << 32);
 }
 // dst[e] = sum over k < members of src[k * stride + e], e < width; width a multiple of 16 / sizeof(T), src 16-byte aligned
-template <typename T, bool CG>
+template <typename T, int MODE /* 0: plain stores, 1: st_cg stores, 2: atomic adds of the non-zero sums */>
 __device__ inline void fold_columns(const T* src, size_t stride, int members, int width, T* dst) {
   constexpr int kPer = 16 / (int)sizeof(T);
   const int last = __builtin_amdgcn_readfirstlane(members - 1);
@@ -126,7 +126,11 @@ __device__ inline void fold_columns(const T* src, size_t stride, int members, in
       for (int j = 0; j < 8; ++j) if (k0 + j <= last) fold_add(s, v[j]);
     }
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) { if (CG) st_cg(dst + q * kPer + j, s[j]); else dst[q * kPer + j] = s[j]; }
+    for (int j = 0; j < kPer; ++j) {
+      if (MODE == 2) { if (s[j]) atomicAdd(dst + q * kPer + j, s[j]); }
+      else if (MODE == 1) st_cg(dst + q * kPer + j, s[j]);
+      else dst[q * kPer + j] = s[j];
+    }
   }
 }
 
@@ -147,7 +151,7 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  fold_columns<T, true>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, gsum + (size_t)g * width);
+  fold_columns<T, 1>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, gsum + (size_t)g * width);
   drain();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -158,9 +162,43 @@ __device__ inline bool fold_slabs(const T* slabs, T* gsum, T* total, int width, 
   }
   __syncthreads();
   if (!s_flag__) return false;
-  fold_columns<T, false>(gsum, (size_t)width, ngroups, width, total);
+  fold_columns<T, 0>(gsum, (size_t)width, ngroups, width, total);
   __syncthreads();
   return true;
+}
+
+// The same with ONE level of reading: the last workgroup of a group adds the group's sums to total[] (global, zero before
+// the launch) with atomics -- a few dozen per word in all -- instead of leaving them for a second pass by a single
+// workgroup, which for a wide slab (K4': 16 KB) is as long again as the first (half a megabyte through one workgroup's
+// loads).  True in the workgroup that arrives last, after every group's atomics have completed; read total[] with ld_cg.
+template <typename T>
+__device__ inline bool fold_slabs_add(const T* slabs, T* total, int width, int per_group, unsigned int* counters) {
+  __shared__ unsigned int s_flag2__;
+  const int nblocks = (int)gridDim.x;
+  const int g = (int)blockIdx.x / per_group;
+  const int ngroups = (nblocks + per_group - 1) / per_group;
+  const int members = (g + 1) * per_group <= nblocks ? per_group : nblocks - g * per_group;
+  drain();
+  __syncthreads();   // the slab's st_cg stores have completed
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(&counters[1 + g], 1u);
+    const bool last = t == (unsigned int)members - 1u;
+    if (last) atomicExch(&counters[1 + g], 0u);
+    s_flag2__ = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_flag2__) return false;
+  fold_columns<T, 2>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, total);
+  drain();
+  __syncthreads();   // this group's atomics have completed
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(&counters[0], 1u);
+    const bool last = t == (unsigned int)ngroups - 1u;
+    if (last) atomicExch(&counters[0], 0u);
+    s_flag2__ = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return s_flag2__ != 0;
 }
 
 // Whole-workgroup copy of `bytes` (multiple of 4) from device memory written by other workgroups to mapped host memory.

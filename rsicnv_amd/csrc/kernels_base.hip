@@ -1314,9 +1314,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   // and hands [BinAccum | histogram] to the host ----
   unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
-  if (!fold_slabs(hist_slabs, gsum, s_hist, vr * kResClasses, per_group, counters)) return;
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&res_hist[e], s_hist[e]);
-  sync_drained();
+  // res_hist is zero when the launch begins (K1's FillList): the groups' sums go straight into it
+  if (!fold_slabs_add(hist_slabs, res_hist, vr * kResClasses, per_group, counters)) return;
   export_words(exp_dst, exp_src, exp_bytes);
 }
 

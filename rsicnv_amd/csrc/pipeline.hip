@@ -843,7 +843,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     FillList fl{};
     fill_add(fl, small, kHeaderBytes, 0u);
     if (P.gcadjust || want_cap) fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
-    fill_add(fl, ctx->hist_res.p, kResHead, 0u);   // BinAccum of K4
+    fill_add(fl, ctx->hist_res.p, kResHead + (size_t)256 * kResClasses * 4, 0u);   // BinAccum of K4 and the rows K4' adds its groups' sums to (its range is at most 256 values)
     Timer t(ctx, "fasta_classify", true);
     launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, fl, st);
   }
