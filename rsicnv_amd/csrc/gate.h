@@ -1,0 +1,33 @@
+// gate.h -- GpuGate, the turnstile of a pool's per-base phases.  Plain C++ (no HIP): tests/sanitize/gate_tsan.cpp drives it
+// from a dozen threads under ThreadSanitizer.
+#pragma once
+#include <condition_variable>
+#include <mutex>
+
+namespace rsip {
+
+// One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
+// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
+// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
+// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
+// a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
+// sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
+struct GpuGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int sharers = 0, streamers_waiting = 0, streaming = 0;
+  bool few_chromosomes = false;   // set per rsi_pool_run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
+  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
+  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
+  void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
+  void lock(bool exclude_sharers) {
+    std::unique_lock<std::mutex> lk(m);
+    ++streamers_waiting;
+    cv.wait(lk, [&] { return exclude_sharers ? (streaming == 0 && sharers == 0) : streaming < max_streamers; });
+    --streamers_waiting;
+    ++streaming;
+  }
+  void unlock() { { std::lock_guard<std::mutex> lk(m); --streaming; } cv.notify_all(); }
+};
+
+}  // namespace rsip

@@ -32,6 +32,8 @@ using rsih::Candidate;
 using rsih::Region;
 
 
+#include "gate.h"   // GpuGate: who may run a per-base phase when (plain C++, also built under ThreadSanitizer: tests/sanitize)
+
 namespace rsip {
 
 
@@ -86,30 +88,6 @@ struct PinBuf {   // grow-only pinned host allocation: destination of the large 
 };
 
 struct KernelTime { const char* name; hipEvent_t a, b; };
-
-// One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
-// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
-// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
-// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
-// a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
-// sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
-struct GpuGate {
-  std::mutex m;
-  std::condition_variable cv;
-  int sharers = 0, streamers_waiting = 0, streaming = 0;
-  bool few_chromosomes = false;   // set per rsi_pool_run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
-  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
-  void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
-  void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
-  void lock(bool exclude_sharers) {
-    std::unique_lock<std::mutex> lk(m);
-    ++streamers_waiting;
-    cv.wait(lk, [&] { return exclude_sharers ? (streaming == 0 && sharers == 0) : streaming < max_streamers; });
-    --streamers_waiting;
-    ++streaming;
-  }
-  void unlock() { { std::lock_guard<std::mutex> lk(m); --streaming; } cv.notify_all(); }
-};
 
 inline double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

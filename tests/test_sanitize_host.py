@@ -27,3 +27,20 @@ def test_host_code_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "host_harness"), bam], capture_output=True, text=True, env=env, timeout=500)
     assert r.returncode == 0 and "host harness ok" in r.stdout, (r.stdout[-1500:] + r.stderr[-3000:])
+
+
+@pytest.mark.timeout(300)
+def test_pool_gate_under_tsan(tmp_path):
+    """The pool's turnstile for per-base phases (rsicnv_amd/csrc/gate.h) from twelve threads under ThreadSanitizer, both
+    schedules, one to three turns at a time: no data race, never more turns at once than allowed, no shared section inside an
+    exclusive turn."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run(["g++", "-fsanitize=thread", "-x", "c++", "-", "-o", str(tmp_path / "probe")], input=b"int main(){return 0;}",
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ cannot link the ThreadSanitizer runtime here")
+    r = subprocess.run(["make", "-f", "tests/sanitize/Makefile", "tests/sanitize/gate_tsan"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "gate_tsan")], capture_output=True, text=True, timeout=250)
+    assert r.returncode == 0 and "gate harness ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
