@@ -72,8 +72,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config (1-based as in SURVEY 8d): 2, 3, 4 or 5")
     ap.add_argument("--shard", choices=("genome", "sample"), default="genome",
                     help="N > 1: one genome sharded by chromosome over the ranks (strong scaling, the north_star mode) or one genome per rank (weak)")
