@@ -230,6 +230,20 @@ struct WaveGc {            // per-wave LDS slot
   uint32_t pre[kSubLds + 2];
 };
 
+// GC bases among the 201 starting at bit `lo` of the mask (0 <= lo, lo + 201 <= number of bits): popcounts of the four or
+// five words the window touches -- the tails of K2 and K3 used to walk it bit by bit, 201 dependent loads per cell.
+__device__ inline int gc_window_count(const uint64_t* __restrict__ gcbits, int64_t lo) {
+  const int64_t hi = lo + 201;   // exclusive
+  int g = 0;
+  for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
+    uint64_t x = gcbits[w];
+    const int64_t b0 = w << 6;
+    if (lo > b0) x &= ~0ull << (lo - b0);
+    if (hi < b0 + 64) x &= (1ull << (hi - b0)) - 1;
+    g += __popcll(x);
+  }
+  return g;
+}
 __device__ inline uint32_t wgc_rank(const WaveGc& t, uint32_t rel) {
   const uint32_t k = rel >> 6, b = rel & 63;
   const uint64_t m = b ? (t.word[k] & ((1ull << b) - 1)) : 0;
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restri
   if (!fold_slabs(slabs, gsum, total, kGcSlab, per_group, counters)) return;
   if (threadIdx.x == 0 && (n & 3) != 0) {
     int g = 0;
-    for (int64_t i = n - 202; i <= n - 2; ++i) g += (int)((gcbits[i >> 6] >> (i & 63)) & 1);
+    g = gc_window_count(gcbits, n - 202);   // bits n-202 .. n-2
     for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
       const int v = depth[i];
       total[g] += (unsigned long long)(long long)v;
@@ -461,7 +475,7 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
     if (lo < 0) lo = 0;
     if (lo > n - 202) lo = n - 202;
     int g = 0;
-    for (int k = 0; k < 201; ++k) g += (int)((gcbits[(lo + k) >> 6] >> ((lo + k) & 63)) & 1);
+    g = gc_window_count(gcbits, lo);
     return (int)((double)depth[i] * rdmean / table[g] + 0.5);
   };
   if (!adjust) {
