@@ -202,11 +202,37 @@ __device__ inline bool fold_slabs_add(const T* slabs, T* total, int width, int p
 }
 
 // Whole-workgroup copy of `bytes` (multiple of 4) from device memory written by other workgroups to mapped host memory.
+// Sixteen bytes per load and store, four loads in flight per thread, where both ends are 16-byte aligned: K4''s 15 KB
+// histogram went out as four thousand dword loads, sixteen dependent rounds per thread.
 __device__ inline void export_words(void* host_dst, const void* dev_src, size_t bytes) {
   if (!host_dst) return;
+  size_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) == 0) {
+    const size_t nvec = bytes / 16;
+    u32x4* d = static_cast<u32x4*>(host_dst);
+    const unsigned long long base = uniform_address(dev_src);
+    for (size_t q0 = 0; q0 < nvec; q0 += 4 * (size_t)blockDim.x) {
+      u32x4 v[4];
+      unsigned int off[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const size_t q = q0 + (size_t)j * blockDim.x + threadIdx.x; off[j] = (unsigned int)((q < nvec ? q : 0) * 16); }
+      asm volatile(
+          "global_load_dwordx4 %0, %4, %8 sc1\n\t"
+          "global_load_dwordx4 %1, %5, %8 sc1\n\t"
+          "global_load_dwordx4 %2, %6, %8 sc1\n\t"
+          "global_load_dwordx4 %3, %7, %8 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+          : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(base)
+          : "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const size_t q = q0 + (size_t)j * blockDim.x + threadIdx.x; if (q < nvec) d[q] = v[j]; }
+    }
+    done = nvec * 16;
+  }
   unsigned int* d = static_cast<unsigned int*>(host_dst);
   const unsigned int* s = static_cast<const unsigned int*>(dev_src);
-  for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = ld_cg(s + i);
+  for (size_t i = done / 4 + threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = ld_cg(s + i);
 }
 #endif
 
