@@ -2,6 +2,9 @@
 // iterations are independent): `nworkers` host threads, each with its own context (stream + workspace), and the gate
 // that lets at most two per-base phases stream at a time.
 #include "pipeline_internal.h"
+#include <condition_variable>
+#include <functional>
+#include <thread>
 
 using namespace rsik;
 using namespace rsip;
@@ -19,6 +22,46 @@ struct rsi_pool {
   std::vector<rsi_ctx*> workers;
   GpuGate gate;
   std::string err;
+  // Workers 1 .. W-1 are threads that live as long as the pool and sleep between runs (worker 0 is the caller's thread):
+  // starting eleven threads per run took 0.3 ms before the last chromosome of the first wave was under way.
+  std::vector<std::thread> threads;
+  std::mutex jm;
+  std::condition_variable jcv, dcv;
+  const std::function<void(size_t)>* job = nullptr;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool quit = false;
+  void worker_loop(size_t w) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t)>* f;
+      {
+        std::unique_lock<std::mutex> lk(jm);
+        jcv.wait(lk, [&] { return quit || generation != seen; });
+        if (quit) return;
+        seen = generation;
+        f = job;
+      }
+      (*f)(w);
+      {
+        std::lock_guard<std::mutex> lk(jm);
+        if (--pending == 0) dcv.notify_one();
+      }
+    }
+  }
+  void run_on_all(const std::function<void(size_t)>& f) {   // f(w) on every worker, w = 0 on the calling thread; returns when all are done
+    {
+      std::lock_guard<std::mutex> lk(jm);
+      job = &f;
+      pending = (int)threads.size();
+      ++generation;
+    }
+    jcv.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(jm);
+    dcv.wait(lk, [&] { return pending == 0; });
+    job = nullptr;
+  }
 };
 
 rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
@@ -41,12 +84,19 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
     c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
     pool->workers.push_back(c);
   }
+  for (size_t w = 1; w < pool->workers.size(); ++w) pool->threads.emplace_back([pool, w] { pool->worker_loop(w); });
   if (status) *status = RSI_OK;
   return pool;
 }
 
 void rsi_pool_destroy(rsi_pool* pool) {
   if (!pool) return;
+  {
+    std::lock_guard<std::mutex> lk(pool->jm);
+    pool->quit = true;
+  }
+  pool->jcv.notify_all();
+  for (std::thread& t : pool->threads) t.join();
   for (rsi_ctx* c : pool->workers) rsi_hot_destroy(c);
   delete pool;
 }
@@ -113,11 +163,9 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
       }
     }
   };
-  std::vector<std::thread> th;
-  for (size_t w = 1; w < pool->workers.size(); ++w) th.emplace_back(work, w);
-  work(0);
-  const double t_work = now_ms() - t_run0;
-  for (auto& t : th) t.join();
+  double t_work = 0;
+  const std::function<void(size_t)> job = [&](size_t w) { work(w); if (w == 0) t_work = now_ms() - t_run0; };
+  pool->run_on_all(job);
   if (trace) fprintf(stderr, "[trace] pool_run: own work done at %.2f ms, all workers joined at %.2f ms\n", t_work, now_ms() - t_run0);
   int worst = RSI_OK;
   for (int i = 0; i < nchrom; ++i) {
