@@ -178,24 +178,29 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const TD* __restrict
     ArgBest r{s_v[0], s_i[0]};
     for (int w = 1; w < kThreads / 64; ++w) r = arg_pick(r, ArgBest{s_v[w], s_i[w]}, want_max);
     const size_t slot = (size_t)jb * 2 * kEdgeChunks + blockIdx.x;
-    W.part_v[slot] = r.v; W.part_i[slot] = r.i; W.part_t[slot] = cur;
-    __threadfence();
+    // hand-over without fences (device_util.h): write-through stores, wait for them, then the arrival counter; the reader
+    // uses coherent loads.  An agent-scope fence here writes back the XCD's whole L2 -- in a pool that is other
+    // chromosomes' streaming output, and 1280 workgroups per launch each waited for it.
+    st_cg(reinterpret_cast<unsigned long long*>(&W.part_v[slot]), (unsigned long long)r.v);
+    st_cg(reinterpret_cast<unsigned int*>(&W.part_i[slot]), (unsigned int)r.i);
+    st_cg(reinterpret_cast<unsigned long long*>(&W.part_t[slot]), (unsigned long long)cur);
+    drain();
     s_last = atomicAdd(&W.done[jb], 1u) == 2 * kEdgeChunks - 1;
   }
   __syncthreads();
   if (s_last && threadIdx.x == 0) {   // every piece of this candidate is in: chain and fold them
-    __threadfence();
     ArgBest pick[2] = {{0, -1}, {0, -1}};
     for (int w = 0; w < 2; ++w) {
       const bool wmax = w == 0 ? del : !del;
       long long off = (long long)atomicAdd(&W.start_acc[jb * 2 + w], 0ull);   // dd at the window's first index
       for (int c = 0; c < kEdgeChunks; ++c) {
         const size_t a = (size_t)jb * 2 * kEdgeChunks + w * kEdgeChunks + c;
-        if (W.part_i[a] >= 0) {
-          const long long v = W.part_v[a] + off;
-          if (wmax ? v > 0 : v < 0) pick[w] = arg_pick(pick[w], ArgBest{v, W.part_i[a]}, wmax);
+        const int pi = (int)ld_cg(reinterpret_cast<const unsigned int*>(&W.part_i[a]));
+        if (pi >= 0) {
+          const long long v = (long long)ld_cg(reinterpret_cast<const unsigned long long*>(&W.part_v[a])) + off;
+          if (wmax ? v > 0 : v < 0) pick[w] = arg_pick(pick[w], ArgBest{v, pi}, wmax);
         }
-        off += W.part_t[a];
+        off += (long long)ld_cg(reinterpret_cast<const unsigned long long*>(&W.part_t[a]));
       }
       W.start_acc[jb * 2 + w] = 0;   // ready for the second call
     }
@@ -826,13 +831,11 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_hist(const CandJob* __res
   }
   __syncthreads();
   for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) { const unsigned c = s_hist[e]; if (c) atomicAdd(&ghist[e], c); }
-  __threadfence();
-  __syncthreads();
+  sync_drained();   // this workgroup's atomics have completed (no fence: device_util.h)
   if (threadIdx.x == 0) s_last = atomicAdd(&M.done, 1u) == kCandChunks - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = atomicAdd(&ghist[e], 0u);   // the folded histogram, read past the caches
+  for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = ld_cg(&ghist[e]);   // the folded histogram, read past the caches
   __syncthreads();
   int qb[3];
   hist_ranks(s_hist, (unsigned)nbk, (size_t)g.nwin, s_scan, s_q, qb);
