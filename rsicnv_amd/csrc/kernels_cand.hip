@@ -258,8 +258,13 @@ __device__ inline void walk_load16(const int32_t* __restrict__ A, int64_t N, lon
 template <typename TD>
 __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, int pos, int room /* slots left */,
                                   int32_t* __restrict__ dst, int first_slot, const int2* __restrict__ chain, int nchain,
-                                  int kind, double too_high, double too_low, WalkShared& W, int* reach, int* chain_used) {
+                                  int kind, double too_high, double too_low, WalkShared& W, int* reach, int* chain_used,
+                                  int* __restrict__ stage /* LDS, kWalkBlock ints: a trip's taken values in rank order */) {
   constexpr int kNone = 0x7fffffff;
+  // A thread's sixteen values have consecutive ranks, so a store of value j by the 64 lanes of a wave would touch 64 cache
+  // lines 64 bytes apart -- the walk spent most of its time in those stores.  The values go to LDS first (the rank's low
+  // four bits XORed with the lane's, which spreads a wave over the banks) and leave as consecutive dwords per wave.
+  auto swz = [](int r) { return r ^ ((r >> 4) & 15); };
   int stored = 0, ci = 0, trip = 0;
   int last = pos;
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -323,13 +328,17 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
     for (int j = 0; j < kWalkPer; ++j) {
       const int t = t0 + j;
       if (((accm >> j) & 1u) && t < tstar) {
-        if (rank < room) dst[first_slot + dir * (stored + rank)] = v[j];
+        if (rank < room) stage[swz(rank)] = v[j];
         if (fills && rank == room - 1) W.lastt[par] = t;      // the value that fills the last slot
         ++rank;
       }
     }
+    __syncthreads();
+    {
+      const int ncopy = total < room ? total : room;
+      for (int e = threadIdx.x; e < ncopy; e += blockDim.x) dst[first_slot + dir * (stored + e)] = stage[swz(e)];
+    }   // the next trip writes `stage` only behind its own exchange barrier, which every thread reaches after this loop
     if (fills) {   // the walk stops right after the value that filled the last slot
-      __syncthreads();
       last = pos + dir * (1 + W.lastt[par]);
       stored += room; room = 0;
       break;
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
   int lreach = J.start, rreach = J.end;
   int lcnt = 0, lused = 0, rused = 0;
   if (J.top >= 0)
-    lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
+    lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused, reinterpret_cast<int*>(s_hist));
   __syncthreads();
   // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
   const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
     if (lim - used0 < room) room = lim - used0;
     if (room < 0) room = 0;
   }
-  const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, ref, used0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused);
+  const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, ref, used0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused, reinterpret_cast<int*>(s_hist));
   __syncthreads();
   // a chain the host cut short was consumed to its end: the walk may have missed a neighbour
   if (((J.cut & 1) && lused >= J.nleft) || ((J.cut & 2) && rused >= J.nright)) O.flags |= 8;
@@ -642,6 +651,7 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_gather(const TD* __restri
                                                           const int2* __restrict__ chains, int32_t* __restrict__ iscratch,
                                                           long long* __restrict__ lscratch, double RDmedian, CandMid* __restrict__ mid) {
   __shared__ WalkShared W;
+  extern __shared__ int s_stage[];   // kWalkBlock ints: a trip's taken values on their way to coalesced stores
   const CandJob J = jobs[blockIdx.y];
   const CandBufs b = cand_buffers(J, iscratch, lscratch);
   const double too_high = RDmedian * 3.0, too_low = RDmedian * 0.15;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_gather(const TD* __restri
   if (blockIdx.x == 0) {
     int lreach = J.start, lused = 0, lcnt = 0;
     if (J.top >= 0)
-      lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, b.left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused);
+      lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, b.left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused, s_stage);
     if (threadIdx.x == 0) { M.lcnt = lcnt; M.lreach = lreach; M.lused = lused; }
   } else {
     // the right walk does not know yet how many slots the left one leaves: it fills as many as it could ever get
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_gather(const TD* __restri
     if (lim < room) room = lim;
     if (room < 0) room = 0;
     int rreach = J.end, rused = 0;
-    const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, b.right, 0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused);
+    const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, b.right, 0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused, s_stage);
     if (threadIdx.x == 0) { M.rcnt_max = rcnt; M.rreach = rreach; M.rused = rused; }
   }
 }
@@ -882,13 +892,16 @@ void launch_candidate_test_split(DepthRef d, int64_t ncompact, const CandJob* jo
                                  CandOut* outs, hipStream_t stream) {
   if (njobs <= 0) return;
   const size_t lds = (size_t)kCandHistBins * 4;
+  static_assert(kCandHistBins * 4 >= (unsigned)kWalkBlock * 4, "the walks stage a trip in the histogram's LDS");
+  RSI_ALLOW_FULL_LDS(k_cand_gather<int32_t>);
+  RSI_ALLOW_FULL_LDS(k_cand_gather<uint8_t>);
   RSI_ALLOW_FULL_LDS(k_cand_prefix<int32_t>);
   RSI_ALLOW_FULL_LDS(k_cand_prefix<uint8_t>);
   RSI_ALLOW_FULL_LDS(k_cand_hist);
   const int2* ch = static_cast<const int2*>(chains);
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_cand_gather<int32_t>, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid),
-    hipLaunchKernelGGL(k_cand_gather<uint8_t>, dim3(2, njobs), dim3(kTestThreads), 0, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid));
+    hipLaunchKernelGGL(k_cand_gather<int32_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid),
+    hipLaunchKernelGGL(k_cand_gather<uint8_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid));
   RSI_DEPTH_DISPATCH(d,
     hipLaunchKernelGGL(k_cand_prefix<int32_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid),
     hipLaunchKernelGGL(k_cand_prefix<uint8_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid));
