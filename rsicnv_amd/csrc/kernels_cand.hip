@@ -415,7 +415,13 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
   __syncthreads();
   // the reference closes the gap when the left side ran out of sequence, otherwise used = top + 1 (rsi.cpp:231-236)
   const int used0 = lcnt < J.top + 1 ? lcnt : J.top + 1;
-  for (int j = threadIdx.x; j < used0; j += kTestThreads) ref[j] = left[J.top + 1 - used0 + j];
+  for (int j0 = threadIdx.x; j0 < used0; j0 += 8 * kTestThreads) {   // eight independent loads per round
+    int x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int j = j0 + k * kTestThreads; x[k] = left[J.top + 1 - used0 + (j < used0 ? j : j0)]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int j = j0 + k * kTestThreads; if (j < used0) ref[j] = x[k]; }
+  }
   __syncthreads();
   int room = J.capacity - used0;
   {   // `used < 2*chklen*d` with the double right-hand side (rsi.cpp:243)
@@ -438,7 +444,13 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
     const int total = nref + nbody;
     const int tref = (int)((double)nref / (double)total * (double)J.budget);
     const int tbody = (int)((double)nbody / (double)total * (double)J.budget);
-    for (int q = threadIdx.x; q < tref; q += kTestThreads) thin[q] = ref[(int)((double)q / (double)tref * (double)nref)];
+    for (int q0 = threadIdx.x; q0 < tref; q0 += 8 * kTestThreads) {   // eight independent loads per round
+      int x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; x[k] = ref[(int)((double)(q < tref ? q : q0) / (double)tref * (double)nref)]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; if (q < tref) thin[q] = x[k]; }
+    }
     __syncthreads();
     R = thin; nref = tref; thin_body = true; nbody_eff = tbody;
   }
@@ -453,7 +465,13 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
   // ---- body statistics: integer histogram quantiles (partition_stat_tp with dy = 1), sum, sum of squares ----
   {
     int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
-    for (int q = threadIdx.x; q < width; q += kTestThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
+    for (int q0 = threadIdx.x; q0 < width; q0 += 8 * kTestThreads) {   // eight independent loads per round (see k_cand_prefix)
+      int x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; x[k] = body_at(q < width ? q : q0); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (q0 + k * kTestThreads < width) { lo = x[k] < lo ? x[k] : lo; hi = x[k] > hi ? x[k] : hi; s1 += x[k]; s2 += (long long)x[k] * x[k]; }
+    }
     lo = block_reduce(lo, [](int a, int b) { return a < b ? a : b; }, s_i2);
     hi = block_reduce(hi, [](int a, int b) { return a > b ? a : b; }, s_i2);
     s1 = block_reduce(s1, [](long long a, long long b) { return a + b; }, s_l);
@@ -466,7 +484,13 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
       else {
         for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
         __syncthreads();
-        for (int q = threadIdx.x; q < width; q += kTestThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
+        for (int q0 = threadIdx.x; q0 < width; q0 += 8 * kTestThreads) {
+          int x[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; x[k] = body_at(q < width ? q : q0); }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) if (q0 + k * kTestThreads < width) atomicAdd(&s_hist[x[k] - lo], 1u);
+        }
         __syncthreads();
         int qb[3];
         hist_ranks(s_hist, nbk, (size_t)width, W.s_scan, s_q, qb);
@@ -695,17 +719,21 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     int ce = cb + Lc; if (ce > g.nref) ce = g.nref;
     long long carry = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) b.P[0] = 0;
-    for (int t0 = cb; t0 < ce; t0 += 4 * kTestThreads) {
-      const int e = t0 + 4 * (int)threadIdx.x;
-      const int v0 = e < ce ? cand_value(J, g, b, e) : 0, v1 = e + 1 < ce ? cand_value(J, g, b, e + 1) : 0;
-      const int v2 = e + 2 < ce ? cand_value(J, g, b, e + 2) : 0, v3 = e + 3 < ce ? cand_value(J, g, b, e + 3) : 0;
-      const long long a1 = v0, a2 = a1 + v1, a3 = a2 + v2, a4 = a3 + v3;
+    // sixteen consecutive values per thread and round (sixteen independent loads, ONE block scan): with four per round the
+    // chunk's 62 000 values took sixteen rounds of barriers
+    constexpr int kPer = 16;
+    for (int t0 = cb; t0 < ce; t0 += kPer * kTestThreads) {
+      const int e = t0 + kPer * (int)threadIdx.x;
+      int v[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) v[k] = e + k < ce ? cand_value(J, g, b, e + k) : 0;
+      long long run = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) run += v[k];
       long long total;
-      const long long base = carry + block_exscan_i64(a4, s_l, &total);
-      if (e < ce) b.P[e + 1] = base + a1;
-      if (e + 1 < ce) b.P[e + 2] = base + a2;
-      if (e + 2 < ce) b.P[e + 3] = base + a3;
-      if (e + 3 < ce) b.P[e + 4] = base + a4;
+      long long at = carry + block_exscan_i64(run, s_l, &total);
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) { at += v[k]; if (e + k < ce) b.P[e + k + 1] = at; }
       carry += total;
     }
     if (threadIdx.x == 0) M.totals[blockIdx.x] = carry;
@@ -717,7 +745,15 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     return (int)(g.thin ? A[J.start + (int)((double)q / (double)g.nbody_eff * (double)g.nbody)] : A[J.start + q]);
   };
   int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
-  for (int q = threadIdx.x; q < width; q += kTestThreads) { const int x = body_at(q); lo = x < lo ? x : lo; hi = x > hi ? x : hi; s1 += x; s2 += (long long)x * x; }
+  // eight independent loads per thread and round: one after the other, each waiting for memory, the 200 000 values of a large
+  // candidate took 120 us through this one workgroup
+  for (int q0 = threadIdx.x; q0 < width; q0 += 8 * kTestThreads) {
+    int x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; x[k] = body_at(q < width ? q : q0); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (q0 + k * kTestThreads < width) { lo = x[k] < lo ? x[k] : lo; hi = x[k] > hi ? x[k] : hi; s1 += x[k]; s2 += (long long)x[k] * x[k]; }
+  }
   lo = block_reduce(lo, [](int a, int b2) { return a < b2 ? a : b2; }, s_i2);
   hi = block_reduce(hi, [](int a, int b2) { return a > b2 ? a : b2; }, s_i2);
   s1 = block_reduce(s1, [](long long a, long long b2) { return a + b2; }, s_l);
@@ -730,7 +766,13 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     else {
       for (unsigned e = threadIdx.x; e < nbk; e += kTestThreads) s_hist[e] = 0;
       __syncthreads();
-      for (int q = threadIdx.x; q < width; q += kTestThreads) atomicAdd(&s_hist[body_at(q) - lo], 1u);
+      for (int q0 = threadIdx.x; q0 < width; q0 += 8 * kTestThreads) {
+        int x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int q = q0 + k * kTestThreads; x[k] = body_at(q < width ? q : q0); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (q0 + k * kTestThreads < width) atomicAdd(&s_hist[x[k] - lo], 1u);
+      }
       __syncthreads();
       int qb[3];
       hist_ranks(s_hist, nbk, (size_t)width, s_scan, s_q, qb);
