@@ -824,6 +824,7 @@ __device__ inline bool seg_better(double s, int L, int j, double bs, int bL, int
   return j < bj;
 }
 
+constexpr int kBestLds = 6144;   // doubles of a run's prefix staged in LDS (48 KB)
 __global__ __launch_bounds__(kThreads) void k_best_subsegment(const SegItem* __restrict__ items,
                                                               const int64_t* __restrict__ poff,
                                                               const double* __restrict__ scratch, double tmedian,
@@ -833,12 +834,31 @@ __global__ __launch_bounds__(kThreads) void k_best_subsegment(const SegItem* __r
   const SegItem it = items ? items[blockIdx.x] : inl.it[blockIdx.x];
   const double* P = scratch + (poff ? poff[it.run] : (int64_t)inl.off[it.run]);
   double bs = -1.0; int bL = 0x7fffffff, bj = 0x7fffffff;
-  for (int L = it.Lbeg; L < it.Lend; ++L) {
-    const double dL = (double)L, sq = sqrt(dL);
-    for (int j = threadIdx.x; j + L <= it.len; j += kThreads) {
-      const double sum = P[j + L] - P[j];
-      const double score = fabs(sum / dL - tmedian) * sq;      // rsi.cpp:1084
-      if (seg_better(score, L, j, bs, bL, bj)) { bs = score; bL = L; bj = j; }
+  // The run's prefix sums in LDS when they fit (runs are a few thousand bins at most), four lengths per round so that the
+  // four window sums, divisions and comparisons of a thread overlap: from global memory, one (L, j) pair at a time, the
+  // loop waited for its two loads in every iteration.
+  __shared__ double s_P[kBestLds];
+  const bool staged = it.len + 1 <= kBestLds;
+  if (staged) for (int e = threadIdx.x; e <= it.len; e += kThreads) s_P[e] = P[e];
+  __syncthreads();
+  const double* Q = staged ? s_P : P;
+  for (int L0 = it.Lbeg; L0 < it.Lend; L0 += 4) {
+    double dL[4], sq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { dL[u] = (double)(L0 + u); sq[u] = sqrt(dL[u]); }
+    for (int j = threadIdx.x; j + L0 <= it.len; j += kThreads) {
+      const double pj = Q[j];
+      double sum[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int L = L0 + u; sum[u] = (L < it.Lend && j + L <= it.len) ? Q[j + L] - pj : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int L = L0 + u;
+        if (L < it.Lend && j + L <= it.len) {
+          const double score = fabs(sum[u] / dL[u] - tmedian) * sq[u];      // rsi.cpp:1084
+          if (seg_better(score, L, j, bs, bL, bj)) { bs = score; bL = L; bj = j; }
+        }
+      }
     }
   }
   s_s[threadIdx.x] = bs; s_L[threadIdx.x] = bL; s_j[threadIdx.x] = bj;
