@@ -90,23 +90,24 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_sums(const float* __restr
 // Pass 2 (one workgroup): exclusive prefixes over the chunks.
 __global__ __launch_bounds__(kThreads) void k_fs_chunk_scan(double* __restrict__ csum, int32_t* __restrict__ cmark, int nchunks,
                                                             int32_t* __restrict__ total_marked) {
-  __shared__ double s_d[kThreads];
-  __shared__ int s_m[kThreads];
+  __shared__ double s_d[kThreads / 64];
+  __shared__ int s_m[kThreads / 64];
   double cd = 0.0;
   int cm = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int t0 = 0; t0 < nchunks; t0 += kThreads) {
     const int t = t0 + (int)threadIdx.x;
     const double v = t < nchunks ? csum[t] : 0.0;
     const int m = t < nchunks ? cmark[t] : 0;
-    s_d[threadIdx.x] = v; s_m[threadIdx.x] = m;
+    double id = v; int im = m;   // inclusive wave scans (the double sums are bounds for the candidate binades, not results)
+    for (int d = 1; d < 64; d <<= 1) { const double ud = __shfl_up(id, d); const int um = __shfl_up(im, d); if (lane >= d) { id += ud; im += um; } }
+    __syncthreads();   // the previous batch's totals have been read
+    if (lane == 63) { s_d[wave] = id; s_m[wave] = im; }
     __syncthreads();
-    double pd = 0.0; int pm = 0;
-    for (int k = 0; k < (int)threadIdx.x; ++k) { pd += s_d[k]; pm += s_m[k]; }   // 256 x 128 adds: nothing next to the passes over the bins
-    double td = 0.0; int tm = 0;
-    for (int k = 0; k < kThreads; ++k) { td += s_d[k]; tm += s_m[k]; }
-    if (t < nchunks) { csum[t] = cd + pd; cmark[t] = cm + pm; }
+    double pd = 0.0, td = 0.0; int pm = 0, tm = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { if (w < wave) { pd += s_d[w]; pm += s_m[w]; } td += s_d[w]; tm += s_m[w]; }
+    if (t < nchunks) { csum[t] = cd + pd + id - v; cmark[t] = cm + pm + im - m; }
     cd += td; cm += tm;
-    __syncthreads();
   }
   if (threadIdx.x == 0) total_marked[0] = cm;
 }
@@ -332,10 +333,15 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
       float s = 0.0f;
       int cnt = 0, qn = 0;
       if (!bad && level_count[li] != 0) {
-        for (int k0 = 0; k0 < M; k0 += 64 * 8) {   // eight loads in flight per lane, then the eight 64-entry steps in order
+        int nxt[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int e = 64 * j + lane; nxt[j] = e < M ? clist_s[e] : 0; }   // 0 is never a marked level
+        for (int k0 = 0; k0 < M; k0 += 64 * 8) {   // eight loads in flight per lane, one batch ahead of the eight 64-entry steps
           int key[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { const int e = k0 + 64 * j + lane; key[j] = e < M ? clist_s[e] : 0; }   // 0 is never a marked level
+          for (int j = 0; j < 8; ++j) key[j] = nxt[j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int e = k0 + 64 * 8 + 64 * j + lane; nxt[j] = e < M ? clist_s[e] : 0; }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const bool hit = key[j] == l;
