@@ -227,7 +227,6 @@ constexpr int kGcMaxSubPerWg = 256;                   // 2^18 bases per workgrou
 
 struct WaveGc {            // per-wave LDS slot
   uint64_t word[kSubLds + 2];
-  uint32_t pre[kSubLds + 2];
 };
 
 // GC bases among the 201 starting at bit `lo` of the mask (0 <= lo, lo + 201 <= number of bits): popcounts of the four or
@@ -244,10 +243,16 @@ __device__ inline int gc_window_count(const uint64_t* __restrict__ gcbits, int64
   }
   return g;
 }
-__device__ inline uint32_t wgc_rank(const WaveGc& t, uint32_t rel) {
+// GC bases among the 201 from staged bit `rel` on: popcounts of the five words the window can touch, all five reads
+// independent.  (The first version kept a popcount prefix per wave and took two rank queries; building the prefix -- five
+// dependent cross-lane steps per sub-tile -- was on the critical path of every trip of K2 and K3'.)
+__device__ inline uint32_t wgc_window(const WaveGc& t, uint32_t rel) {
   const uint32_t k = rel >> 6, b = rel & 63;
-  const uint64_t m = b ? (t.word[k] & ((1ull << b) - 1)) : 0;
-  return t.pre[k] + (uint32_t)__popcll(m);
+  const uint64_t w0 = t.word[k], w1 = t.word[k + 1], w2 = t.word[k + 2], w3 = t.word[k + 3], w4 = t.word[k + 4];
+  const uint32_t rem = 9 + b;                                   // bits of the window behind the first three words: 9 .. 72
+  const uint64_t m3 = rem >= 64 ? ~0ull : ((1ull << rem) - 1);
+  const uint64_t m4 = rem > 64 ? ((1ull << (rem - 64)) - 1) : 0ull;
+  return (uint32_t)(__popcll(w0 >> b) + __popcll(w1) + __popcll(w2) + __popcll(w3 & m3) + __popcll(w4 & m4));
 }
 __device__ inline uint32_t wgc_field16(const WaveGc& t, uint32_t rel) {
   const uint32_t k = rel >> 6, b = rel & 63;
@@ -302,14 +307,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restri
   auto trip = [&](const SubRegs& cur, SubRegs& nxt, int64_t sub) {
     const int64_t base = sub * kSubBases;
     const int64_t first_bit = base - kGcLeft * 64;
-    // ---- commit this sub-tile's GC words + popcount prefix to the wave's LDS slot ----
+    // ---- commit this sub-tile's GC words to the wave's LDS slot ----
     {
       const int64_t w = base / 64 - kGcLeft + lane;
       const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
-      uint32_t c = __popcll(word), incl = c;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane < kSubLds + 1) { G.word[lane] = word; G.pre[lane] = incl - c; }
+      if (lane < kSubLds + 1) G.word[lane] = word;
     }
     if (sub + stride < nsub) sub_request(nxt, depth, gcbits, nwords, (sub + stride) * kSubBases, n, lane);
     __builtin_amdgcn_wave_barrier();
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restri
     const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102;   // no edge clamping in this sub-tile
     if (interior) {
       const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
-      cnt0 = wgc_rank(G, rel + 201) - wgc_rank(G, rel);
+      cnt0 = wgc_window(G, rel);
       leave = wgc_field16(G, rel); enter = wgc_field16(G, rel + 201);
     } else {
       cnt0 = leave = enter = 0;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restri
         if (lo > n - 202) lo = n - 202;
         const uint32_t rel = (uint32_t)(lo - first_bit);
         const int val = depth[i];
-        add(val, wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+        add(val, wgc_window(G, rel));
         if (d8) { d8[i] = (uint8_t)sat8(val); escapes += val >= kByteEscape; }
       }
     }
@@ -783,10 +785,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
     {
       const int64_t w = base / 64 - kGcLeft + lane;
       const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
-      uint32_t c = __popcll(word), incl = c;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane < kSubLds + 1) { G.word[lane] = word; G.pre[lane] = incl - c; }
+      if (lane < kSubLds + 1) G.word[lane] = word;
     }
     if (sub + stride < nsub) sub8_request(nxt, d8, gcbits, nwords, (sub + stride) * kSubBases, lane);
     __builtin_amdgcn_wave_barrier();
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
     const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102 && base + kSubBases <= whole;
     if (interior) {
       const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
-      uint32_t cnt = wgc_rank(G, rel + 201) - wgc_rank(G, rel);
+      uint32_t cnt = wgc_window(G, rel);
       const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
       const uint32_t w4[4] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
       const bool esc = has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3]);
@@ -850,7 +849,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
         if (lo < 0) lo = 0;
         if (lo > n - 202) lo = n - 202;
         const uint32_t rel = (uint32_t)(lo - first_bit);
-        const int ve = rescale(depth[i], wgc_rank(G, rel + 201) - wgc_rank(G, rel));
+        const int ve = rescale(depth[i], wgc_window(G, rel));
         value_hist_add(s_hist, ghist, aux, ve, phase);
         lane_hi = ve > lane_hi ? ve : lane_hi;
         out8[i] = (uint8_t)(ve > kByteSat ? kByteSat : ve);
