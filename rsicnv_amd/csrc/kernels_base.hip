@@ -20,6 +20,7 @@ constexpr int kGcLeft = 4;                 // margin words left of the tile (256
 constexpr int kGcRight = 2;                // margin words right of the tile (128 bits >= 101)
 constexpr int kGcLds = kGcLeft + kGcWords + kGcRight;   // 70
 
+constexpr int kK3Width = 512, kK3PhaseShift = 4, kK3Phases = 1 << kK3PhaseShift;   // K3': its LDS value histogram is [512 values][16 lane phases]
 constexpr int kValLds = 256;               // K3 / K3': values below this are counted in LDS, [value][32 lane phases]
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
@@ -759,7 +760,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
   __shared__ WaveGc s_gc[kThreads / 64];
   __shared__ double s_table[kGcLevels];
   __shared__ float s_ratio[kGcLevels];
-  __shared__ unsigned int s_hist[kValLds * 32];
+  // [512 values][16 lane phases]: a GC level with an odd mean (a stretch of lower-case sequence next to N runs: table[0] =
+  // 3.2 where the depth is 21) rescales its bases by 9 -- past 255, where every value used to be a global atomic on one of
+  // a few hundred words: 0.2 % of a chromosome's bases cost the kernel 40 % more time.
+  __shared__ unsigned int s_hist[kK3Width * kK3Phases];
   // Deep coverage: most bases did not fit K2's byte copy.  Nothing to do here but hand the header (with that count) to the
   // host, which sends the chromosome through the int32 kernels instead (per_base_phase).
   if (escapes[0] > escape_limit) {
@@ -767,12 +771,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
     return;
   }
   const double rdmean = table[kGcLevels];
-  for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kK3Width * kK3Phases; e += kThreads) s_hist[e] = 0;
   for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(rdmean / t); }
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   WaveGc& G = s_gc[wave];
-  const int phase = lane & 31;
+  const int phase = lane & (kK3Phases - 1);
   int lane_hi = 0;   // largest value this lane sent past the LDS range
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
   const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
@@ -834,12 +838,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
         }
         *reinterpret_cast<uint4*>(out8 + i0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
       }
-      if (ored < (unsigned)kValLds) {   // the common case, branch-free: sixteen LDS atomics into [value][lane phase]
+      if (ored < (unsigned)kK3Width) {   // the common case, branch-free: sixteen LDS atomics into [value][lane phase]
 #pragma unroll
-        for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * 32 + phase], 1u);
+        for (int j = 0; j < 16; ++j) atomicAdd(&s_hist[v[j] * kK3Phases + phase], 1u);
       } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { value_hist_add(s_hist, ghist, aux, v[j], phase); lane_hi = v[j] > lane_hi ? v[j] : lane_hi; }
+        for (int j = 0; j < 16; ++j) { value_hist_add(s_hist, ghist, aux, v[j], phase, 0, kK3Width, kK3PhaseShift); lane_hi = v[j] > lane_hi ? v[j] : lane_hi; }
       }
     } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only, straight from the int32 array
       for (int j = 0; j < 16; ++j) {
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
         if (lo > n - 202) lo = n - 202;
         const uint32_t rel = (uint32_t)(lo - first_bit);
         const int ve = rescale(depth[i], wgc_window(G, rel));
-        value_hist_add(s_hist, ghist, aux, ve, phase);
+        value_hist_add(s_hist, ghist, aux, ve, phase, 0, kK3Width, kK3PhaseShift);
         lane_hi = ve > lane_hi ? ve : lane_hi;
         out8[i] = (uint8_t)(ve > kByteSat ? kByteSat : ve);
       }
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
   }
   __syncthreads();
   publish_hist_hi(lane_hi, aux);
-  value_hist_finish<true>(s_hist, depth, gcbits, n, table, nullptr, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes);
+  value_hist_finish<true>(s_hist, depth, gcbits, n, table, nullptr, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, 0, kK3Width, kK3PhaseShift);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1419,7 +1423,7 @@ static int value_hist8_grid(int64_t n) {
   if (grid > 256 * 4) grid = 256 * 4;
   return (int)(grid < 1 ? 1 : grid);
 }
-size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kValLds * 4; }
+size_t value_hist8_slab_bytes(int64_t n) { return (size_t)value_hist8_grid(n) * kK3Width * 4; }
 void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                         uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum, unsigned int* counters, ValueMedian* vm,
                         const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8, const unsigned int* escapes,
