@@ -429,6 +429,29 @@ def test_deep_coverage_sends_tests_to_the_host_walk(hot, hotlib, oracle_cls):
     assert len(res.calls("calls")) > 0
 
 
+def test_gc_level_with_a_tiny_mean_rescales_past_the_lds_histograms(hot, hotlib, oracle_cls):
+    """A soft-masked stretch shares GC level 0 with the N runs; give it a depth of 8 with a sprinkle of 200s and the level's mean
+    is ~1.7, its bases are rescaled by ~16: values in the thousands from BYTE depths -- past K3''s 512-value LDS histogram
+    (global atomics), saturated in the byte copy, capped by K4'.  Everything must still equal the oracle's arrays."""
+    import oracle
+    from rsicnv_amd import api
+    plan, fasta, depth = make_case(hotlib, dict(n=1_600_003, seed=0x7199, model=1, n_events=6, gaps=1, max_len=30000, end_n=4000, gap_len=9000))
+    (a, b), = [tuple(x) for x in plan["lower"]][:1]
+    depth = depth.copy()
+    depth[a:b] = 8
+    depth[a:b:97] = 200
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    rd_gc = hot.fetch("rd_gc")
+    assert rd_gc.max() >= 512, rd_gc.max()              # the case does what it says
+    assert np.array_equal(rd_gc, O.i32("rd_gc"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert res.stats["RDmedian"] == O.f64("chrom")[0]
+    ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
+    assert ok, why
+
+
 @pytest.mark.parametrize("model", [0, 1])
 def test_300x_coverage_takes_the_int32_kernels(hot, hotlib, oracle_cls, model):
     """At 300x hardly a base fits K2's byte copy: K3' hands over, the int32 rescale (LDS histogram anchored at the mean depth)
