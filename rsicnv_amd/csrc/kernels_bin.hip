@@ -98,7 +98,9 @@ __global__ __launch_bounds__(kThreads) void k_minmax_f32(const float* __restrict
                                                          int64_t nb, int use_abs, double center, MinMaxF* __restrict__ mm) {
   minmax_body(x, mask, nb, use_abs, center, mm);
 }
-constexpr uint32_t kLdsBins = 32768;   // 128 KB of LDS counters (one workgroup per CU): covers a value range of 327
+constexpr uint32_t kLdsBins = 12288;   // 48 KB of LDS counters: covers a value range of 122 from the minimum; the buckets behind go
+                                       // to global atomics (few values live there).  With 128 KB the kernel only fitted on a CU no per-base
+                                       // kernel of another chromosome was resident on, and waited for one: covers a value range of 327
 
 // Each thread takes kHistRun consecutive elements and merges equal neighbouring buckets before the
 // atomic: bin medians (-MED) are small integers, so long runs land in one bucket and a plain
@@ -108,7 +110,8 @@ constexpr int kHistRun = 8;
 __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int32_t* __restrict__ mask, int64_t nb, int use_abs,
                                           double center, double ymin, uint32_t* __restrict__ hist, uint32_t np, int use_lds,
                                           unsigned int* s_h) {
-  if (use_lds) { for (uint32_t e = threadIdx.x; e < np; e += kThreads) s_h[e] = 0; __syncthreads(); }
+  const uint32_t nl = use_lds ? (np < (uint32_t)use_lds ? np : (uint32_t)use_lds) : 0;   // buckets counted in LDS (use_lds = how many fit)
+  if (use_lds) { for (uint32_t e = threadIdx.x; e < nl; e += kThreads) s_h[e] = 0; __syncthreads(); }
   const int64_t nchunks = (nb + kHistRun - 1) / kHistRun;
   for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
     uint32_t pend_k = 0xffffffffu, pend_c = 0;
@@ -120,16 +123,16 @@ __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int
       uint32_t k = (uint32_t)(unsigned long long)idx;
       if (k >= np) k = np - 1;                                 // cannot happen (np = range/dy + 2)
       if (k != pend_k) {
-        if (pend_c) { if (use_lds) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+        if (pend_c) { if (pend_k < nl) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
         pend_k = k; pend_c = 0;
       }
       ++pend_c;
     }
-    if (pend_c) { if (use_lds) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+    if (pend_c) { if (pend_k < nl) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
   }
   if (use_lds) {
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < np; e += kThreads) { const unsigned int c = s_h[e]; if (c) atomicAdd(&hist[e], c); }
+    for (uint32_t e = threadIdx.x; e < nl; e += kThreads) { const unsigned int c = s_h[e]; if (c) atomicAdd(&hist[e], c); }
   }
 }
 
@@ -241,12 +244,12 @@ __global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict_
                                                         int64_t nb, int use_abs, double center,
                                                         const double* __restrict__ center_ptr,
                                                         GridMedian* __restrict__ g, uint32_t* __restrict__ hist,
-                                                        unsigned int* __restrict__ counter, ExportPair ex, FillList fill) {
+                                                        unsigned int* __restrict__ counter, ExportPair ex, FillList fill, uint32_t lds_bins) {
   extern __shared__ unsigned int s_h[];
   fill_ranges(fill);   // for the kernels behind this one (the scan's first-L arrays, its counters)
   if (!g->flags) {
     const uint32_t np = g->np;
-    hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, np <= kLdsBins, s_h);
+    hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, (int)lds_bins, s_h);   // the first lds_bins buckets in LDS
   }
   if (!last_block_done(counter)) return;
   if (!g->flags) grid_walk_block(hist, g);
@@ -899,8 +902,8 @@ void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_
 }
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin, uint32_t* hist,
                      uint32_t np, hipStream_t stream) {
-  const int use_lds = np <= kLdsBins;
-  const size_t lds = use_lds ? (size_t)np * 4 : 0;
+  const int use_lds = (int)kLdsBins;   // the first kLdsBins buckets in LDS, the rest through global atomics
+  const size_t lds = (size_t)(np < kLdsBins ? np : kLdsBins) * 4;
   RSI_ALLOW_FULL_LDS(k_hist_f32);
   // few, long-lived workgroups: every one flushes np counters at the end
   int grid = grid_for(nb, kThreads * kHistRun * 8);
@@ -914,7 +917,8 @@ void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use
 }
 void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
                       const GridChain& c, GridMedian* out, const GridExport* ex, const FillList* fill, hipStream_t stream) {
-  const size_t lds = (size_t)kLdsBins * 4;
+  const uint32_t bins = kLdsBins;
+  const size_t lds = (size_t)bins * 4;
   RSI_ALLOW_FULL_LDS(k_hist_walk);
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
@@ -922,7 +926,7 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
   if (ex) for (int k = 0; k < 2; ++k) { e.src[k] = ex->src[k]; e.dst[k] = ex->dst[k]; e.bytes[k] = (unsigned int)ex->bytes[k]; }
   FillList f{};
   if (fill) f = *fill;
-  hipLaunchKernelGGL(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f);
+  hipLaunchKernelGGL(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
