@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
 // out: [2 Lmax + 1] float sums then [2 Lmax + 1] int counts (index = level + Lmax); the workgroup that finishes last copies
 // them to mapped host memory.  A count of -1 at the unmarked level tells the host to do the sums itself (more marked bins
 // than the compact list holds, or a negative / non-finite value: the integer-step argument needs x >= 0).
-constexpr int kFnBatch = 768;
+constexpr int kFnBatch = 512;   // 20 KB: the kernel fits on a CU next to three K3' workgroups
 __device__ inline bool fs_apply(float& s, int ue, StepFn f) {   // one step of a function valid for unit exponent ue; false: not applicable
   const uint32_t bits = __float_as_uint(s);
   const int ex = (int)((bits >> 23) & 0xff);
