@@ -167,8 +167,25 @@ static void bam_checks(const char* path) {
   remove(tmp.c_str());
 }
 
+// IntSpan's sparse form (the status array inside the marked runs only, as the pipeline hands it to the block tests) against the
+// dense array it stands for: every index inside a range, at its ends, between ranges and outside all of them.
+static void span_checks() {
+  std::vector<int> dense(5000, 0), values;
+  std::vector<rsih::IntSpan::Range> ranges;
+  const int bounds[][2] = {{0, 0}, {7, 19}, {20, 20}, {100, 1099}, {4990, 4999}};
+  int v = 1;
+  for (const auto& b : bounds) {
+    ranges.push_back({b[0], b[1], (int64_t)values.size()});
+    for (int i = b[0]; i <= b[1]; ++i) { dense[(size_t)i] = (v % 7) - 3 ? (v % 7) - 3 : 5; values.push_back(dense[(size_t)i]); ++v; }
+  }
+  const rsih::IntSpan sparse(values.data(), (int64_t)dense.size(), &ranges), full(dense);
+  for (int64_t i = 0; i < (int64_t)dense.size(); ++i) CHECK(sparse[i] == full[i], "sparse span differs from the dense array");
+  CHECK(sparse.at(100)[999] == dense[1099] && *sparse.at(4999) == dense[4999] && *sparse.at(50) == 0, "sparse span: at()");
+}
+
 int main(int argc, char** argv) {
   quantile_checks();
+  span_checks();
   orc_params P;
   orc_default_params(&P);
   candidate_stage_case(0x5A11, 400007, 0, P);
