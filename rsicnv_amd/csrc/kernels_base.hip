@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
       uint32_t ssum = 0;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const int d = d0 + part + 4 * i;
+        const int d = d0 + part + parts * i;
         const uint32_t v = w[d <= d1 ? d : d1];
         const int lo_cut = B - 4 * d, hi_cut = 4 * d + 4 - (B + m);          // bytes of the dword before / after the bin
         uint32_t keep = 0xffffffffu;
@@ -1298,32 +1298,43 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
       }
       if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
-    } else {
-    const unsigned char* x = s_val + b_local * m;
-    int lo = 0x7fffffff, hi = (int)0x80000000;
-    int ssum = 0;
-    int r[EPT];
+    } else if (EPT == 0) {
+      // Caps of 128 .. 253 (a byte has no spare bit): the same scheme on 16-bit fields, two values to a register -- bytes 0
+      // and 2 of a dword in one, bytes 1 and 3 in another, bit 15 of every field as the guard.  #{x > mid} of four values is
+      // two subtractions and two popcounts; eight bisection steps from [0, cap].
+      const int B = b_local * m;
+      const int d0 = B >> 2, d1 = (B + m - 1) >> 2;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(s_val);
+      uint32_t xa[7], xc[7];
+      uint32_t ssum = 0;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int j = part + parts * i;
-      const bool in = active && j < m;
-      const int val = in ? (int)x[j] : 0x7fffffff;   // slots past the bin hold INT_MAX (never <= mid)
-      r[i] = val;
-      lo = (in && val < lo) ? val : lo; hi = (in && val > hi) ? val : hi; ssum += in ? val : 0;
-    }
-    for (int d = 1; d < parts; d <<= 1) {
-      const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d), os = __shfl_xor(ssum, d);
-      lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; ssum += os;
-    }
-    while (__any(active && lo < hi)) {   // bisection on the value: smallest v with #{x <= v} >= kth
-      const int mid = (lo + hi) >> 1;
-      int c = 0;
+      for (int i = 0; i < 7; ++i) {
+        const int d = d0 + part + parts * i;
+        const uint32_t v = w[d <= d1 ? d : d1];
+        const int lo_cut = B - 4 * d, hi_cut = 4 * d + 4 - (B + m);          // bytes of the dword before / after the bin
+        uint32_t keep = 0xffffffffu;
+        keep = lo_cut > 0 ? keep << (8 * lo_cut) : keep;
+        keep = hi_cut > 0 ? keep & (0xffffffffu >> (8 * hi_cut)) : keep;
+        keep = (d <= d1 && active) ? keep : 0u;
+        ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
+        const uint32_t xb = v | ~keep;                                       // bytes outside the bin: 0xff, above every mid
+        xa[i] = (xb & 0x00ff00ffu) | 0x80008000u;
+        xc[i] = ((xb >> 8) & 0x00ff00ffu) | 0x80008000u;
+      }
+      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      int lo = 0, hi = capval;
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t sub = (uint32_t)(mid + 1) * 0x00010001u;
+        int gt = 0;
 #pragma unroll
-      for (int i = 0; i < EPT; ++i) c += r[i] <= mid;
-      for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
-      if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
-    }
-    if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+        for (int i = 0; i < 7; ++i) gt += __popc((xa[i] - sub) & 0x80008000u) + __popc((xc[i] - sub) & 0x80008000u);
+        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        const int le = 4 * 7 * parts - gt;   // masked bytes (0xff) always count as "> mid" (mid <= 252)
+        if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
+      }
+      if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
     }
   }
   __syncthreads();
@@ -1450,10 +1461,14 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact, int vbase
 }
 // K4' applies when the cap keeps every value in a byte below the escape code and the bin fits the register median phase.
 int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteSat && m <= 104 ? 1 : 0; }
+// Bins per tile: 64 with four threads per bin; 128 with two threads per bin for small bins (m <= 52: a bin is at most 14 dwords,
+// seven per thread), so that a tile still holds ~6500 values -- at -m 51 tiles of 64 bins were half as long, twice as many
+// barriers and median phases per base.
+static int k48_bins_per_tile(int m) { return m <= 52 ? 128 : 64; }
 static void k48_geometry(int m, int32_t capval, int64_t ncompact, int& vr, int& grid, int& maxc) {
   vr = 64;
   while (vr < 256 && vr <= capval) vr <<= 1;
-  const int64_t tile = (int64_t)64 * m;
+  const int64_t tile = (int64_t)k48_bins_per_tile(m) * m;
   const int64_t ntiles = (ncompact + tile - 1) / tile;
   grid = (int)(ntiles < 256 * 4 ? (ntiles < 1 ? 1 : ntiles) : 256 * 4);   // 3, 5 or 6 per CU: 2-5 % slower
   maxc = tile / 16 <= kThreads ? 1 : 2;
@@ -1469,7 +1484,7 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
   int vr, grid, maxc;
   k48_geometry(m, capval, ncompact, vr, grid, maxc);
-  const int TB = 64;
+  const int TB = k48_bins_per_tile(m);
   const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
@@ -1480,11 +1495,9 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
                        cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
                        exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
   const bool sw7 = capval <= 127;   // four values to a register in the median phase (k_cap_compact_bin8, SW7)
+  (void)ept;
   if (sw7) { if (maxc == 1) RSI_K48(1, 1, true); else RSI_K48(2, 1, true); }
-  else if (maxc == 1 && ept <= 13) RSI_K48(1, 13, false);
-  else if (ept <= 13) RSI_K48(2, 13, false);
-  else if (maxc == 1) RSI_K48(1, 26, false);
-  else RSI_K48(2, 26, false);
+  else { if (maxc == 1) RSI_K48(1, 0, false); else RSI_K48(2, 0, false); }   // caps of 128 .. 253: two values to a register (EPT = 0)
 #undef RSI_K48
 }
 unsigned int byte_escape_limit(int64_t n) { return (unsigned int)(n >> 3 > 0xffffffffll ? 0xffffffffll : n >> 3); }
