@@ -208,8 +208,9 @@ void rsi_hot_set_timing(rsi_ctx* ctx, int on);
 
 /* ---- Pool: several chromosomes in flight on one GPU ------------------------------------------
  * The reference's per-chromosome loop (rsi.cpp:2189-2217) has independent iterations.  A pool owns
- * `nworkers` host threads, each with its own context (stream + workspace); rsi_pool_run hands the
- * chromosomes out longest first (the first `nworkers` to fixed workers).  At most two HBM-bound
+ * `nworkers` host threads (created with the pool, asleep between runs; worker 0 is the calling thread), each with its
+ * own context (stream + workspace); rsi_pool_run hands the chromosomes out longest first (the first `nworkers` to fixed
+ * workers).  One rsi_pool_run at a time per pool; several pools (one per GPU, or per host thread) are independent.  At most two HBM-bound
  * per-base phases are in flight per GPU (rsi_pool_set_schedule); bin-level and candidate kernels,
  * copies and the host stages of different chromosomes overlap. */
 typedef struct rsi_pool rsi_pool;
