@@ -5,6 +5,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+// The hand-over protocol below (write-through `sc1` stores, `s_waitcnt vmcnt(0)` as "my stores are done", hand-written
+// `global_load_dwordx4 ... sc1`) is correct on the cache behaviour of gfx942 / gfx950 only: on gfx10 and later stores count in
+// vscnt, not vmcnt, and the asm does not assemble or, worse, races silently.  The library is written for gfx950 alone.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "librsi_hot's fence-free hand-over (device_util.h) is only valid on gfx942 / gfx950: build with --offload-arch=gfx950"
+#endif
 
 namespace rsik {
 
@@ -18,7 +27,11 @@ struct FillList {
   int n;
 };
 inline void fill_add(FillList& f, void* p, size_t bytes, unsigned int value) {   // host side; bytes rounded up to 16
-  if (!p || bytes == 0 || f.n >= kFillMax) return;
+  if (!p || bytes == 0) return;
+  if (f.n >= kFillMax) {   // a dropped range = stale counters behind it (wrong medians, a hand-over that never completes): never silent
+    fprintf(stderr, "librsi_hot: FillList overflow (more than %d ranges): raise kFillMax\n", kFillMax);
+    abort();
+  }
   f.p[f.n] = p; f.units[f.n] = (bytes + 15) / 16; f.value[f.n] = value; ++f.n;
 }
 
@@ -42,7 +55,14 @@ __device__ inline void fill_ranges(const FillList& f) {
 // stores on this target), the workgroup meets at a barrier, and only then does one lane bump the arrival counter; the
 // reader uses ld_cg (agent-scope load).  Plain loads of data other workgroups of the same launch wrote with plain stores
 // are NOT safe and not used.
+// -DRSI_HOT_FENCES=1 (make FENCES=1 -> librsi_hot_fences.so) is the debug form: every drain also runs a full agent-scope
+// fence (write-back + invalidate), i.e. the textbook release / acquire on both sides of every hand-over, for A/B validation of
+// results against the fence-free build (RSI_HOT_LIB selects the library; tools/ab_bench.py compares two in one process).
+#if defined(RSI_HOT_FENCES) && RSI_HOT_FENCES
+__device__ inline void drain() { __builtin_amdgcn_s_waitcnt(0); __threadfence(); }
+#else
 __device__ inline void drain() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's memory operations are done
+#endif
 // barrier after which every thread of the workgroup may ld_cg what any of its threads wrote with st_cg / atomics before it
 __device__ inline void sync_drained() { drain(); __syncthreads(); }
 __device__ inline void st_cg(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

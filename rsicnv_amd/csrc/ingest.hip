@@ -67,6 +67,7 @@ int rsi_hot_load_depth_text(rsi_ctx* ctx, const char* path, int64_t n, rsi_text_
   struct stat sb;
   if (fstat(fd, &sb) != 0) return fail(ctx, RSI_ERR_BAD_ARG, std::string("Cannot stat file ") + path);
   st->bytes = (int64_t)sb.st_size;
+  if (!ctx_enter(ctx)) return RSI_ERR_HIP;
   mailbox_reset(ctx);
   HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
   HIPCHK(hipMemsetAsync(ctx->in_depth.p, 0, (size_t)n * 4, ctx->stream));
@@ -200,6 +201,8 @@ int rsi_hot_load_depth_bam(rsi_ctx* ctx, const char* bam_path, const char* chrom
   st->tid = tid; st->n = n;
   uint64_t idx_off = 0;
   if (rsih::bai_first_offset(std::string(bam_path) + ".bai", tid, idx_off)) { voff = idx_off; st->indexed = 1; }
+
+  if (!ctx_enter(ctx)) return RSI_ERR_HIP;
 
   mailbox_reset(ctx);
   HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));

@@ -10,6 +10,20 @@
 
 namespace rsik {
 
+// A rejected launch (too much dynamic LDS, a bad grid) raises no error where it happens: the wrappers below return nothing.
+// Every launch of the library therefore goes through RSI_LAUNCH, which reads the runtime's last error right behind the launch
+// and keeps the first failure in a thread-local slot; the pipeline's next wait (ctx_sync) collects it.  A context's launches all
+// come from the thread that runs it, and the entry points drain whatever the host application's own calls left in the runtime's
+// slot before the first launch (drain_stale_errors), so only this library's launches are attributed to a run.
+inline thread_local hipError_t tl_launch_error = hipSuccess;
+inline void note_launch() {
+  const hipError_t e = hipGetLastError();   // cleared by the read
+  if (e != hipSuccess && tl_launch_error == hipSuccess) tl_launch_error = e;
+}
+inline void drain_stale_errors() { (void)hipGetLastError(); tl_launch_error = hipSuccess; }
+inline hipError_t take_launch_error() { const hipError_t e = tl_launch_error; tl_launch_error = hipSuccess; return e; }
+#define RSI_LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); rsik::note_launch(); } while (0)
+
 constexpr int kGcLevels = 202;        // window GC count 0..201 (gccontent.cpp:102, 115)
 constexpr int kHistValues = 65536;    // directly indexed integer histogram range
 constexpr int kResClasses = 32;       // 31 MAD residues (rsi.cpp:1130) + 1 class for the tail

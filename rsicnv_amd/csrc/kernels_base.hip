@@ -1361,7 +1361,7 @@ void report_attribute_failure(const char* kernel, const char* what) {
 }
 void launch_fasta_classify(const uint8_t* fasta, int64_t n, uint64_t* gcbits, uint64_t* nbits, int64_t nwords,
                            const FillList& fill, hipStream_t stream) {
-  hipLaunchKernelGGL(k_fasta_classify, dim3(grid_for(nwords * 4, kThreads)), dim3(kThreads), 0, stream, fasta, n, gcbits,
+  RSI_LAUNCH(k_fasta_classify, dim3(grid_for(nwords * 4, kThreads)), dim3(kThreads), 0, stream, fasta, n, gcbits,
                      nbits, nwords, fill);
 }
 __global__ __launch_bounds__(kThreads) void k_fill(FillList fill) { fill_ranges(fill); }
@@ -1369,11 +1369,11 @@ void launch_fill(const FillList& fill, hipStream_t stream) {
   unsigned long long units = 0;
   for (int k = 0; k < fill.n; ++k) units += fill.units[k];
   if (units == 0) return;
-  hipLaunchKernelGGL(k_fill, dim3(grid_for((int64_t)units, kThreads)), dim3(kThreads), 0, stream, fill);
+  RSI_LAUNCH(k_fill, dim3(grid_for((int64_t)units, kThreads)), dim3(kThreads), 0, stream, fill);
 }
 void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
                           hipStream_t stream) {
-  hipLaunchKernelGGL(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
+  RSI_LAUNCH(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
                      count, cap);
 }
 static int gc_hist_grid(int64_t n) {
@@ -1392,8 +1392,8 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
   unsigned long long* sl = static_cast<unsigned long long*>(slabs);
   unsigned long long* gs = static_cast<unsigned long long*>(gsum);
   const int pg = fold_per_group(grid);
-  if (packed) hipLaunchKernelGGL(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
-  else hipLaunchKernelGGL(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
+  if (packed) RSI_LAUNCH(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
+  else RSI_LAUNCH(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kDeepWidth * 4; }   // the wider of K3's two windows
 
@@ -1411,9 +1411,9 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   // adjust = 1 (rescaled array + histogram in one pass) is the deep-coverage path; adjust = 0, out = NULL the -NOGC histogram.
   // The tail cells of out[] get their quirks from a launch of their own (see k_gc_tail_fixup_out).
   if (adjust) {
-    hipLaunchKernelGGL(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
-    if (out) hipLaunchKernelGGL(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
-  } else hipLaunchKernelGGL(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+    RSI_LAUNCH(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+    if (out) RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
+  } else RSI_LAUNCH(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
 }
 // The tail quirks in out[] as a launch of its own: the cells it rewrites were written by other workgroups of the streaming
 // launch, and two stores to one address from different XCDs within one launch have no defined order.
@@ -1424,9 +1424,9 @@ __global__ void k_gc_tail_fixup_out(const int32_t* __restrict__ depth, const uin
 void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,
                            unsigned int* counter, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
-  hipLaunchKernelGGL(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
+  RSI_LAUNCH(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
                      nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1);
-  hipLaunchKernelGGL(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
+  RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
 }
 static int value_hist8_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
@@ -1440,7 +1440,7 @@ void launch_value_hist8(const uint8_t* depth8, const int32_t* depth, const uint6
                         const void* head_src, void* head_dst, size_t head_bytes, uint8_t* rescaled8, const unsigned int* escapes,
                         hipStream_t stream) {
   const int grid = value_hist8_grid(n);
-  hipLaunchKernelGGL(k_value_hist8, dim3(grid), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, n / 64 + 1, table, hist, aux,
+  RSI_LAUNCH(k_value_hist8, dim3(grid), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, n / 64 + 1, table, hist, aux,
                      static_cast<unsigned int*>(slabs), static_cast<unsigned int*>(gsum), fold_per_group(grid), counters, vm, head_src, head_dst,
                      (unsigned int)head_bytes, rescaled8, escapes, byte_escape_limit(n));
 }
@@ -1491,7 +1491,7 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
   const int pg = fold_per_group(grid);
   const int ept = (m + 3) / 4;
 #define RSI_K48(MC, EP, SW) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP, SW>));                                                  \
-    hipLaunchKernelGGL((k_cap_compact_bin8<MC, EP, SW>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
+    RSI_LAUNCH((k_cap_compact_bin8<MC, EP, SW>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
                        cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
                        exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
   const bool sw7 = capval <= 127;   // four values to a register in the median phase (k_cap_compact_bin8, SW7)
@@ -1527,7 +1527,7 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   const int pg = fold_per_group(grid);
   const int overwrite = vbase == 0 && capval < vr ? 1 : 0;
 #define RSI_K4(MV, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin<MV, EP>));                                                            \
-    hipLaunchKernelGGL((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
+    RSI_LAUNCH((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
                        ncompact, capval, m, TB, vr, vbase, rdc, binmed, binsum, res_hist, acc, sl, gs, pg, counters, overwrite,              \
                        exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)

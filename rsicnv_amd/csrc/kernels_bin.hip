@@ -909,22 +909,22 @@ void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, d
                    hipStream_t stream) {
   int grid = grid_for(nb, kThreads * 4);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(k_nb_raw, dim3(grid), dim3(kThreads), 0, stream, binsum, nb, m, ncompact, r, raw, rawmin_bits);
+  RSI_LAUNCH(k_nb_raw, dim3(grid), dim3(kThreads), 0, stream, binsum, nb, m, ncompact, r, raw, rawmin_bits);
 }
 void launch_nb_scale_minmax(float* x, int64_t nb, const uint32_t* rawmin_bits, double med_raw, double del_raw, double dup_raw,
                             double RDmedian, const GridChain& c, GridMedian* out, hipStream_t stream) {
   NbLevels lv{med_raw, del_raw, dup_raw, RDmedian};
-  hipLaunchKernelGGL(k_nb_scale_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, x, nb, rawmin_bits, lv, c.mm, c.counters, c.cap,
+  RSI_LAUNCH(k_nb_scale_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, x, nb, rawmin_bits, lv, c.mm, c.counters, c.cap,
                      c.hist, out);
 }
 void launch_i32_to_f32_minmax(const int32_t* in, float* out_f, int64_t nb, double center, const GridChain& c, GridMedian* out,
                               hipStream_t stream) {
-  hipLaunchKernelGGL(k_i32_to_f32_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, in, out_f, nb, center, c.mm, c.counters, c.cap,
+  RSI_LAUNCH(k_i32_to_f32_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, in, out_f, nb, center, c.mm, c.counters, c.cap,
                      c.hist, out);
 }
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
                        hipStream_t stream) {
-  hipLaunchKernelGGL(k_minmax_f32, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
+  RSI_LAUNCH(k_minmax_f32, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, mm);
 }
 void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, double ymin, uint32_t* hist,
                      uint32_t np, hipStream_t stream) {
@@ -934,11 +934,11 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
   // few, long-lived workgroups: every one flushes np counters at the end
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
-  hipLaunchKernelGGL(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
+  RSI_LAUNCH(k_hist_f32, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, ymin, hist, np, use_lds);
 }
 void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
                         const GridChain& c, GridMedian* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_minmax_plan, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, d_center, c.mm,
+  RSI_LAUNCH(k_minmax_plan, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, d_center, c.mm,
                      c.counters, c.cap, c.hist, out);
 }
 void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
@@ -952,7 +952,7 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
   if (ex) for (int k = 0; k < 2; ++k) { e.src[k] = ex->src[k]; e.dst[k] = ex->dst[k]; e.bytes[k] = (unsigned int)ex->bytes[k]; }
   FillList f{};
   if (fill) f = *fill;
-  hipLaunchKernelGGL(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
+  RSI_LAUNCH(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
@@ -968,29 +968,29 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
   if (inl) {
     RSI_ALLOW_FULL_LDS(k_rsi_scan<true>);
-    hipLaunchKernelGGL(k_rsi_scan<true>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, *inl);
+    RSI_LAUNCH(k_rsi_scan<true>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, *inl);
   } else {
     RSI_ALLOW_FULL_LDS(k_rsi_scan<false>);
     static const ScanThr none{};
-    hipLaunchKernelGGL(k_rsi_scan<false>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, none);
+    RSI_LAUNCH(k_rsi_scan<false>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, none);
   }
 }
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(k_level_stop, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 8, stream, first_del, first_dup, nb,
+  RSI_LAUNCH(k_level_stop, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 8, stream, first_del, first_dup, nb,
                      Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
 }
 void launch_resolve_runs(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb, int32_t* status,
                          int32_t* copy, uint64_t* runs, uint32_t* count, uint32_t cap, unsigned int* counter, void* host_copy,
                          uint32_t host_entries, hipStream_t stream) {
-  hipLaunchKernelGGL(k_resolve_runs, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, first_del, first_dup, levels, nb, status, copy,
+  RSI_LAUNCH(k_resolve_runs, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, first_del, first_dup, levels, nb, status, copy,
                      runs, count, cap, counter, host_copy, host_entries);
 }
 void launch_trim_runs(const float* T, int32_t* status, const int32_t* run_start, const int32_t* run_end, const RunsInline* inl, int nruns,
                       double delthr, double addthr, hipStream_t stream) {
   if (nruns <= 0) return;
   static const RunsInline none{};
-  hipLaunchKernelGGL(k_trim_runs, dim3(nruns), dim3(kThreads), 0, stream, T, status, run_start, run_end,
+  RSI_LAUNCH(k_trim_runs, dim3(nruns), dim3(kThreads), 0, stream, T, status, run_start, run_end,
                      nruns, delthr, addthr, inl ? *inl : none);
 }
 
@@ -999,13 +999,13 @@ void launch_run_prefix(const float* T, const int32_t* run_start, const int32_t* 
                        double* scratch, const int32_t* status, int32_t* status_out, hipStream_t stream) {
   if (nruns <= 0) return;
   static const RunsInline none{};
-  hipLaunchKernelGGL(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch, inl ? *inl : none, status, status_out);
+  RSI_LAUNCH(k_run_prefix, dim3(nruns), dim3(kThreads), 0, stream, T, run_start, run_end, poff, scratch, inl ? *inl : none, status, status_out);
 }
 void launch_best_items(const void* items, const ItemsInline* inl, int nitems, const int64_t* poff, const double* scratch, double tmedian,
                        BestSeg* out, hipStream_t stream) {
   if (nitems <= 0) return;
   static const ItemsInline none{};
-  hipLaunchKernelGGL(k_best_subsegment, dim3(nitems), dim3(kThreads), 0, stream, reinterpret_cast<const SegItem*>(items), poff,
+  RSI_LAUNCH(k_best_subsegment, dim3(nitems), dim3(kThreads), 0, stream, reinterpret_cast<const SegItem*>(items), poff,
                      scratch, tmedian, out, inl ? *inl : none);
 }
 

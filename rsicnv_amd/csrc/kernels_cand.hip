@@ -919,15 +919,15 @@ __global__ __launch_bounds__(kThreads) void k_range_sums(const TD* __restrict__ 
 void launch_range_sums(DepthRef d, const void* ranges, int nranges, long long* sums, hipStream_t stream) {
   if (nranges <= 0) return;
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_range_sums<int32_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums),
-    hipLaunchKernelGGL(k_range_sums<uint8_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums));
+    RSI_LAUNCH(k_range_sums<int32_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums),
+    RSI_LAUNCH(k_range_sums<uint8_t>, dim3(nranges), dim3(kThreads), 0, stream, rdc, static_cast<const int2*>(ranges), sums));
 }
 
 void launch_sharpen_edges(DepthRef d, int64_t ncompact, EdgeJob* jobs, int njobs, void* ws, int ws_jobs, hipStream_t stream) {
   if (njobs <= 0) return;
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_sharpen_edges<int32_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws),
-    hipLaunchKernelGGL(k_sharpen_edges<uint8_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws));
+    RSI_LAUNCH(k_sharpen_edges<int32_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws),
+    RSI_LAUNCH(k_sharpen_edges<uint8_t>, dim3(2 * kEdgeChunks, njobs), dim3(kThreads), 0, stream, rdc, ncompact, jobs, ws_jobs, ws));
 }
 void launch_candidate_test_split(DepthRef d, int64_t ncompact, const CandJob* jobs, int njobs, const void* chains,
                                  int32_t* iscratch, long long* lscratch, double RDmedian, CandMid* mid, uint32_t* ghist,
@@ -942,13 +942,13 @@ void launch_candidate_test_split(DepthRef d, int64_t ncompact, const CandJob* jo
   RSI_ALLOW_FULL_LDS(k_cand_hist);
   const int2* ch = static_cast<const int2*>(chains);
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_cand_gather<int32_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid),
-    hipLaunchKernelGGL(k_cand_gather<uint8_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid));
+    RSI_LAUNCH(k_cand_gather<int32_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid),
+    RSI_LAUNCH(k_cand_gather<uint8_t>, dim3(2, njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, ch, iscratch, lscratch, RDmedian, mid));
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_cand_prefix<int32_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid),
-    hipLaunchKernelGGL(k_cand_prefix<uint8_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid));
-  hipLaunchKernelGGL(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid);
-  hipLaunchKernelGGL(k_cand_hist, dim3(kCandChunks, njobs), dim3(kTestThreads), lds, stream, jobs, iscratch, lscratch, mid, ghist, outs);
+    RSI_LAUNCH(k_cand_prefix<int32_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid),
+    RSI_LAUNCH(k_cand_prefix<uint8_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid));
+  RSI_LAUNCH(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid);
+  RSI_LAUNCH(k_cand_hist, dim3(kCandChunks, njobs), dim3(kTestThreads), lds, stream, jobs, iscratch, lscratch, mid, ghist, outs);
 }
 size_t sharpen_workspace_bytes(int njobs) { return sharpen_zero_bytes(njobs) + (size_t)njobs * 2 * kEdgeChunks * (8 + 8 + 4); }
 size_t sharpen_workspace_zero_bytes(int njobs) { return sharpen_zero_bytes(njobs); }
@@ -959,8 +959,8 @@ void launch_candidate_test(DepthRef d, int64_t ncompact, const CandJob* jobs, in
   RSI_ALLOW_FULL_LDS(k_candidate_test<int32_t>);
   RSI_ALLOW_FULL_LDS(k_candidate_test<uint8_t>);
   RSI_DEPTH_DISPATCH(d,
-    hipLaunchKernelGGL(k_candidate_test<int32_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs),
-    hipLaunchKernelGGL(k_candidate_test<uint8_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs));
+    RSI_LAUNCH(k_candidate_test<int32_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs),
+    RSI_LAUNCH(k_candidate_test<uint8_t>, dim3(njobs), dim3(kTestThreads), lds, stream, rdc, ncompact, jobs, static_cast<const int2*>(chains), iscratch, lscratch, RDmedian, outs));
 }
 #undef RSI_DEPTH_DISPATCH
 
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void k_widen_u8(const uint8_t* __restrict__ sr
 void launch_widen_u8(const uint8_t* src, int64_t n, int32_t* dst, hipStream_t stream) {
   if (n <= 0) return;
   const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-  hipLaunchKernelGGL(k_widen_u8, dim3((unsigned int)blocks), dim3(256), 0, stream, src, n, dst);
+  RSI_LAUNCH(k_widen_u8, dim3((unsigned int)blocks), dim3(256), 0, stream, src, n, dst);
 }
 
 }  // namespace rsik

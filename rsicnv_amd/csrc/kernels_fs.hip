@@ -388,10 +388,10 @@ void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lm
   int32_t* cmark = reinterpret_cast<int32_t*>(p); p += ((size_t)nchunks * 4 + 15) & ~size_t(15);
   int32_t* clist_s = reinterpret_cast<int32_t*>(p); p += (size_t)clist_cap * 4;
   float* clist_t = reinterpret_cast<float*>(p);
-  hipLaunchKernelGGL(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
-  hipLaunchKernelGGL(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
-  hipLaunchKernelGGL(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), (size_t)(2 * Lmax + 1) * 4, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap, Lmax, level_count);
-  hipLaunchKernelGGL(k_fs_level_sums, dim3((2 * Lmax + 1 + kThreads / 64 - 1) / (kThreads / 64) + 1), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, level_count,
+  RSI_LAUNCH(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
+  RSI_LAUNCH(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
+  RSI_LAUNCH(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), (size_t)(2 * Lmax + 1) * 4, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap, Lmax, level_count);
+  RSI_LAUNCH(k_fs_level_sums, dim3((2 * Lmax + 1 + kThreads / 64 - 1) / (kThreads / 64) + 1), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, level_count,
                      clist_cap, Lmax, out, counter, host_copy);
 }
 

@@ -108,7 +108,7 @@ void launch_parse_depth_text(const void* text, long long nbytes, long long size,
                              long long* wg_max, TextParseStats* stats, hipStream_t stream) {
   const int grid = text_parse_workgroups(nbytes);
   if (grid <= 0) return;
-  hipLaunchKernelGGL(k_parse_depth_text, dim3(grid), dim3(kThreads), 0, stream, static_cast<const unsigned char*>(text), nbytes, size,
+  RSI_LAUNCH(k_parse_depth_text, dim3(grid), dim3(kThreads), 0, stream, static_cast<const unsigned char*>(text), nbytes, size,
                      depth, wg_first, wg_max, stats);
 }
 
@@ -250,16 +250,16 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t* __restrict
 void launch_bam_depth(const void* data, const uint32_t* rec_off, int nrec, int tid, int minq, int min_baseq, long long n, int32_t* diff,
                       BamDepthStats* stats, hipStream_t stream) {
   if (nrec <= 0) return;
-  hipLaunchKernelGGL(k_bam_depth, dim3((nrec + 255) / 256), dim3(256), 0, stream, static_cast<const unsigned char*>(data), rec_off, nrec, tid,
+  RSI_LAUNCH(k_bam_depth, dim3((nrec + 255) / 256), dim3(256), 0, stream, static_cast<const unsigned char*>(data), rec_off, nrec, tid,
                      minq, min_baseq, n, diff, stats);
 }
 int scan_tiles(long long n) { return (int)((n + kScanTileElems - 1) / kScanTileElems); }
 void launch_inclusive_scan_i32(int32_t* x, long long n, int32_t* tile_scratch, hipStream_t stream) {
   const int ntiles = scan_tiles(n);
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
-  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, stream, tile_scratch, ntiles);
-  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
+  RSI_LAUNCH(k_scan_tile_sums, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
+  RSI_LAUNCH(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, stream, tile_scratch, ntiles);
+  RSI_LAUNCH(k_scan_apply, dim3(ntiles), dim3(kScanThreads), 0, stream, x, n, tile_scratch);
 }
 
 }  // namespace rsik

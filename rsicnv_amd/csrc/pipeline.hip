@@ -1236,6 +1236,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->phases.clear();
   tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
   tl_grow_ms = 0.0;
+  if (!ctx_enter(ctx)) return RSI_ERR_HIP;
   mailbox_reset(ctx);
   PerBase pb;
   int rc = per_base_phase(ctx, P, d_depth, d_fasta, n, res, pb);
@@ -1370,6 +1371,7 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(cnt, cap);
+    if (!ctx_enter(ctx)) return RSI_ERR_HIP;
     mailbox_reset(ctx);
     HIPCHK(copy_d2h(ctx, out, src, (size_t)k * 4));
     HIPCHK(CTX_SYNC());
@@ -1385,6 +1387,7 @@ int64_t rsi_hot_fetch_f32(rsi_ctx* ctx, const char* name, float* out, int64_t ca
   if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(cnt, cap);
+    if (!ctx_enter(ctx)) return RSI_ERR_HIP;
     mailbox_reset(ctx);
     HIPCHK(copy_d2h(ctx, out, src, (size_t)k * 4));
     HIPCHK(CTX_SYNC());
@@ -1397,6 +1400,7 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
   if (s != "binsum" || ctx->nb == 0) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(ctx->nb, cap);
+    if (!ctx_enter(ctx)) return RSI_ERR_HIP;
     mailbox_reset(ctx);
     HIPCHK(copy_d2h(ctx, out, ctx->binsum.p, (size_t)k * 8));
     HIPCHK(CTX_SYNC());
@@ -1408,6 +1412,7 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
 int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status, int64_t nb, int Lmax, float* sums, int32_t* counts) {
   if (!ctx || !T || !status || !sums || !counts || nb <= 0 || Lmax < 1 || Lmax > kMaxL) return fail(ctx, RSI_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx_enter(ctx)) return RSI_ERR_HIP;
   mailbox_reset(ctx);
   HIPCHK(ctx->small.ensure(kSmallBytes));
   HIPCHK(ctx->tnb.ensure((size_t)nb * 4));

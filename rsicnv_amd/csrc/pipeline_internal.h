@@ -161,6 +161,7 @@ struct rsi_ctx {
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
   int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
+  bool poisoned = false;      // a wait hit its deadline with work still queued (ctx_sync): no further runs
   bool gate_shared = false;   // RSI_HOT_ISOLATE_STREAMING=1: bin-level kernels wait while a per-base phase runs (clean kernel timings, ~20 % less throughput)
 };
 
@@ -249,14 +250,30 @@ inline hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t by
 // grid) raises no error at the launch site -- the launch wrappers return nothing -- and the copies and event calls behind it
 // still succeed; without this check the run would return RSI_OK on stale data.
 inline hipError_t ctx_sync(rsi_ctx* ctx) {
+  if (ctx->poisoned) return hipErrorLaunchTimeOut;
   hipError_t e = stream_wait(ctx->stream, ctx->sync_ev);
-  const hipError_t launch = hipGetLastError();   // this thread's last failed runtime call; cleared by the read
+  // A queue that outlived the wait's deadline is still running: its kernels write the workspaces and the mapped mailbox of
+  // this context, so the context takes no further run (a next run would reset the mailbox and reuse the buffers under
+  // them) -- every entry point refuses a poisoned context; rsi_hot_destroy is what is left to do with it.
+  if (e == hipErrorLaunchTimeOut) ctx->poisoned = true;
+  const hipError_t launch = take_launch_error();   // first failed launch of this thread since the last wait (kernels.h, RSI_LAUNCH)
   if (e == hipSuccess && launch != hipSuccess) e = launch;
   if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
   ctx->pending.clear();
   return e;
 }
 inline void mailbox_reset(rsi_ctx* ctx) { ctx->mb_used = 0; ctx->pending.clear(); }
+// First thing an entry point does with a context: refuse a poisoned one, forget errors that are not this run's (the calling
+// thread is the host application's: torch or RCCL may have left a benign failure in the runtime's per-thread slot).
+inline bool ctx_enter(rsi_ctx* ctx) {
+  if (ctx->poisoned) {
+    ctx->err = "context unusable: an earlier wait gave up after 60 s with kernels still queued (destroy it)";
+    set_global_error(ctx->err);
+    return false;
+  }
+  drain_stale_errors();
+  return true;
+}
 #define CTX_SYNC() ctx_sync(ctx)
 
 inline int fail(rsi_ctx* ctx, int code, const std::string& msg) {

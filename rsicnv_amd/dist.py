@@ -28,18 +28,26 @@ def lpt_assign(lengths, world):
     return out
 
 
-def pack_results(chrom_ids, results, nslots):
+def pack_results(chrom_ids, results, nslots, id_offset=0):
     """results: rsicnv_amd.api.Result objects (anything with summary_into).  Returns a float64
     [nslots, BLOCK_W] block in the layout of rsi_result_summary; unused slots have chromosome id -1.
-    A chromosome with more than MAX_CALLS calls does not fit its slot: that is an error, not a
-    silent truncation."""
+    A chromosome with more than MAX_CALLS calls does not fit its slot; its block then says so
+    (stored < calls) and unpack_blocks raises -- on EVERY rank, after the collective: raising here, on
+    the one rank that holds the chromosome, would leave the others waiting in the all_gather.
+    check_blocks() is the same test for a caller that does not gather.  id_offset: added to the ids
+    (the weak-scaling mode gives every rank's sample its own id range)."""
     block = np.zeros((nslots, BLOCK_W), dtype=np.float64)
     block[:, 0] = -1
     for slot, (cid, res) in enumerate(zip(chrom_ids, results)):
-        res.summary_into(block[slot], cid, MAX_CALLS)
-        if block[slot, 4] < block[slot, 3]:
-            raise OverflowError(f"chromosome {cid}: {int(block[slot, 3])} calls do not fit the {MAX_CALLS} slots of a summary block")
+        res.summary_into(block[slot], cid + id_offset, MAX_CALLS)
     return block
+
+
+def check_blocks(block):
+    """Raises OverflowError when a slot of `block` was truncated (more than MAX_CALLS calls)."""
+    for row in np.asarray(block):
+        if row[0] >= 0 and row[4] < row[3]:
+            raise OverflowError(f"chromosome {int(row[0])}: {int(row[3])} calls do not fit the {MAX_CALLS} slots of a summary block")
 
 
 def unpack_blocks(blocks):

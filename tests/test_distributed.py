@@ -79,8 +79,19 @@ def test_truncated_block_is_an_error():
     from rsicnv_amd import dist as rd
     big = FakeResult(1)
     big._calls = [dict(start=i, end=i + 10, type=0, qscore=50) for i in range(rd.MAX_CALLS + 1)]
+    block = rd.pack_results([1], [big], 1)      # packing never raises: the other ranks would hang in the collective
     with pytest.raises(OverflowError):
-        rd.pack_results([1], [big], 1)
+        rd.check_blocks(block)
+    with pytest.raises(OverflowError):          # every rank sees the truncated block after the gather
+        rd.unpack_blocks([block])
+
+
+def test_sample_mode_ids_do_not_collide():
+    from rsicnv_amd import dist as rd
+    ids = [0, 1, 2]
+    blocks = [rd.pack_results(ids, [FakeResult(c) for c in ids], 3, id_offset=r * 3) for r in range(2)]
+    merged = rd.unpack_blocks(blocks)
+    assert sorted(merged) == list(range(6))
 
 
 @pytest.mark.timeout(120)
