@@ -21,11 +21,18 @@ a cohort, weak scaling), reported with that label.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  In it:
-  roofline      the dominant per-base kernel (cap_compact_bin): algorithmic bytes (9.1
-                B/base) over its HIP-event time inside the timed steps (on the library's own
-                streams), `isolated` = the same launches with the chip to themselves (one extra,
-                untimed pass), `whole_path` = 23.7 (m = 101) / 24.3 (m = 51) algorithmic B/base x
-                genome bases over the step time: the fraction BASELINE.md defines for the path.
+  roofline      the dominant per-base kernel -- the one an untimed pass with HIP events around every
+                per-base launch MEASURES as the longest -- then timed inside the timed steps (events
+                around that kernel only, on the library's own streams): algorithmic bytes (SURVEY 8d's
+                row of the kernel) over that time; `isolated` = the same launches with the chip to
+                themselves (one extra, untimed pass); `streaming_kernels` = every per-base kernel with
+                three fractions each, in situ and isolated: `algorithmic` (SURVEY's bytes), `actual`
+                (the bytes the committed PMC passes counted, profiles/pmc_traffic.json) and `valu` (the
+                vector instructions the PMC passes counted over the chip's 1.23e12 wave-instructions/s);
+                `whole_path` = 23.7 (m = 101) / 24.3 (m = 51) algorithmic B/base x genome bases over
+                the step time: the fraction BASELINE.md defines for the path; `scan` = window
+                evaluations per second of the RSI scan kernel (2 sweeps x Lmax x bins x 2 passes).
+  steps_identical  every timed step's rows hashed: true when all steps produced the same bytes.
   cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or the CPU restatement
                 (kind "port") on one 60 Mb chromosome of the same model, one core; `all_cores` =
                 one such process per host core at once.
@@ -45,10 +52,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per base of the per-base kernels
-ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "value_hist8": 9.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1, "fasta_classify": 1.0,
-                       "value_hist": 4.0}
+ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "gc_joint_hist": 5.0, "value_hist8": 9.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1,
+                       "fasta_classify": 1.0, "value_hist": 4.0}
 WHOLE_PATH_BYTES_PER_BASE = {101: 23.7, 51: 24.3}   # SURVEY 8d, GC on
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz = 1.23e12 /s
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py --json
 
 
@@ -61,6 +69,16 @@ def pmc_traffic_per_base(kernel):
             d = json.load(f)
         k = d["kernels"][kernel]
         return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / d["bases_per_launch"]
+    except Exception:
+        return None
+
+
+def pmc_valu_per_base(kernel):
+    """Vector instructions (wave-instructions, SQ_INSTS_VALU) per base of a kernel from the committed PMC passes."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        return d["kernels"][kernel]["SQ_INSTS_VALU"] / d["bases_per_launch"]
     except Exception:
         return None
 
@@ -123,7 +141,7 @@ def main():
     pool = api.RsiPool(local_rank, args.workers)
     # HIP events around the dominant per-base kernel only inside the timed steps (event records are not free); the
     # per-kernel tables come from extra, untimed passes.
-    pool.set_timing(3)
+    pool.set_timing(0)
     flags = synth.config_flags(args.config)
     params = api.make_params(**flags)
 
@@ -159,10 +177,17 @@ def main():
     names = [f"chr{c + 1}" for c in chrom_ids]
     chrom_args = [(data[i][0].data_ptr(), data[i][1].data_ptr(), data[i][2]) for i in mine]
 
+    import hashlib
+    step_hashes = []
+    scan_evals = [0]
+    id_offset = 0 if sharded else rank * len(plans)   # weak-scaling mode: every rank's sample keeps its own ids
+
     def step(timed=False):
         """One genome: this rank's chromosomes through the pool, the gather, rank 0's rows in chromosome order."""
         results = pool.run(params, chrom_args, collect_times=timed) if chrom_args else []
-        block = rd.pack_results(mine, results, nslots)
+        if timed:   # window evaluations of the scan this step: 2 sweeps x Lmax x bins x 2 passes per chromosome
+            scan_evals[0] = sum(4 * int(r.stats["Lmax"]) * int(r.stats["nbins"]) for r in results)
+        block = rd.pack_results(mine, results, nslots, id_offset)
         if world > 1:   # the one exchange of the path
             blocks = rd.gather_blocks(block, world, coll_dev)
         else:
@@ -170,10 +195,17 @@ def main():
         if rank != 0:
             return 0
         merged = rd.unpack_blocks(blocks)
-        if sharded and len(merged) != len(plans):
-            raise RuntimeError(f"gather returned {len(merged)} of {len(plans)} chromosomes")
-        rows = rd.format_rows(lib, merged, names) if sharded or world == 1 else []
-        return len(rows) if rows else sum(m["ncalls"] for m in merged.values())
+        if len(merged) != (len(plans) if sharded else world * len(plans)):
+            raise RuntimeError(f"gather returned {len(merged)} chromosomes of {len(plans)} x {1 if sharded else world}")
+        rows = rd.format_rows(lib, merged, names if sharded else [names[c % len(plans)] for c in range(world * len(plans))])
+        if timed:   # a step whose rows differ from another step's is a wrong step: every timed step is hashed
+            h = hashlib.sha256()
+            for r in rows:
+                h.update(r.encode()); h.update(b"\n")
+            for c in sorted(merged):
+                h.update(repr((c, merged[c]["RDmedian"], merged[c]["RDsd"])).encode())
+            step_hashes.append(h.hexdigest())
+        return len(rows)
 
     def fence():
         if world > 1:
@@ -182,6 +214,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # ---- which per-base kernel is the dominant one?  Measured, not assumed: one untimed pass with HIP events around every
+    # per-base launch (timing mode 2); the timed steps then bracket that kernel only (event records are not free). ----
+    pool.reset_times()
+    pool.set_timing(2)
+    fence()
+    step(timed=True)
+    fence()
+    insitu_all = pool.kernel_table()
+    streaming_names = [k for k in insitu_all if k in ALGO_BYTES_PER_BASE]
+    dom = max(streaming_names, key=lambda k: insitu_all[k][0]) if streaming_names else "cap_compact_bin"
+    if world > 1:   # every rank brackets the kernel rank 0 measured
+        obj = [dom]
+        dist.broadcast_object_list(obj, src=0)
+        dom = obj[0]
+    pool.set_timing_kernel(dom)
+    pool.set_timing(3)
+    step_hashes.clear()
     pool.reset_times()
     fence()
     t_start = time.perf_counter()
@@ -206,8 +255,20 @@ def main():
         achieved = byts / (ms * 1e-3) / 1e9
         return ms, cnt, bases, byts, achieved
 
+    def three_fractions(table, name):
+        """SURVEY-algorithmic, actual (PMC bytes) and VALU-issue fractions of one kernel's launches in `table`."""
+        ms, cnt, bases = table[name]
+        sec = ms * 1e-3
+        out = {"avg_launch_ms": round(ms / cnt, 4), "launches": int(cnt),
+               "algorithmic": round(ALGO_BYTES_PER_BASE[name] * bases / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        tpb, vpb = pmc_traffic_per_base(name), pmc_valu_per_base(name)
+        out["actual"] = None if tpb is None else round(tpb * bases / sec / 1e9 / HBM_PEAK_GBS, 4)
+        out["valu"] = None if vpb is None else round(vpb * bases / sec / VALU_PEAK_WAVE_INSTS, 4)
+        return out
+
     roofline = None
     streaming = [k for k in per_kernel if k in ALGO_BYTES_PER_BASE]
+    steps_identical = len(set(step_hashes)) <= 1
     if streaming:
         dom = max(streaming, key=lambda k: per_kernel[k][0])
         ms, cnt, bases, byts, achieved = kernel_roofline(per_kernel, dom)
@@ -221,12 +282,15 @@ def main():
                     "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[dom],
                     "algorithmic_bytes_per_launch": round(byts / cnt),
                     "measured": "in situ: the timed steps, with the kernels of up to "
-                                f"{args.workers - 1} other chromosomes sharing the GPU",
+                                f"{args.workers - 1} other chromosomes sharing the GPU; the kernel is the per-base kernel with the largest "
+                                "summed HIP-event time in an untimed pass that bracketed every per-base launch",
+                    "dominant_pick_ms": {k: round(insitu_all[k][0], 3) for k in sorted(streaming_names, key=lambda k: -insitu_all[k][0])},
                     "whole_path": {"algorithmic_bytes_per_base": whole_bpb, "achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
                                    "note": "SURVEY 8d's whole-path algorithmic bytes x the bases one GPU processed per step / step time"}}
         # The same kernel with the per-base phases run alone on the chip (rsi_pool_set_schedule isolate=1):
         # one extra, untimed genome pass; `value` above does not include it.
         pool.set_schedule(isolate=True)
+        pool.set_timing(2)
         timed_tables = (pool.times, )
         pool.reset_times()
         fence()
@@ -234,10 +298,20 @@ def main():
         fence()
         iso = pool.kernel_table()
         pool.set_schedule(isolate=False)
+        pool.set_timing(3)
         if dom in iso:
             ims, icnt, ibases, ibyts, iach = kernel_roofline(iso, dom)
             roofline["isolated"] = {"achieved": round(iach, 1), "frac": round(iach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ims / icnt, 4),
                                     "launches": int(icnt), "note": "same launches with the chip to themselves (untimed extra pass)"}
+        # every per-base kernel, three fractions each: against SURVEY's algorithmic bytes, against the bytes the kernel
+        # really moves (PMC), against the chip's vector-instruction issue rate (PMC) -- in situ (the untimed pass that picked
+        # the dominant kernel) and isolated
+        roofline["streaming_kernels"] = {
+            k: {"algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE[k],
+                "actual_bytes_per_base": None if pmc_traffic_per_base(k) is None else round(pmc_traffic_per_base(k), 3),
+                "valu_insts_per_base_x64": None if pmc_valu_per_base(k) is None else round(64 * pmc_valu_per_base(k), 2),
+                "in_situ": three_fractions(insitu_all, k), "isolated": three_fractions(iso, k) if k in iso else None}
+            for k in sorted(streaming_names, key=lambda k: -insitu_all[k][0])}
         pool.times = timed_tables[0]
     # every launch of one more untimed pass (normal schedule), for the per-kernel picture of the whole path
     timed_table = pool.times
@@ -246,7 +320,14 @@ def main():
     fence()
     step(timed=True)
     fence()
-    kernel_ms_all = {k: round(v[0], 3) for k, v in sorted(pool.kernel_table().items(), key=lambda kv: -kv[1][0])}
+    all_table = pool.kernel_table()
+    kernel_ms_all = {k: round(v[0], 3) for k, v in sorted(all_table.items(), key=lambda kv: -kv[1][0])}
+    if roofline is not None and "rsi_scan" in all_table and all_table["rsi_scan"][0] > 0:
+        sms = all_table["rsi_scan"][0]
+        roofline["scan"] = {"kernel": "rsi_scan", "bound": "lds/alu", "window_evaluations_per_step": int(scan_evals[0]),
+                            "kernel_ms_per_step_in_situ": round(sms, 3),
+                            "evaluations_per_s": round(scan_evals[0] / (sms * 1e-3), 1),
+                            "note": "2 sweeps x Lmax x bins x 2 passes per chromosome over the kernel's HIP-event time (all launches of one untimed pass)"}
     pool.set_timing(3)
     pool.times = timed_table
     phase_ms = pool.phase_table()
@@ -277,6 +358,7 @@ def main():
                        "bases_on_rank0": my_bases, "flags": flag_string(flags), "calls_per_genome": ncalls, "shard": args.shard,
                        "parallelism": par},
             "roofline": roofline, "cpu_baseline": cpu,
+            "steps_identical": steps_identical, "rows_sha256": step_hashes[0] if step_hashes else None,
             "kernel_ms_all_launches_extra_pass": kernel_ms_all,
             "worker_phase_ms_per_step": {k: round(v / args.steps, 2) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
         }
@@ -337,6 +419,12 @@ def side_measurements(lib, pool, dev, args):
             host_case = (fasta_np.copy(), depth_np.copy())
         del h_rd, h_fa
     hot.close()
+    # ---- configs[4] (3 Gb at 60x, -m 51 -MED -cap 4) as a side pass: a driver-timed number for the other 3 Gb
+    # configuration, with its scan kernel's rate (Lmax 196 there) ----
+    try:
+        out["configs[4]_side_pass"] = config5_side_pass(lib, pool, dev, args)
+    except Exception as e:   # a side measurement must not take the bench line down
+        out["configs[4]_side_pass"] = {"error": str(e)[:200]}
     pool.set_timing(3)
     # ---- t_e2e: the command line on the 60 Mb chromosome as files (FASTA + .fai, 700 MB of "pos depth" text) ----
     try:
@@ -358,6 +446,54 @@ def side_measurements(lib, pool, dev, args):
                             "note": "rsicnv rsi -f REF -d RDFILE -c chrS on configs[1] (process start, FASTA, depth text parse, device path, output file)"}
     except Exception as e:   # a side measurement must not take the bench line down
         out["t_e2e"] = {"error": str(e)[:200]}
+    return out
+
+
+def config5_side_pass(lib, pool, dev, args, steps=6, warmup=2):
+    """BASELINE.json configs[4] through the same pool: ms per genome, whole-path fraction (24.3 B/base at m = 51), the scan
+    kernel's window evaluations per second.  Never part of `value`."""
+    import torch
+    from rsicnv_amd import api, synth
+    flags = synth.config_flags(5)
+    params = api.make_params(**flags)
+    data, total = [], 0
+    for c in range(24):
+        p = synth.config_plan(5, chrom=c)
+        d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device=dev)
+        d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device=dev)
+        synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
+        data.append((d_rd, d_fa, p["n"]))
+        total += p["n"]
+    torch.cuda.synchronize()
+    chrom_args = [(a.data_ptr(), b.data_ptr(), n) for a, b, n in data]
+    pool.set_timing(0)
+    for _ in range(warmup):
+        pool.run(params, chrom_args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pool.run(params, chrom_args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ncalls = sum(len(r.calls("calls")) for r in res)
+    evals = sum(4 * int(r.stats["Lmax"]) * int(r.stats["nbins"]) for r in res)
+    whole = WHOLE_PATH_BYTES_PER_BASE[51] * total / dt / 1e9
+    saved = pool.times
+    pool.reset_times()
+    pool.set_timing(1)
+    pool.run(params, chrom_args, collect_times=True)
+    torch.cuda.synchronize()
+    table = pool.kernel_table()
+    pool.times = saved
+    pool.set_timing(0)
+    out = {"workload": "24 synthetic chromosomes totalling 3 Gb, 60x, -m 51 -MED -cap 4 (configs[4])", "flags": flag_string(flags),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "bases_per_s": round(total / dt, 1), "calls_per_genome": ncalls,
+           "whole_path": {"algorithmic_bytes_per_base": WHOLE_PATH_BYTES_PER_BASE[51], "achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4)},
+           "kernel_ms_all_launches_extra_pass": {k: round(v[0], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][0])[:10]}}
+    if "rsi_scan" in table and table["rsi_scan"][0] > 0:
+        out["scan"] = {"window_evaluations_per_step": int(evals), "kernel_ms_per_step_in_situ": round(table["rsi_scan"][0], 3),
+                       "evaluations_per_s": round(evals / (table["rsi_scan"][0] * 1e-3), 1)}
+    del data
     return out
 
 

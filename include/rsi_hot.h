@@ -205,6 +205,10 @@ int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int 
 /* Per-kernel event timing: 0 off, 1 an event pair around every launch, 2 around the per-base (HBM-bound)
  * kernels only -- some sixty launches per chromosome make the event records themselves cost 13 % of a pooled step. */
 void rsi_hot_set_timing(rsi_ctx* ctx, int on);
+/* Mode 3: an event pair around the launches of ONE kernel, named as in rsi_hot_kernel_times' table (e.g. "gc_hist",
+ * "cap_compact_bin", "rsi_scan"): what bench.py's timed steps use for the kernel that an untimed pass measured as the
+ * dominant one.  NULL / "" = "cap_compact_bin". */
+void rsi_hot_set_timing_kernel(rsi_ctx* ctx, const char* name);
 
 /* ---- Pool: several chromosomes in flight on one GPU ------------------------------------------
  * The reference's per-chromosome loop (rsi.cpp:2189-2217) has independent iterations.  A pool owns
@@ -230,6 +234,7 @@ void rsi_pool_destroy(rsi_pool* pool);
 int rsi_pool_workers(const rsi_pool* pool);
 rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w);
 void rsi_pool_set_timing(rsi_pool* pool, int on);
+void rsi_pool_set_timing_kernel(rsi_pool* pool, const char* name);   /* rsi_hot_set_timing_kernel on every worker */
 /* Scheduling of the pool's workers on the GPU.  isolate != 0: a chromosome's per-base (HBM-bound) phase runs
  * alone on the chip -- bin-level work of the other workers waits -- so that every streaming launch is a clean
  * bandwidth sample (profiling); 0 (default): bin-level work overlaps it (about 20 % more throughput).

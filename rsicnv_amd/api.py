@@ -28,7 +28,7 @@ EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_l
            "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_summary_format_rows", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
-           "rsi_pool_set_timing", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
+           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
 
 
 class RsiParams(C.Structure):
@@ -144,6 +144,8 @@ def load_library():
     L.rsi_pool_worker.argtypes = [C.c_void_p, C.c_int]
     L.rsi_pool_worker.restype = C.c_void_p
     L.rsi_pool_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.rsi_pool_set_timing_kernel.argtypes = [C.c_void_p, C.c_char_p]
+    L.rsi_hot_set_timing_kernel.argtypes = [C.c_void_p, C.c_char_p]
     L.rsi_pool_set_schedule.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.rsi_pool_last_error.argtypes = [C.c_void_p]
     L.rsi_pool_last_error.restype = C.c_char_p
@@ -384,6 +386,10 @@ class RsiPool:
 
     def set_timing(self, on=True):
         self.lib.rsi_pool_set_timing(self.pool, int(on))
+
+    def set_timing_kernel(self, name):
+        """The kernel timing mode 3 brackets (a name of kernel_table())."""
+        self.lib.rsi_pool_set_timing_kernel(self.pool, name.encode())
 
     def set_schedule(self, isolate=False, streamers=0):
         """isolate: per-base phases run alone on the chip (clean kernel timings); streamers: per-base phases in flight (0 = keep)."""

@@ -338,6 +338,8 @@ struct ScanLds {     // plain base pointers and one stride: nothing here is inde
   uint16_t* CB;     // four prefix-count arrays CL, CG, CTd, CTu, `stride` apart (count + 1 used)
   uint16_t* RB;     // four position-by-rank arrays, `stride` apart
   uint16_t* PF;     // count: predicate bits of each staged bin (bit q = predicate q)
+  float* Pf;        // count + 1: the prefixes rounded to float (the score pre-filter; NULL without it)
+  float2* TH;       // Lmax + 1 + kScanPad: the pre-filter's thresholds per L (x: DEL, y: DUP), widened by the rounding bound
   int stride;       // count + 2
   int count, kcap;
   __device__ uint16_t& C(int q, int x) const { return CB[q * stride + x]; }
@@ -346,13 +348,19 @@ struct ScanLds {     // plain base pointers and one stride: nothing here is inde
 };
 enum { kCL = 0, kCG = 1, kCTd = 2, kCTu = 3 };
 
-__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap) {
+__host__ __device__ inline size_t scan_lds_base_bytes(int count, int kcap) {
   size_t b = ((size_t)(count + 1) + kThreads) * sizeof(double);
   b += 2 * (size_t)(kcap + 1) * count * 4 + (size_t)count * 4;
   b += 9 * (size_t)(count + 2) * 2;
+  return (b + 7) & ~(size_t)7;
+}
+// pre = 1: room for the float prefixes and the per-L float thresholds of the score pre-filter behind the base layout
+__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap, int pre = 0, int Lmax = 0) {
+  size_t b = scan_lds_base_bytes(count, kcap);
+  if (pre) b += (size_t)(Lmax + 1 + kScanPad) * 8 + (((size_t)count + 2) & ~(size_t)1) * 4;
   return b;
 }
-__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap) {
+__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap, int pre = 0, int Lmax = 0) {
   S.count = count; S.kcap = kcap; S.stride = count + 2;
   S.P = sm;
   S.tot = S.P + count + 1;
@@ -361,6 +369,11 @@ __device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kca
   S.CB = reinterpret_cast<uint16_t*>(S.M + count);
   S.RB = S.CB + 4 * S.stride;
   S.PF = S.RB + 4 * S.stride;
+  S.Pf = nullptr; S.TH = nullptr;
+  if (pre) {
+    S.TH = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(sm) + scan_lds_base_bytes(count, kcap));
+    S.Pf = reinterpret_cast<float*>(S.TH + (Lmax + 1 + kScanPad));
+  }
 }
 
 // first staged position >= x where predicate q holds, vhi when none; last position <= x, vlo-1 when none
@@ -439,13 +452,46 @@ struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; }
 struct ScanRun { int lastL, i1, i2; };
 struct ScanMid { int upto, a, b; };
 
-template <bool EDGE>
+// PRE: the score pre-filter.  Nearly every (bin, L) pair is far from both thresholds (0.5 % of the pairs of a 30x genome are
+// hits, in 0.5 % of the waves), and the exact test costs a 64-bit LDS read, an f64 subtraction and two f64 compares (half
+// rate) with their hazard bubbles per pair, plus the wave's wait for sixteen scalar threshold loads per group.  The filter
+// decides a whole group of eight L for the whole wave from FLOAT prefixes: |fl32(Pf[hi] - Pf[lo]) - (P[hi] - P[lo])| <=
+// 3 * 2^-24 * max|P| (one rounding per prefix, one in the subtraction), so with thresholds widened by 4 * 2^-24 * max|P| of
+// THIS tile (ScanLds::TH, built per workgroup) "no float hit" implies "no exact hit".  Only a group in which some lane's
+// float test fires runs the exact code below -- unchanged, so the marks are bit for bit what they were.
+template <bool EDGE, bool PRE>
 __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const double* __restrict__ thr_del,
                                   const double* __restrict__ thr_dup, int relc, int Lmax, int Lend, uint32_t* counters) {
   double p_lo = S.P[relc], p_hi = 0.0;
+  int lo_at = relc;                                   // staged index p_lo was read from (the pre-filter skips groups)
   ScanRun run_del = {-1, 0, 0}, run_dup = {-1, 0, 0};
   ScanMid mid_del = {0, (int)0x80000000, 0x7fffffff}, mid_dup = {0, (int)0x80000000, 0x7fffffff};
+  float f_lo = 0.0f, f_hi = 0.0f;
+  if (PRE) f_lo = S.Pf[relc];
   for (int L0 = 1; L0 <= Lmax; L0 += kScanPad) {
+    if (PRE) {
+      float pf[kScanPad];
+      float2 th[kScanPad];
+#pragma unroll
+      for (int u = 0; u < kScanPad; ++u) {
+        int L = L0 + u;
+        L = L > Lmax ? Lmax : L;
+        const int h = L >> 1;
+        pf[u] = S.Pf[(u & 1) ? relc - h : relc + h + 1];
+        th[u] = S.TH[L0 + u];                           // the same address in every lane: a broadcast read
+      }
+      bool cand = false;
+#pragma unroll
+      for (int u = 0; u < kScanPad; ++u) {
+        if (u & 1) f_lo = pf[u]; else f_hi = pf[u];
+        const float fs = f_hi - f_lo;
+        cand = cand || fs <= th[u].x || fs >= th[u].y;
+      }
+      if (!__ballot(cand)) continue;                    // wave-uniform: nobody is near a threshold in this group
+      // the exact code needs p_lo as the skipped groups would have left it: the left end of the window of length L0 - 1
+      const int want = relc - ((L0 - 1) >> 1);
+      if (lo_at != want) { p_lo = S.P[want]; lo_at = want; }
+    }
     double pv[kScanPad], td[kScanPad], tu[kScanPad];
 #pragma unroll
     for (int u = 0; u < kScanPad; ++u) {
@@ -456,6 +502,7 @@ __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const dou
       td[u] = thr_del[L0 + u];
       tu[u] = thr_dup[L0 + u];
     }
+    if (PRE) { int Ll = L0 + kScanPad - 1; Ll = Ll > Lmax ? Lmax : Ll; lo_at = relc - (Ll >> 1); }   // where p_lo ends up after this group
     unsigned hits = 0;   // bit u: DEL score hit at L0+u, bit 8+u: DUP
 #pragma unroll
     for (int u = 0; u < kScanPad; ++u) {

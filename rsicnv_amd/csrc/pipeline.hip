@@ -1314,6 +1314,7 @@ const char* rsi_hot_last_error(const rsi_ctx* ctx) {
 }
 
 void rsi_hot_set_timing(rsi_ctx* ctx, int on) { if (ctx) ctx->timing = on < 0 ? 0 : on > 3 ? 1 : on; }
+void rsi_hot_set_timing_kernel(rsi_ctx* ctx, const char* name) { if (ctx) ctx->timing_kernel = (name && name[0]) ? name : "cap_compact_bin"; }
 
 int rsi_hot_run_device(rsi_ctx* ctx, const rsi_params* p, const void* d_depth, const void* d_fasta, int64_t n, rsi_result** out) {
   if (!ctx || !p || !d_depth || !d_fasta || !out) return fail(ctx, RSI_ERR_BAD_ARG, "null argument");

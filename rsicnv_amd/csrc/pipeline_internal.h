@@ -121,7 +121,8 @@ struct rsi_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t sync_ev = nullptr;   // event every wait on the stream polls (stream_wait)
   std::string err;
-  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around cap_compact_bin only
+  int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around the kernel named timing_kernel only
+  std::string timing_kernel = "cap_compact_bin";
   std::vector<KernelTime> ktimes;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
@@ -308,7 +309,7 @@ constexpr int kMaxL = kMaxScanL;
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
   Timer(rsi_ctx* c, const char* nm, bool per_base = false) : ctx(c), name(nm) {
-    if (!ctx->timing || (ctx->timing == 2 && !per_base) || (ctx->timing == 3 && strcmp(nm, "cap_compact_bin") != 0)) return;
+    if (!ctx->timing || (ctx->timing == 2 && !per_base) || (ctx->timing == 3 && ctx->timing_kernel != nm)) return;
     auto get = [&]() { if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); } return ctx->event_pool[ctx->event_next++]; };
     a = get(); b = get();
     (void)hipEventRecord(a, ctx->stream);

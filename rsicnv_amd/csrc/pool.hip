@@ -104,6 +104,7 @@ void rsi_pool_destroy(rsi_pool* pool) {
 int rsi_pool_workers(const rsi_pool* pool) { return pool ? (int)pool->workers.size() : 0; }
 rsi_ctx* rsi_pool_worker(rsi_pool* pool, int w) { return (pool && w >= 0 && w < (int)pool->workers.size()) ? pool->workers[(size_t)w] : nullptr; }
 void rsi_pool_set_timing(rsi_pool* pool, int on) { if (pool) for (rsi_ctx* c : pool->workers) rsi_hot_set_timing(c, on); }
+void rsi_pool_set_timing_kernel(rsi_pool* pool, const char* name) { if (pool) for (rsi_ctx* c : pool->workers) rsi_hot_set_timing_kernel(c, name); }
 void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
   if (!pool) return;
   std::lock_guard<std::mutex> lk(pool->gate.m);

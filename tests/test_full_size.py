@@ -127,7 +127,8 @@ def test_config4_one_60x_med_chromosome_against_reference_golden(hot, hotlib):
 
 def test_config3_genome_in_flight_equals_one_at_a_time_and_golden(hot, hotlib):
     """configs[3]: the 24 chromosomes of the 3 Gb genome, twelve in flight on one GPU: every chromosome's calls and statistics
-    equal the same chromosome alone on one context, and three of them (<= 60 Mb) equal the reference's golden tables."""
+    equal the same chromosome alone on one context, and four of them (chr8 at 142 Mb, three of <= 60 Mb) equal the
+    reference's golden tables."""
     from rsicnv_amd import api, synth
     flags = synth.config_flags(4)
     params = api.make_params(**flags)
@@ -148,9 +149,65 @@ def test_config3_genome_in_flight_equals_one_at_a_time_and_golden(hot, hotlib):
             for k in ("RDmedian", "RDsd", "cap_median", "nb_mad", "tmedian1", "tlamda1", "tmedian2", "tlamda2", "Lmax", "n_compact", "nbins"):
                 assert one.stats[k] == other.stats[k], (c + 1, k)
         ncalls += len(one.calls("calls"))
-        if c in (18, 20, 21):
+        if c in (7, 18, 20, 21):          # chr8 (142 Mb) is one of the twelve that start together; the other three are <= 60 Mb
             g, gplan, gflags = _golden(f"cfg4_chr{c + 1}")
             assert _plan(gplan)["seed"] == plans[c]["seed"] and gflags == flags
             _check_against_golden(a, g, f"chr{c + 1} in flight")
     pool.close()
     assert ncalls >= 300
+
+
+def _digest(results):
+    """Everything a run reports for its chromosomes, as one comparable tuple (exact: no tolerance anywhere)."""
+    out = []
+    for r in results:
+        st = r.stats
+        out.append((tuple(st[k] for k in ("RDmedian", "RDsd", "cap_median", "gc_rdmean", "nb_mad", "nb_r", "nb_tmin", "tmedian1", "tsigma1",
+                                          "tlamda1", "tmedian2", "tsigma2", "tlamda2", "Lmax", "n_compact", "nbins", "trim_escapes", "inexact_sums")),
+                    tuple(tuple(c[k] for k in ("start", "end", "type", "qscore", "score", "p1", "cnvmed", "cnviqr", "refmed", "refiqr"))
+                          for which in ("calls_raw", "calls") for c in r.calls(which))))
+    return tuple(out)
+
+
+@pytest.mark.timeout(240)
+def test_soak_of_the_in_kernel_hand_over(hotlib):
+    """The kernels hand partial results from workgroup to workgroup without fences (device_util.h: write-through stores, a
+    per-wave wait, arrival counters) -- a protocol whose one known failure showed once in a few thousand launches, under
+    load.  Soak: a genome of six chromosomes (3 - 13 Mb: hundreds of workgroups per launch, every fold with all its groups)
+    through TWO pools at once, several hundred passes each; every pass of either pool must report exactly what the first
+    pass reported.  Both pools share the GPU, so launches of one are the uneven load of the other."""
+    import threading
+    import time
+    from rsicnv_amd import api, synth
+    plans = [synth.make_plan(n=3_000_017 + 2_000_003 * i, seed=0x50A4 + i, model=1, n_events=6, gaps=2, max_len=30000, end_n=5000,
+                             gap_len=8000, centromere=40000) for i in range(6)]
+    bufs = [_device_case(hotlib, p) for p in plans]
+    args = [(b[0].data_ptr(), b[1].data_ptr(), p["n"]) for b, p in zip(bufs, plans)]
+    params = api.make_params()
+    pools = [api.RsiPool(0, 6), api.RsiPool(0, 6)]
+    first = _digest(pools[0].run(params, args))
+    assert sum(len(c[1]) for c in first) > 0
+    passes, budget_s = 400, 50.0
+    failures, done = [], [0, 0]
+    t_end = time.time() + budget_s
+
+    def soak(k):
+        for it in range(passes):
+            if time.time() > t_end:
+                break
+            d = _digest(pools[k].run(params, args))
+            if d != first:
+                bad = [i for i, (x, y) in enumerate(zip(d, first)) if x != y]
+                failures.append((k, it, bad))
+                break
+            done[k] += 1
+
+    threads = [threading.Thread(target=soak, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for p in pools:
+        p.close()
+    assert not failures, f"pass differs from the first: (pool, pass, chromosomes) {failures}"
+    assert min(done) >= 300, f"only {done} passes inside {budget_s} s"

@@ -5,6 +5,7 @@ GPU suite checks at their stated sizes (tests/test_full_size.py):
   cfg2_60mb           configs[1]: the 60 Mb Poisson chromosome, -m 101 -NB
   cfg3_250mb          configs[2]: the 250 Mb gamma-Poisson chromosome, -m 101 -NB
   cfg4_chr19/21/22    configs[3]: three chromosomes (<= 60 Mb) of the 24-chromosome 3 Gb genome, -m 101 -NB
+  cfg4_chr8           configs[3]: a 142 Mb chromosome of the same genome (the in-flight check's large one)
   cfg5_chr13          configs[4]: one 60x chromosome of 112 Mb, -m 51 -MED -cap 4
 
 Per case: the plan, sha256 of the generated inputs (guards against generator drift), chromosome median / SD, the padded N
@@ -25,7 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CALL_KEYS = ("start", "end", "type", "geno", "status", "length", "qscore", "score", "p1", "cnvmed", "cnvsd", "cnviqr",
              "refmed", "refsd", "refiqr")
-CASES = {"cfg2_60mb": (2, 0), "cfg3_250mb": (3, 0), "cfg4_chr19": (4, 18), "cfg4_chr21": (4, 20), "cfg4_chr22": (4, 21), "cfg5_chr13": (5, 12)}
+CASES = {"cfg2_60mb": (2, 0), "cfg3_250mb": (3, 0), "cfg4_chr19": (4, 18), "cfg4_chr21": (4, 20), "cfg4_chr22": (4, 21), "cfg5_chr13": (5, 12),
+         "cfg4_chr8": (4, 7)}   # a chromosome of 140 Mb and more for the in-flight check
 
 
 def sha(a):

@@ -38,5 +38,8 @@ if "--json" in sys.argv:
         if k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
             d["kernels"][short] = {"FETCH_SIZE_KB": acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1],
                                    "WRITE_SIZE_KB": acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]}
+            for extra in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVES"):   # wave-instructions per launch (bench.py: the `valu` fraction)
+                if extra in acc[k]:
+                    d["kernels"][short][extra] = acc[k][extra][0] / acc[k][extra][1]
     with open(out, "w") as f:
         json.dump(d, f, indent=1)
