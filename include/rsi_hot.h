@@ -79,6 +79,8 @@ typedef struct rsi_chrom_stats {
   double t_device_ms;   /* wall time of the call, inputs already on the device */
   double t_kernels_ms;  /* sum of HIP-event times around the per-base kernels */
   int64_t byte_escapes; /* bases of depth >= 255: the per-base kernels fetch those from the int32 array instead of the byte copy */
+  int32_t scan_tiles;        /* tiles of 256 bins per scan pass */
+  int32_t scan_tiles_listed; /* tiles the detection passes of the (last) scan listed for the exact sweep, both passes together */
 } rsi_chrom_stats;
 
 typedef struct rsi_ctx rsi_ctx;

@@ -52,7 +52,7 @@ class RsiChromStats(C.Structure):
                 ("tmedian1", C.c_double), ("tsigma1", C.c_double), ("tlamda1", C.c_double), ("tmedian2", C.c_double),
                 ("tsigma2", C.c_double), ("tlamda2", C.c_double), ("trim_escapes", C.c_int32),
                 ("inexact_sums", C.c_int32), ("t_device_ms", C.c_double), ("t_kernels_ms", C.c_double),
-                ("byte_escapes", C.c_int64)]
+                ("byte_escapes", C.c_int64), ("scan_tiles", C.c_int32), ("scan_tiles_listed", C.c_int32)]
 
 
 RSI_MAX_TIMED = 64

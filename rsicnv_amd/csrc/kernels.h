@@ -206,9 +206,14 @@ constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable e
 constexpr int kThrInline = 232;   // thresholds that fit the kernel arguments: Lmax + 1 + kScanPad <= kThrInline
 struct ScanThr { double del[kThrInline]; double dup[kThrInline]; };
 // inl != NULL: thresholds in the kernel arguments (thr_del / thr_dup unused)
+// Two launches (kernels_bin.hip): a detection pass lists the tiles of 256 bins in which any lane can hit at any L (float
+// prefixes against thresholds widened by the rounding bound: a superset), the exact sweep then runs on the listed tiles only,
+// each tile's lengths split over several workgroups.  tiles: scratch for (nb / 256 + 1) tile indices; NULL = no detection
+// pass, every tile through the exact sweep.  counters: the pass' work block (zero before): [0] trim escapes, [1] values
+// breaking the exact-sum precondition, [8] tiles listed, [9] the exact sweep's task counter.
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del,
                      const double* thr_dup, const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
-                     hipStream_t stream);
+                     uint32_t* tiles, hipStream_t stream);
 // Stop levels of the two sweeps (rsi.cpp:1225, 1255; DEL marks win, App. A Q14) in one launch.
 // work: [16 uint32: escapes, inexact (the scan's), ldel, ldup, both-count, ...][hist_del kMaxLevels][hist_dup kMaxLevels], zero
 // before the scan; both: scratch for kBothCap (first_del, first_dup) pairs.  The last workgroup copies host_bytes of work to

@@ -338,8 +338,6 @@ struct ScanLds {     // plain base pointers and one stride: nothing here is inde
   uint16_t* CB;     // four prefix-count arrays CL, CG, CTd, CTu, `stride` apart (count + 1 used)
   uint16_t* RB;     // four position-by-rank arrays, `stride` apart
   uint16_t* PF;     // count: predicate bits of each staged bin (bit q = predicate q)
-  float* Pf;        // count + 1: the prefixes rounded to float (the score pre-filter; NULL without it)
-  float2* TH;       // Lmax + 1 + kScanPad: the pre-filter's thresholds per L (x: DEL, y: DUP), widened by the rounding bound
   int stride;       // count + 2
   int count, kcap;
   __device__ uint16_t& C(int q, int x) const { return CB[q * stride + x]; }
@@ -348,19 +346,13 @@ struct ScanLds {     // plain base pointers and one stride: nothing here is inde
 };
 enum { kCL = 0, kCG = 1, kCTd = 2, kCTu = 3 };
 
-__host__ __device__ inline size_t scan_lds_base_bytes(int count, int kcap) {
+__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap) {
   size_t b = ((size_t)(count + 1) + kThreads) * sizeof(double);
   b += 2 * (size_t)(kcap + 1) * count * 4 + (size_t)count * 4;
   b += 9 * (size_t)(count + 2) * 2;
-  return (b + 7) & ~(size_t)7;
-}
-// pre = 1: room for the float prefixes and the per-L float thresholds of the score pre-filter behind the base layout
-__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap, int pre = 0, int Lmax = 0) {
-  size_t b = scan_lds_base_bytes(count, kcap);
-  if (pre) b += (size_t)(Lmax + 1 + kScanPad) * 8 + (((size_t)count + 2) & ~(size_t)1) * 4;
   return b;
 }
-__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap, int pre = 0, int Lmax = 0) {
+__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap) {
   S.count = count; S.kcap = kcap; S.stride = count + 2;
   S.P = sm;
   S.tot = S.P + count + 1;
@@ -369,11 +361,6 @@ __device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kca
   S.CB = reinterpret_cast<uint16_t*>(S.M + count);
   S.RB = S.CB + 4 * S.stride;
   S.PF = S.RB + 4 * S.stride;
-  S.Pf = nullptr; S.TH = nullptr;
-  if (pre) {
-    S.TH = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(sm) + scan_lds_base_bytes(count, kcap));
-    S.Pf = reinterpret_cast<float*>(S.TH + (Lmax + 1 + kScanPad));
-  }
 }
 
 // first staged position >= x where predicate q holds, vhi when none; last position <= x, vlo-1 when none
@@ -452,46 +439,85 @@ struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; }
 struct ScanRun { int lastL, i1, i2; };
 struct ScanMid { int upto, a, b; };
 
-// PRE: the score pre-filter.  Nearly every (bin, L) pair is far from both thresholds (0.5 % of the pairs of a 30x genome are
-// hits, in 0.5 % of the waves), and the exact test costs a 64-bit LDS read, an f64 subtraction and two f64 compares (half
-// rate) with their hazard bubbles per pair, plus the wave's wait for sixteen scalar threshold loads per group.  The filter
-// decides a whole group of eight L for the whole wave from FLOAT prefixes: |fl32(Pf[hi] - Pf[lo]) - (P[hi] - P[lo])| <=
-// 3 * 2^-24 * max|P| (one rounding per prefix, one in the subtraction), so with thresholds widened by 4 * 2^-24 * max|P| of
-// THIS tile (ScanLds::TH, built per workgroup) "no float hit" implies "no exact hit".  Only a group in which some lane's
-// float test fires runs the exact code below -- unchanged, so the marks are bit for bit what they were.
-template <bool EDGE, bool PRE>
+// The hits of one side (SIDE 0 = DEL, 1 = DUP) in one group of kScanPad lengths, in increasing L.  What every length of the group
+// may need from LDS -- the two ends of the median-predicate count of its window and the predicate bits of the bin the window
+// gained -- is read for all eight lengths at once, before the first hit is looked at: inside an event every lane hits at every
+// L, and three dependent LDS round trips per hit add up over a hundred hits.  The rare cases (first hit of a run, a bin whose
+// median predicate fails, the straddling median) still go to LDS when they come up.
+template <int SIDE>
+__device__ inline void scan_hits_side(const ScanLds& S, const ScanTile& t, unsigned hs, int relc, int L0, int Lmax, ScanRun& run,
+                                      ScanMid& mid, uint32_t* counters) {
+  constexpr int qm = SIDE ? kCG : kCL, qt = SIDE ? kCTu : kCTd;
+  int cw[kScanPad];          // bins of the window beyond the median limit
+  unsigned pb[kScanPad];     // predicate bits of the bin the window gained at this length
+#pragma unroll
+  for (int u = 0; u < kScanPad; ++u) {
+    int L = L0 + u;
+    L = L > Lmax ? Lmax : L;                       // a bit of hs is never set past Lmax; stay in range
+    const int hh = L >> 1, w0 = relc - hh;
+    cw[u] = (int)S.C(qm, w0 + L) - (int)S.C(qm, w0);
+    pb[u] = S.PF[(L & 1) ? w0 + L - 1 : w0];       // even L: the window grew on the left
+  }
+#pragma unroll
+  for (int u = 0; u < kScanPad; ++u) {
+    if (!((hs >> u) & 1u)) continue;
+    const int L = L0 + u;
+    const bool grew_left = !(L & 1);
+    const int hh = L >> 1, w0 = relc - hh, e = w0 + L - 1;
+    const int c = cw[u];
+    bool pass = c >= hh + 1;                         // enough bins beyond the limit for either parity
+    if (!pass && grew_left && c == hh) {             // even L, the two middle elements straddle the limit: need their values
+      ScanMid m = mid;
+      const int thr = SIDE ? t.ce_dup : t.fl_del;
+      const int ow0 = relc - (m.upto >> 1), oe = ow0 + m.upto - 1;   // window the pair covers (empty for upto = 0)
+      const int* M = S.M;
+      // DEL: a = max{x <= thr}, b = min{x > thr}; DUP: a = max{x < thr}, b = min{x >= thr}
+      auto fold = [&](int j) {
+        const int x = M[j];
+        const bool near = SIDE ? x < thr : x <= thr;
+        if (near) m.a = x > m.a ? x : m.a; else m.b = x < m.b ? x : m.b;
+      };
+      for (int j = w0; j < ow0; ++j) fold(j);        // the bins gained on the left since ...
+      for (int j = oe + 1; j <= e; ++j) fold(j);     // ... and on the right
+      m.upto = L;
+      mid = m;
+      const double md = 0.5 * ((double)m.a + (double)m.b);
+      pass = SIDE ? !(md < t.lim_dup) : !(md > t.lim_del);   // rsi.cpp:1236 / 1206
+    }
+    const ScanRun old = run;
+    ScanRun now = {-1, 0, 0};
+    if (pass && old.lastL == L - 1) {                // the run continues
+      const int g = grew_left ? w0 : e;
+      const unsigned bits = pb[u];
+      const bool vt = (bits >> qt) & 1u, vm = (bits >> qm) & 1u;
+      now.lastL = L; now.i1 = old.i1; now.i2 = old.i2;
+      int lo_m, hi_m;
+      if (grew_left) {
+        if (vt) now.i1 = vm ? g : scan_next(S, qm, g, t.vhi);
+        lo_m = now.i1; hi_m = now.i2 < old.i1 - 1 ? now.i2 : old.i1 - 1;
+      } else {
+        if (vt) now.i2 = vm ? g : scan_prev(S, qm, g, t.vlo);
+        lo_m = now.i1 > old.i2 + 1 ? now.i1 : old.i2 + 1; hi_m = now.i2;
+      }
+      if (lo_m <= hi_m) scan_mark(S, SIDE, lo_m, hi_m, L);
+    } else if (pass) {
+      const int r = scan_hit_slow(S.count, S.kcap, w0, L, SIDE, t.vlo, t.vhi, t.ends, counters);
+      if (r >= 0) { now.lastL = L; now.i1 = r & 0xfff; now.i2 = (r >> 12) & 0xfff; }
+    }
+    run = now;
+  }
+}
+
+// [Lbeg, Lfin]: the lengths this workgroup looks at (Lbeg = 1 mod kScanPad, whole groups): a tile's lengths are split over
+// several workgroups (k_rsi_scan).  A lane that starts in the middle has no run to continue: its first hit takes the general
+// path (scan_hit_slow), exactly as the first hit of a run does, and smallest-L-wins is an atomicMin whoever comes first.
+template <bool EDGE>
 __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const double* __restrict__ thr_del,
-                                  const double* __restrict__ thr_dup, int relc, int Lmax, int Lend, uint32_t* counters) {
-  double p_lo = S.P[relc], p_hi = 0.0;
-  int lo_at = relc;                                   // staged index p_lo was read from (the pre-filter skips groups)
+                                  const double* __restrict__ thr_dup, int relc, int Lmax, int Lend, int Lbeg, int Lfin, uint32_t* counters) {
+  double p_lo = S.P[relc - ((Lbeg - 1) >> 1)], p_hi = 0.0;   // the left end of the window of length Lbeg - 1
   ScanRun run_del = {-1, 0, 0}, run_dup = {-1, 0, 0};
   ScanMid mid_del = {0, (int)0x80000000, 0x7fffffff}, mid_dup = {0, (int)0x80000000, 0x7fffffff};
-  float f_lo = 0.0f, f_hi = 0.0f;
-  if (PRE) f_lo = S.Pf[relc];
-  for (int L0 = 1; L0 <= Lmax; L0 += kScanPad) {
-    if (PRE) {
-      float pf[kScanPad];
-      float2 th[kScanPad];
-#pragma unroll
-      for (int u = 0; u < kScanPad; ++u) {
-        int L = L0 + u;
-        L = L > Lmax ? Lmax : L;
-        const int h = L >> 1;
-        pf[u] = S.Pf[(u & 1) ? relc - h : relc + h + 1];
-        th[u] = S.TH[L0 + u];                           // the same address in every lane: a broadcast read
-      }
-      bool cand = false;
-#pragma unroll
-      for (int u = 0; u < kScanPad; ++u) {
-        if (u & 1) f_lo = pf[u]; else f_hi = pf[u];
-        const float fs = f_hi - f_lo;
-        cand = cand || fs <= th[u].x || fs >= th[u].y;
-      }
-      if (!__ballot(cand)) continue;                    // wave-uniform: nobody is near a threshold in this group
-      // the exact code needs p_lo as the skipped groups would have left it: the left end of the window of length L0 - 1
-      const int want = relc - ((L0 - 1) >> 1);
-      if (lo_at != want) { p_lo = S.P[want]; lo_at = want; }
-    }
+  for (int L0 = Lbeg; L0 <= Lfin; L0 += kScanPad) {
     double pv[kScanPad], td[kScanPad], tu[kScanPad];
 #pragma unroll
     for (int u = 0; u < kScanPad; ++u) {
@@ -502,7 +528,6 @@ __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const dou
       td[u] = thr_del[L0 + u];
       tu[u] = thr_dup[L0 + u];
     }
-    if (PRE) { int Ll = L0 + kScanPad - 1; Ll = Ll > Lmax ? Lmax : Ll; lo_at = relc - (Ll >> 1); }   // where p_lo ends up after this group
     unsigned hits = 0;   // bit u: DEL score hit at L0+u, bit 8+u: DUP
 #pragma unroll
     for (int u = 0; u < kScanPad; ++u) {
@@ -513,66 +538,162 @@ __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const dou
       hits |= (hd ? 1u << u : 0u) | (hu ? 0x100u << u : 0u);
     }
     if (!__ballot(hits != 0)) continue;
-    while (hits) {
-      const int bit = __ffs(hits) - 1;
-      hits &= hits - 1u;
-      const int side = bit >> 3, L = L0 + (bit & 7);
-      const bool grew_left = !(L & 1);
-      const int qm = side ? kCG : kCL, qt = side ? kCTu : kCTd;
-      const int hh = L >> 1, w0 = relc - hh, e = w0 + L - 1;
-      const int c = (int)S.C(qm, w0 + L) - (int)S.C(qm, w0);
-      bool pass = c >= hh + 1;                         // enough bins beyond the limit for either parity
-      if (!pass && grew_left && c == hh) {             // even L, the two middle elements straddle the limit: need their values
-        ScanMid m = side ? mid_dup : mid_del;
-        const int thr = side ? t.ce_dup : t.fl_del;
-        const int ow0 = relc - (m.upto >> 1), oe = ow0 + m.upto - 1;   // window the pair covers (empty for upto = 0)
-        const int* M = S.M;
-        // DEL: a = max{x <= thr}, b = min{x > thr}; DUP: a = max{x < thr}, b = min{x >= thr}
-        auto fold = [&](int j) {
-          const int x = M[j];
-          const bool near = side ? x < thr : x <= thr;
-          if (near) m.a = x > m.a ? x : m.a; else m.b = x < m.b ? x : m.b;
-        };
-        for (int j = w0; j < ow0; ++j) fold(j);        // the bins gained on the left since ...
-        for (int j = oe + 1; j <= e; ++j) fold(j);     // ... and on the right
-        m.upto = L;
-        if (side) mid_dup = m; else mid_del = m;
-        const double mid = 0.5 * ((double)m.a + (double)m.b);
-        pass = side ? !(mid < t.lim_dup) : !(mid > t.lim_del);   // rsi.cpp:1236 / 1206
-      }
-      const ScanRun old = side ? run_dup : run_del;
-      ScanRun now = {-1, 0, 0};
-      if (pass && old.lastL == L - 1) {                // the run continues
-        const int g = grew_left ? w0 : e;
-        const unsigned bits = S.PF[g];
-        const bool vt = (bits >> qt) & 1u, vm = (bits >> qm) & 1u;
-        now.lastL = L; now.i1 = old.i1; now.i2 = old.i2;
-        int lo_m, hi_m;
-        if (grew_left) {
-          if (vt) now.i1 = vm ? g : scan_next(S, qm, g, t.vhi);
-          lo_m = now.i1; hi_m = now.i2 < old.i1 - 1 ? now.i2 : old.i1 - 1;
-        } else {
-          if (vt) now.i2 = vm ? g : scan_prev(S, qm, g, t.vlo);
-          lo_m = now.i1 > old.i2 + 1 ? now.i1 : old.i2 + 1; hi_m = now.i2;
-        }
-        if (lo_m <= hi_m) scan_mark(S, side, lo_m, hi_m, L);
-      } else if (pass) {
-        const int r = scan_hit_slow(S.count, S.kcap, w0, L, side, t.vlo, t.vhi, t.ends, counters);
-        if (r >= 0) { now.lastL = L; now.i1 = r & 0xfff; now.i2 = (r >> 12) & 0xfff; }
-      }
-      if (side) run_dup = now; else run_del = now;
-    }
+    if (__ballot((hits & 0xffu) != 0)) scan_hits_side<0>(S, t, hits & 0xffu, relc, L0, Lmax, run_del, mid_del, counters);
+    if (__ballot((hits >> 8) != 0)) scan_hits_side<1>(S, t, hits >> 8, relc, L0, Lmax, run_dup, mid_dup, counters);
   }
 }
 
+// ---- K7a  scan_detect: which tiles can have a hit at all? ------------------------------------------------------------------
+// Nearly every (bin, L) pair is far from both thresholds: 0.5 % of the pairs of a 30x genome are hits, all of them in the few
+// tiles that touch an event -- and those tiles are expensive: every lane inside an event hits at every L and pays the whole hit
+// path a hundred times in sequence, so with one kernel for everything a single wave that lay in an event was the critical
+// path of the launch (a fixed 70 us of a 150 us pass, whatever the chromosome's length and however few its events), and every
+// tile paid for staging the structures only hits need (mark tables, rank arrays, bin medians).
+// So the scan is two launches.  This one decides, tile by tile, whether any lane can hit at any L, from FLOAT prefixes:
+// |fl32(Pf[hi] - Pf[lo]) - (P[hi] - P[lo])| <= 3 * 2^-24 * max|P| (one rounding per prefix -- they are rounded from the exact
+// double prefixes -- and one in the subtraction), so against thresholds widened by 4 * 2^-24 * max|P| of the workgroup's own
+// stretch and rounded outwards, "no float hit" implies "no exact hit".  It lists the tiles where a float test fires; k_rsi_scan
+// then runs the exact sweep on those tiles only, its lengths split over several workgroups.  A listed tile without a real hit
+// costs time, never correctness; a chromosome-end tile ignores the cut-off of its lanes' lengths here (a superset again).
+// One workgroup = kDetTiles tiles of kScanTile bins (one per wave; lane l looks at bins l, l + 64, l + 128, l + 192 of its
+// tile: four independent chains per lane), staged with one halo for all of them.
+constexpr int kScanPartsMax = 8;                   // shares of a listed tile's lengths (k_rsi_scan)
+constexpr int kDetTiles = 4;                       // tiles per workgroup = waves per workgroup
+constexpr int kDetBins = kDetTiles * kScanTile;    // 1024
+__host__ __device__ inline size_t detect_lds_bytes(int Lmax) {
+  const int halo = Lmax / 2 + 1, count = kDetBins + 2 * halo;
+  return (size_t)(Lmax + 1 + kScanPad) * 8 + (((size_t)count + 2) & ~(size_t)1) * 4 + 16;
+}
+template <bool INL>
+__global__ __launch_bounds__(kThreads) void k_scan_detect(const float* __restrict__ T, int64_t nb, int Lmax,
+                                                          const double* __restrict__ thr_del_mem, const double* __restrict__ thr_dup_mem,
+                                                          uint32_t* __restrict__ tiles /* out: listed tiles */, uint32_t* __restrict__ counters
+                                                          /* [1]: inexact values, [8]: tiles listed */, ScanThr inl) {
+  extern __shared__ __align__(16) double sm[];
+  const double* __restrict__ thr_del = INL ? inl.del : thr_del_mem;
+  const double* __restrict__ thr_dup = INL ? inl.dup : thr_dup_mem;
+  const int halo = Lmax / 2 + 1;
+  const int count = kDetBins + 2 * halo;
+  float2* TH = reinterpret_cast<float2*>(sm);                           // per L: (DEL, DUP) float thresholds of this workgroup
+  float* Pf = reinterpret_cast<float*>(TH + (Lmax + 1 + kScanPad));     // count + 1 prefixes
+  __shared__ double s_tot[kThreads];
+  __shared__ unsigned int s_pmax;
+  const int64_t first = (int64_t)blockIdx.x * kDetBins;
+  const int64_t lo = first - halo;
+  if (threadIdx.x == 0) s_pmax = 0u;
+  // ---- exact double prefix of the staged stretch (serial chunk per thread + scan of the chunk totals), rounded to float ----
+  const int chunk = (count + kThreads - 1) / kThreads;
+  const int c0 = threadIdx.x * chunk;
+  double run = 0.0;
+  unsigned int inexact = 0;
+  for (int e = c0; e < c0 + chunk && e < count; ++e) {
+    const int64_t i = lo + e;
+    const float v = (i >= 0 && i < nb) ? T[i] : 0.0f;
+    // exact-sum precondition of the exact sweep: 0, or 2^-10 <= |v| < 2^20; counted once, by the owning workgroup
+    const float av = fabsf(v);
+    if (!(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && e >= halo && e < halo + kDetBins) inexact++;
+    run += (double)v;
+  }
+  s_tot[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
+    double carry = 0.0;
+    for (int k = 0; k < kThreads / 64; ++k) {
+      const int idx = k * 64 + threadIdx.x;
+      const double mine = s_tot[idx];
+      double incl = mine;
+      for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
+      s_tot[idx] = carry + incl - mine;
+      carry += __shfl(incl, 63);
+    }
+  }
+  __syncthreads();
+  {
+    double acc = s_tot[threadIdx.x];
+    float amax = 0.0f;
+    if (threadIdx.x == 0) Pf[0] = 0.0f;
+    for (int e = c0; e < c0 + chunk && e < count; ++e) {
+      const int64_t i = lo + e;
+      const float v = (i >= 0 && i < nb) ? T[i] : 0.0f;   // a second read (L1 / L2) instead of 8 bytes of LDS per staged bin
+      acc += (double)v;
+      const float pf = (float)acc;
+      Pf[e + 1] = pf;
+      const float a = fabsf(pf);
+      amax = (a > amax || !(a == a)) ? a : amax;          // a NaN sticks: the thresholds then list every tile of the workgroup
+    }
+    // max over the stretch as an integer maximum of float bits (the order of non-negative floats; NaN and infinity on top)
+    unsigned int ab = __float_as_uint(amax);
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)ab, d); ab = o > ab ? o : ab; }
+    if (lane_id() == 0) atomicMax(&s_pmax, ab);
+  }
+  for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
+  if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
+  __syncthreads();
+  {
+    const double pmax = (double)__uint_as_float(s_pmax);
+    const double margin = pmax * (4.0 / 16777216.0);
+    const bool open_all = !(margin == margin) || margin > 3.0e38;   // NaN / overflowing bound: every sum is a candidate
+    for (int L = threadIdx.x; L < Lmax + 1 + kScanPad; L += kThreads) {
+      const double d = thr_del[L] + margin, u = thr_dup[L] - margin;
+      float fd = (float)d, fu = (float)u;
+      if ((double)fd < d) fd = nextafterf(fd, INFINITY);
+      if ((double)fu > u) fu = nextafterf(fu, -INFINITY);
+      if (open_all) { fd = INFINITY; fu = -INFINITY; }
+      TH[L] = make_float2(fd, fu);
+    }
+  }
+  __syncthreads();
+  // ---- every (bin, L) of the wave's tile, four bins per lane; the wave stops at its first candidate ----
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t tile = (int64_t)blockIdx.x * kDetTiles + wave;
+  if (tile * kScanTile >= nb) return;
+  const int rel0 = halo + wave * kScanTile + lane;          // staged index of the lane's first bin
+  float f_lo[4], f_hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f_lo[b] = Pf[rel0 + 64 * b];
+  unsigned long long cand = 0;
+  for (int L0 = 1; L0 <= Lmax && cand == 0; L0 += kScanPad) {
+    float2 th[kScanPad];
+    int off[kScanPad];   // wave-uniform: staged offset of the prefix value that is new at this length
+#pragma unroll
+    for (int u = 0; u < kScanPad; ++u) {
+      int L = L0 + u;
+      L = L > Lmax ? Lmax : L;                              // past Lmax the thresholds are unreachable; just stay in range
+      const int h = L >> 1;
+      off[u] = (u & 1) ? -h : h + 1;                        // L0 is odd: odd u <=> even L <=> the window grew on the left
+      th[u] = TH[L0 + u];                                   // the same address in every lane: a broadcast read
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float pf[kScanPad];
+#pragma unroll
+      for (int u = 0; u < kScanPad; ++u) pf[u] = Pf[rel0 + 64 * b + off[u]];
+#pragma unroll
+      for (int u = 0; u < kScanPad; ++u) {
+        if (u & 1) f_lo[b] = pf[u]; else f_hi[b] = pf[u];
+        const float fs = f_hi[b] - f_lo[b];
+        // wave masks straight from the compares, OR-ed with scalar instructions: no per-lane flag, no branches
+        cand |= __builtin_amdgcn_ballot_w64(fs <= th[u].x) | __builtin_amdgcn_ballot_w64(fs >= th[u].y);
+      }
+    }
+  }
+  if (cand != 0 && lane == 0) tiles[atomicAdd(&counters[8], 1u)] = (uint32_t)tile;
+}
+
+// ---- K7b  rsi_scan: the exact sweep on the listed tiles -----------------------------------------------------------------
 // INL: the thresholds ride in the kernel arguments (Lmax <= kThrInline - kScanPad - 1: every configuration BASELINE names);
 // otherwise they are read from device memory the host uploaded.
+// A task = (listed tile, share of the lengths): `parts` tasks per tile, each staging the tile for itself and sweeping its whole
+// groups of kScanPad lengths -- the chain of hits a lane inside an event walks through is cut in `parts`, the tile's marks are
+// atomicMin whoever makes them.  Workgroups pull tasks from a counter (counters[9]) until it runs past the list; tiles ==
+// NULL: every tile of the chromosome is a task list of its own (no detection pass in front).
 template <bool INL>
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
                                                        ScanParams sp, const double* __restrict__ thr_del_mem,
                                                        const double* __restrict__ thr_dup_mem,
                                                        uint32_t* __restrict__ first_del, uint32_t* __restrict__ first_dup,
-                                                       uint32_t* __restrict__ counters, ScanThr inl) {
+                                                       uint32_t* __restrict__ counters, const uint32_t* __restrict__ tiles, int parts,
+                                                       ScanThr inl) {
   extern __shared__ __align__(16) double sm[];
   const double* __restrict__ thr_del = INL ? inl.del : thr_del_mem;
   const double* __restrict__ thr_dup = INL ? inl.dup : thr_dup_mem;
@@ -581,130 +702,149 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   const int count = kScanTile + 2 * halo;          // staged bins
   ScanLds S;
   scan_lds_carve(S, sm, count, kcap);
-  const int64_t tile_start = (int64_t)blockIdx.x * kScanTile;
-  const int64_t lo = tile_start - halo;
-  const int vlo = lo < 0 ? (int)(-lo) : 0;
-  const int vhi = (lo + count > sp.nb) ? (int)(sp.nb - lo) : count;
-  const bool at_start = lo <= 0, at_end = lo + count >= sp.nb;
+  __shared__ int s_c[4][kThreads];
+  __shared__ unsigned int s_task;
   // integer forms of the median limits: x > lim_del <=> x > fl_del ; x < lim_dup <=> x < ce_dup
   const int fl_del = (int)floor(sp.lim_del), ce_dup = (int)ceil(sp.lim_dup);
   const double tmed = sp.tmedian;
-  for (int e = threadIdx.x; e < 2 * (kcap + 1) * count; e += kThreads) S.TB[e] = kUnmarked;
-  // ---- stage + exact prefixes: serial chunk per thread, then a scan of the 256 chunk totals ----
-  const int chunk = (count + kThreads - 1) / kThreads;
-  const int c0 = threadIdx.x * chunk;
-  double run = 0.0;
-  int rc[4] = {0, 0, 0, 0};
-  unsigned int inexact = 0;
-  for (int e = c0; e < c0 + chunk && e < count; ++e) {
-    const bool in = e >= vlo && e < vhi;
-    const float v = in ? T[lo + e] : 0.0f;
-    const int mi = in ? medint[lo + e] : 0;
-    // exact-sum precondition: 0, or 2^-10 <= |v| < 2^20; counted once, by the owning tile
-    const float av = fabsf(v);
-    if (!(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && e >= halo && e < halo + kScanTile) inexact++;
-    S.M[e] = mi;
-    run += (double)v;
-    rc[kCL] += (in && mi <= fl_del);
-    rc[kCG] += (in && mi >= ce_dup);
-    rc[kCTd] += (in && !((double)v > tmed));       // where a DEL value walk stops (rsi.cpp:1211, 1213)
-    rc[kCTu] += (in && !((double)v < tmed));       // where a DUP value walk stops (rsi.cpp:1241, 1243)
-    S.P[e + 1] = run;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) S.C(q, e + 1) = (uint16_t)rc[q];
-  }
-  __shared__ int s_c[4][kThreads];
-  S.tot[threadIdx.x] = run;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) s_c[q][threadIdx.x] = rc[q];
-  if (threadIdx.x == 0) { S.P[0] = 0.0; for (int q = 0; q < 4; ++q) S.C(q, 0) = 0; }
-  __syncthreads();
-  if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
-    double carry = 0.0;
-    int car[4] = {0, 0, 0, 0};
-    for (int k = 0; k < kThreads / 64; ++k) {
-      const int idx = k * 64 + threadIdx.x;
-      const double mine = S.tot[idx];
-      double incl = mine;
-      int m4[4], i4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { m4[q] = s_c[q][idx]; i4[q] = m4[q]; }
-      for (int d = 1; d < 64; d <<= 1) {
-        const double up = __shfl_up(incl, d);
-        int u4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) u4[q] = __shfl_up(i4[q], d);
-        if ((int)threadIdx.x >= d) {
-          incl += up;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) i4[q] += u4[q];
-        }
-      }
-      S.tot[idx] = carry + incl - mine;
-      carry += __shfl(incl, 63);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += __shfl(i4[q], 63); }
-    }
-  }
-  __syncthreads();
-  {
-    const double off = S.tot[threadIdx.x];
-    int o4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o4[q] = s_c[q][threadIdx.x];
-    int before[4] = {o4[0], o4[1], o4[2], o4[3]};   // global count before element e
+  const int groups = (Lmax + kScanPad - 1) / kScanPad, per_part = (groups + parts - 1) / parts;
+  const unsigned int ntiles = tiles ? counters[8] : (unsigned int)((sp.nb + kScanTile - 1) / kScanTile);
+  const unsigned int ntasks = ntiles * (unsigned int)parts;
+  for (;;) {
+    __syncthreads();   // the previous task's LDS is no longer read
+    if (threadIdx.x == 0) s_task = atomicAdd(&counters[9], 1u);
+    __syncthreads();
+    const unsigned int task = s_task;
+    if (task >= ntasks) break;   // every wave reaches this: the grid drains
+    const unsigned int tslot = task / (unsigned int)parts;
+    const int part = (int)(task - tslot * (unsigned int)parts);
+    const int Lbeg = 1 + part * per_part * kScanPad;
+    int Lfin = (part + 1) * per_part * kScanPad;
+    Lfin = Lfin > Lmax ? Lmax : Lfin;
+    if (Lbeg > Lfin) continue;
+    const int64_t tile_start = (int64_t)(tiles ? tiles[tslot] : tslot) * kScanTile;
+    const int64_t lo = tile_start - halo;
+    const int vlo = lo < 0 ? (int)(-lo) : 0;
+    const int vhi = (lo + count > sp.nb) ? (int)(sp.nb - lo) : count;
+    const bool at_start = lo <= 0, at_end = lo + count >= sp.nb;
+    for (int e = threadIdx.x; e < 2 * (kcap + 1) * count; e += kThreads) S.TB[e] = kUnmarked;
+    // ---- stage + exact prefixes: serial chunk per thread, then a scan of the 256 chunk totals ----
+    const int chunk = (count + kThreads - 1) / kThreads;
+    const int c0 = threadIdx.x * chunk;
+    double run = 0.0;
+    int rc[4] = {0, 0, 0, 0};
+    unsigned int inexact = 0;
     for (int e = c0; e < c0 + chunk && e < count; ++e) {
-      S.P[e + 1] += off;
-      unsigned bits = 0;
+      const bool in = e >= vlo && e < vhi;
+      const float v = in ? T[lo + e] : 0.0f;
+      const int mi = in ? medint[lo + e] : 0;
+      // exact-sum precondition: 0, or 2^-10 <= |v| < 2^20; counted once per bin: by the detection pass
+      // when there is one, else by the owning tile's first part
+      const float av = fabsf(v);
+      if (!tiles && part == 0 && !(av == 0.0f || (av >= 0.0009765625f && av < 1048576.0f)) && e >= halo && e < halo + kScanTile) inexact++;
+      S.M[e] = mi;
+      run += (double)v;
+      rc[kCL] += (in && mi <= fl_del);
+      rc[kCG] += (in && mi >= ce_dup);
+      rc[kCTd] += (in && !((double)v > tmed));       // where a DEL value walk stops (rsi.cpp:1211, 1213)
+      rc[kCTu] += (in && !((double)v < tmed));       // where a DUP value walk stops (rsi.cpp:1241, 1243)
+      S.P[e + 1] = run;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int after = (int)S.C(q, e + 1) + o4[q];
-        S.C(q, e + 1) = (uint16_t)after;
-        if (after != before[q]) { S.R(q, before[q]) = (uint16_t)e; bits |= 1u << q; }   // e is the before[q]-th bin with predicate q
-        before[q] = after;
-      }
-      S.PF[e] = (uint16_t)bits;
+      for (int q = 0; q < 4; ++q) S.C(q, e + 1) = (uint16_t)rc[q];
     }
-  }
-  for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
-  if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
-  __syncthreads();
-
-  // ---- every (bin, L) of the tile.  Going from L-1 to L the window gains one bin -- on the left for
-  // even L, on the right for odd L -- so one prefix value per step is new.  ----
-  ScanTile tile;
-  tile.vlo = vlo; tile.vhi = vhi; tile.fl_del = fl_del; tile.ce_dup = ce_dup;
-  tile.lim_del = sp.lim_del; tile.lim_dup = sp.lim_dup; tile.ends = (at_start ? 1 : 0) | (at_end ? 2 : 0);
-  const bool edge_tile = at_start || at_end;   // only there can a lane's L range be cut short
-  for (int r = 0; r < kScanTile / kThreads; ++r) {
-    const int64_t i = tile_start + r * kThreads + threadIdx.x;
-    const int rel = (int)(i - lo);   // staged index of bin i
-    // the reference visits i in [L/2+1, nb-L/2-2] (rsi.cpp:1204): L/2 <= min(i-1, nb-i-2)
-    const int64_t hmax = (i - 1) < (sp.nb - i - 2) ? (i - 1) : (sp.nb - i - 2);
-    int Lend = (i < sp.nb && hmax >= 0) ? (int)(hmax < Lmax ? 2 * hmax + 1 : Lmax) : 0;
-    if (Lend > Lmax) Lend = Lmax;
-    const int relc = Lend > 0 ? rel : halo;   // lanes without a bin read a harmless address
-    if (edge_tile) scan_sweep<true>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, counters);
-    else scan_sweep<false>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, counters);
-  }
-  __syncthreads();
-  // ---- push the block levels down to single bins ----
-  for (int k = kcap; k >= 1; --k) {
-    const int half = 1 << (k - 1);
-    uint32_t* hd = S.level(0, k); uint32_t* ld = S.level(0, k - 1);
-    uint32_t* hu = S.level(1, k); uint32_t* lu = S.level(1, k - 1);
-    for (int e = threadIdx.x; e < count; e += kThreads) {
-      const uint32_t d = hd[e], u = hu[e];
-      if (d != kUnmarked) { atomicMin(&ld[e], d); atomicMin(&ld[e + half], d); }
-      if (u != kUnmarked) { atomicMin(&lu[e], u); atomicMin(&lu[e + half], u); }
+    S.tot[threadIdx.x] = run;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_c[q][threadIdx.x] = rc[q];
+    if (threadIdx.x == 0) { S.P[0] = 0.0; for (int q = 0; q < 4; ++q) S.C(q, 0) = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
+      double carry = 0.0;
+      int car[4] = {0, 0, 0, 0};
+      for (int k = 0; k < kThreads / 64; ++k) {
+        const int idx = k * 64 + threadIdx.x;
+        const double mine = S.tot[idx];
+        double incl = mine;
+        int m4[4], i4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { m4[q] = s_c[q][idx]; i4[q] = m4[q]; }
+        for (int d = 1; d < 64; d <<= 1) {
+          const double up = __shfl_up(incl, d);
+          int u4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) u4[q] = __shfl_up(i4[q], d);
+          if ((int)threadIdx.x >= d) {
+            incl += up;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) i4[q] += u4[q];
+          }
+        }
+        S.tot[idx] = carry + incl - mine;
+        carry += __shfl(incl, 63);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += __shfl(i4[q], 63); }
+      }
     }
     __syncthreads();
-  }
-  // ---- merge the tile's marks into HBM (halo bins are shared with the neighbouring tiles) ----
-  for (int e = vlo + threadIdx.x; e < vhi; e += kThreads) {
-    const uint32_t d = S.level(0, 0)[e], u = S.level(1, 0)[e];
-    if (d != kUnmarked) atomicMin(&first_del[lo + e], d);
-    if (u != kUnmarked) atomicMin(&first_dup[lo + e], u);
+    {
+      const double off = S.tot[threadIdx.x];
+      int o4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o4[q] = s_c[q][threadIdx.x];
+      int before[4] = {o4[0], o4[1], o4[2], o4[3]};   // global count before element e
+      for (int e = c0; e < c0 + chunk && e < count; ++e) {
+        S.P[e + 1] += off;
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int after = (int)S.C(q, e + 1) + o4[q];
+          S.C(q, e + 1) = (uint16_t)after;
+          if (after != before[q]) { S.R(q, before[q]) = (uint16_t)e; bits |= 1u << q; }   // e is the before[q]-th bin with predicate q
+          before[q] = after;
+        }
+        S.PF[e] = (uint16_t)bits;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
+    if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
+    __syncthreads();
+
+    // ---- every (bin, L) of the tile within this task's lengths.  Going from L-1 to L the window gains one bin -- on the left for
+    // even L, on the right for odd L -- so one prefix value per step is new.  ----
+    ScanTile tile;
+    tile.vlo = vlo; tile.vhi = vhi; tile.fl_del = fl_del; tile.ce_dup = ce_dup;
+    tile.lim_del = sp.lim_del; tile.lim_dup = sp.lim_dup; tile.ends = (at_start ? 1 : 0) | (at_end ? 2 : 0);
+    const bool edge_tile = at_start || at_end;   // only there can a lane's L range be cut short
+    static_assert(kScanTile == kThreads, "one bin per lane");
+    {
+      const int64_t i = tile_start + threadIdx.x;
+      const int rel = (int)(i - lo);   // staged index of bin i
+      // the reference visits i in [L/2+1, nb-L/2-2] (rsi.cpp:1204): L/2 <= min(i-1, nb-i-2)
+      const int64_t hmax = (i - 1) < (sp.nb - i - 2) ? (i - 1) : (sp.nb - i - 2);
+      int Lend = (i < sp.nb && hmax >= 0) ? (int)(hmax < Lmax ? 2 * hmax + 1 : Lmax) : 0;
+      if (Lend > Lmax) Lend = Lmax;
+      const int relc = Lend > 0 ? rel : halo;   // lanes without a bin read a harmless address
+      if (edge_tile) scan_sweep<true>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
+      else scan_sweep<false>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
+    }
+    __syncthreads();
+    // ---- push the block levels down to single bins ----
+    for (int k = kcap; k >= 1; --k) {
+      const int half = 1 << (k - 1);
+      uint32_t* hd = S.level(0, k); uint32_t* ld = S.level(0, k - 1);
+      uint32_t* hu = S.level(1, k); uint32_t* lu = S.level(1, k - 1);
+      for (int e = threadIdx.x; e < count; e += kThreads) {
+        const uint32_t d = hd[e], u = hu[e];
+        if (d != kUnmarked) { atomicMin(&ld[e], d); atomicMin(&ld[e + half], d); }
+        if (u != kUnmarked) { atomicMin(&lu[e], u); atomicMin(&lu[e + half], u); }
+      }
+      __syncthreads();
+    }
+    // ---- merge the tile's marks into HBM (halo bins are shared with the neighbouring tiles and with the tile's other parts) ----
+    for (int e = vlo + threadIdx.x; e < vhi; e += kThreads) {
+      const uint32_t d = S.level(0, 0)[e], u = S.level(1, 0)[e];
+      if (d != kUnmarked) atomicMin(&first_del[lo + e], d);
+      if (u != kUnmarked) atomicMin(&first_dup[lo + e], u);
+    }
   }
 }
 
@@ -1002,7 +1142,7 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
   RSI_LAUNCH(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
-                     const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, hipStream_t stream) {
+                     const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, uint32_t* tiles, hipStream_t stream) {
   ScanParams sp = sp_in;
   const int halo = sp.Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;
@@ -1012,15 +1152,29 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   while (kcap > 0 && scan_lds_bytes(count, kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --kcap;
   sp.kcap = kcap;
   const size_t lds = scan_lds_bytes(count, kcap);
-  const int grid = (int)((sp.nb + kScanTile - 1) / kScanTile);
-  if (inl) {
-    RSI_ALLOW_FULL_LDS(k_rsi_scan<true>);
-    RSI_LAUNCH(k_rsi_scan<true>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, *inl);
-  } else {
-    RSI_ALLOW_FULL_LDS(k_rsi_scan<false>);
-    static const ScanThr none{};
-    RSI_LAUNCH(k_rsi_scan<false>, dim3(grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, none);
+  const int64_t ntiles = (sp.nb + kScanTile - 1) / kScanTile;
+  static const ScanThr none{};
+  // RSI_HOT_SCAN_DETECT=0: no detection pass, every tile through the exact sweep in one piece (A/B runs; same marks)
+  const char* det_env = getenv("RSI_HOT_SCAN_DETECT");
+  const bool detect = tiles != nullptr && !(det_env && atoi(det_env) == 0);
+  int parts = 1;
+  if (detect) {
+    // Lengths of a listed tile over several workgroups: whole groups of kScanPad lengths, up to kScanPartsMax shares
+    const int groups = (sp.Lmax + kScanPad - 1) / kScanPad;
+    parts = groups < kScanPartsMax ? groups : kScanPartsMax;
+    if (const char* pe = getenv("RSI_HOT_SCAN_PARTS")) { const int v = atoi(pe); if (v >= 1 && v <= groups) parts = v; }
+    const size_t dlds = detect_lds_bytes(sp.Lmax);
+    const int dgrid = (int)((sp.nb + kDetBins - 1) / kDetBins);
+    if (inl) { RSI_ALLOW_FULL_LDS(k_scan_detect<true>); RSI_LAUNCH(k_scan_detect<true>, dim3(dgrid), dim3(kThreads), dlds, stream, T, sp.nb, sp.Lmax, nullptr, nullptr, tiles, counters, *inl); }
+    else { RSI_ALLOW_FULL_LDS(k_scan_detect<false>); RSI_LAUNCH(k_scan_detect<false>, dim3(dgrid), dim3(kThreads), dlds, stream, T, sp.nb, sp.Lmax, thr_del, thr_dup, tiles, counters, none); }
   }
+  // workgroups pull (tile, share) tasks from a counter: as many as can be resident, never more than there can be tasks
+  int64_t grid = ntiles * parts;
+  const int64_t resident = 256 * (int64_t)(lds > 80 * 1024 ? 1 : lds > 52 * 1024 ? 2 : lds > 39 * 1024 ? 3 : 4);
+  if (detect && grid > resident) grid = resident;
+  const uint32_t* list = detect ? tiles : nullptr;
+  if (inl) { RSI_ALLOW_FULL_LDS(k_rsi_scan<true>); RSI_LAUNCH(k_rsi_scan<true>, dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, list, parts, *inl); }
+  else { RSI_ALLOW_FULL_LDS(k_rsi_scan<false>); RSI_LAUNCH(k_rsi_scan<false>, dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, list, parts, none); }
 }
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream) {

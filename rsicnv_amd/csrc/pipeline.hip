@@ -23,6 +23,7 @@ struct ScanOut {
   std::vector<rsih::IntSpan::Range> run_ranges;
   std::vector<Candidate> segs;
   uint32_t escapes = 0, inexact = 0;
+  uint32_t tiles_listed = 0;        // tiles the two detection passes listed for the exact sweep
   // per-L counts of newly marked bins of the four sweeps (pass 1 DEL, DUP, pass 2 DEL, DUP) and the L each stopped at:
   // what the reference logs per L (rsi.cpp:1221-1224, 1251-1254)
   std::vector<uint32_t> level_log[4];
@@ -468,7 +469,7 @@ int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint,
   ScanParams sp;
   sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
   sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
-  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->stream); }
+  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->scan_tiles.as<uint32_t>(), ctx->stream); }
   { Timer t(ctx, "level_stop"); launch_level_stop(d_first_del, d_first_dup, nb, Lmax, work, ctx->runs.p, d_done + 2, wslot, work_bytes, ctx->stream); }
   { Timer t(ctx, "resolve_runs"); launch_resolve_runs(d_first_del, d_first_dup, work + 2, nb, d_status, d_copy, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, d_done + 3, rslot, kEagerBounds, ctx->stream); }
   *work_slot = wslot; *runs_slot = rslot;
@@ -560,7 +561,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
                       reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4, fs_slot, ctx->stream);
   }
   { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
-  out.escapes += wslot[0]; out.inexact = wslot[1];
+  out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[0].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[1].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
   out.stop_levels[0] = wslot[2]; out.stop_levels[1] = wslot[3];
@@ -658,7 +659,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(CTX_SYNC());
   std::vector<Region> runs;
   if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
-  out.escapes += wslot[0]; out.inexact = wslot[1];
+  out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[3].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
   out.stop_levels[2] = wslot[2]; out.stop_levels[3] = wslot[3];
@@ -1106,6 +1107,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
     HIPCHK(ctx->status2.ensure((size_t)nb * 4));
     HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
+    HIPCHK(ctx->scan_tiles.ensure((size_t)(nb / 256 + 2) * 4));   // the scan's list of tiles that can hit (launch_rsi_scan)
     HIPCHK(ctx->fs_ws.ensure(level_sums_workspace_bytes(nb, kFsListCap, kMaxL)));
     HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
 
@@ -1163,6 +1165,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       S.tmedian1 = so.tmedian1; S.tsigma1 = so.tsigma1; S.tlamda1 = so.tlamda1;
       S.tmedian2 = so.tmedian2; S.tsigma2 = so.tsigma2; S.tlamda2 = so.tlamda2;
       S.Lmax = so.Lmax; S.trim_escapes += (int)so.escapes; S.inexact_sums = (int)so.inexact;
+      S.scan_tiles = (int32_t)((nb + 255) / 256); S.scan_tiles_listed = (int32_t)so.tiles_listed;
       for (int w = 0; w < 4; ++w) { res->level_log[w] = so.level_log[w]; res->stop_levels[w] = so.stop_levels[w]; }
       res->fs_lines = so.fs_lines;
       res->log_nb = !use_med;

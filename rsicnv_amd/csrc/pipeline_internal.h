@@ -140,6 +140,7 @@ struct rsi_ctx {
   DevBuf cand_jobs, cand_chains, cand_outs, cand_i32, cand_i64, cand_mid, cand_hist;   // candidate tests on the device (kernels_cand.hip)
   DevBuf sharpen_ws;          // workspace of k_sharpen_edges, cleared when (re)allocated
   DevBuf fs_ws, fs_out;       // filterstatus' level sums on the device (kernels_fs.hip)
+  DevBuf scan_tiles;          // tiles the scan's detection pass lists for the exact sweep
   int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
