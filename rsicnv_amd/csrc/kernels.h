@@ -75,6 +75,31 @@ struct ValueHistAux { unsigned long long big; unsigned int vmax; unsigned int ne
 // inrange = sum of the counters, lo / hi = smallest / largest value present (lo > hi: none), med = the bucket where the
 // cumulated count first reaches total/2 (-1: never).
 struct ValueMedian { unsigned long long inrange; int32_t lo, hi, med, pad; };
+// ---- K2j: K2 with the joint histogram [window GC count][depth byte] (kernels_base.hip): its last workgroup builds the GC table,
+// the value histogram of the RESCALED depth (what K3' computed per base), walks it to the cap median (*vm) and hands the
+// header over (head_src -> head_dst, mapped host memory) -- the chromosome needs no K3'.  acc->negatives bit 2: a
+// workgroup's 16-bit counters wrapped, the launch's results are void (the caller runs K2 + K3' instead); acc->escapes > 0:
+// the histogram lacks the depths of 255 and more until launch_escape_hist has run.  totals: gc_joint_totals_bytes(), zero
+// before the launch; hist / aux zero before the launch; counters: kFoldGroups + 1 arrival counters.
+// esc_list: gc_joint_esc_list_bytes() of scratch (the workgroups' first escapes by position: the last workgroup adds them to the
+// histogram itself; info->esc_pending says when there were too many for that).  rtab: kGcLevels words, per level the 16.16
+// fixed-point ratio K4j rescales depth bytes with (verified against the reference's expression for every byte; bit 31: not
+// usable, take the exact expression).
+struct JointInfo { int32_t gmin, gmax;   // GC levels that occur
+                   int32_t vmax;         // largest depth byte below kByteEscape that occurs
+                   int32_t esc_pending;  // 1: the value histogram lacks the escapes (launch_escape_hist), or the coverage is deep (int32 kernels)
+};
+size_t gc_joint_slab_bytes(int64_t n);
+size_t gc_joint_totals_bytes();
+size_t gc_joint_esc_list_bytes();
+void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
+                          unsigned int* counters, uint8_t* depth8 /* n + 2048 bytes */, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
+                          const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
+                          hipStream_t stream);
+void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
+                        ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
+                        hipStream_t stream);
+
 size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup histograms
 // table: kGcLevels level means followed by the mean of the positive depths (K2's last workgroup builds it).
 // The last workgroup to finish folds the slabs into hist, fixes the tail quirks of the 20-slice write-back (SURVEY App. A
@@ -142,6 +167,14 @@ void launch_cap_compact_bin8(const uint8_t* rescaled8, const int32_t* depth, con
                              int m, uint8_t* rdc8 /* ncompact + 64 bytes: the capped, compacted depth as bytes */, int32_t* binmed, int64_t* binsum,
                              uint32_t* res_hist, void* slabs, void* gsum,
                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
+
+// K4j: K4' fed from the byte copy of the RAW depth (K2 / K2j's depth8), rescaling on the way with the GC table -- same outputs.
+void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                                 const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                                 int m, uint8_t* rdc8, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                                 unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes,
+                                 const unsigned int* rtab /* K2j's fixed-point ratios, or NULL: the float form with its exactness margin */,
+                                 hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =

@@ -20,10 +20,15 @@ constexpr int kGcLeft = 4;                 // margin words left of the tile (256
 constexpr int kGcRight = 2;                // margin words right of the tile (128 bits >= 101)
 constexpr int kGcLds = kGcLeft + kGcWords + kGcRight;   // 70
 
+constexpr int kK4GcWords = 128;             // staged GC words of a K4j tile: (6656 + 200) / 64 + 3 <= 111
 constexpr int kK3Width = 512, kK3PhaseShift = 4, kK3Phases = 1 << kK3PhaseShift;   // K3': its LDS value histogram is [512 values][16 lane phases]
 constexpr int kValLds = 256;               // K3 / K3': values below this are counted in LDS, [value][32 lane phases]
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
+__device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
+  const uint32_t x = ~w;                          // a zero byte of x
+  return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // K1  fasta_classify: one thread per 16 bytes; 4 neighbouring lanes assemble one 64-bit word.
@@ -259,6 +264,22 @@ __device__ inline uint32_t wgc_field16(const WaveGc& t, uint32_t rel) {
   const uint32_t k = rel >> 6, b = rel & 63;
   uint64_t v = t.word[k] >> b;
   if (b > 48) v |= t.word[k + 1] << (64 - b);
+  return (uint32_t)v & 0xffffu;
+}
+
+// the same two queries on a plain array of staged words (a workgroup's tile in K4j)
+__device__ inline uint32_t gcw_window(const uint64_t* __restrict__ word, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  const uint64_t w0 = word[k], w1 = word[k + 1], w2 = word[k + 2], w3 = word[k + 3], w4 = word[k + 4];
+  const uint32_t rem = 9 + b;
+  const uint64_t m3 = rem >= 64 ? ~0ull : ((1ull << rem) - 1);
+  const uint64_t m4 = rem > 64 ? ((1ull << (rem - 64)) - 1) : 0ull;
+  return (uint32_t)(__popcll(w0 >> b) + __popcll(w1) + __popcll(w2) + __popcll(w3 & m3) + __popcll(w4 & m4));
+}
+__device__ inline uint32_t gcw_field16(const uint64_t* __restrict__ word, uint32_t rel) {
+  const uint32_t k = rel >> 6, b = rel & 63;
+  uint64_t v = word[k] >> b;
+  if (b > 48) v |= word[k + 1] << (64 - b);
   return (uint32_t)v & 0xffffu;
 }
 
@@ -517,14 +538,14 @@ template <int NT>
 __device__ inline void value_median_block(const uint32_t* __restrict__ hist, unsigned long long total, ValueMedian* __restrict__ out, int range) {
   __shared__ unsigned long long s_w[NT / 64];
   __shared__ int s_lo[NT / 64], s_hi[NT / 64], s_med;
-  const int kPer = range / NT;
+  const int kPer = (range + NT - 1) / NT;   // hist has kHistValues counters: a stretch may run past `range` (zeros there), never past the array
   const int v0 = threadIdx.x * kPer;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long local = 0;
   int lo = 0x7fffffff, hi = -1;
 #pragma unroll 8
   for (int i = 0; i < kPer; ++i) {
-    const uint32_t c = ld_cg(hist + v0 + i);
+    const uint32_t c = v0 + i < kHistValues ? ld_cg(hist + v0 + i) : 0u;
     local += c;
     if (c) { lo = v0 + i < lo ? v0 + i : lo; hi = v0 + i; }
   }
@@ -542,7 +563,7 @@ __device__ inline void value_median_block(const uint32_t* __restrict__ hist, uns
   const unsigned long long r2 = total / 2;
   unsigned long long seen = base + incl - local;
   if (local != 0 && seen < r2 && seen + local >= r2) {   // the walk's bucket lies in this thread's stretch
-    for (int i = 0; i < kPer; ++i) {
+    for (int i = 0; i < kPer && v0 + i < kHistValues; ++i) {
       const unsigned long long upto = seen + ld_cg(hist + v0 + i);
       if (seen < r2 && upto >= r2) s_med = v0 + i;
       seen = upto;
@@ -625,6 +646,503 @@ __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __
     range = range < vb + width ? vb + width : range;
     range = (range + kThreads - 1) / kThreads * kThreads;
     value_median_block<kThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
+  }
+  sync_drained();
+  export_words(head_dst, head_src, head_bytes);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2j  gc_joint_hist: K2 with the JOINT histogram H[window GC count][depth byte] instead of a sum and a count per GC count.
+// Everything K3' computed per base follows from H without touching the bases again -- the rescaled value is a pure function
+// of (depth, GC count): (int)(d * rdmean / table[g] + 0.5), gccontent.cpp:89 -- so the last workgroup of THIS launch builds the
+// GC table (row sums of H), the histogram of the rescaled depth (202 x 255 evaluations of that expression instead of n) and
+// the cap median from it, and the chromosome is one per-base pass shorter: K1, K2j, K4j.
+//
+// LDS: 202 x 256 counters of 16 bits, two to a word (103 KB: one workgroup of kJWaves waves per CU, wave-autonomous trips as in
+// K2).  A 16-bit counter can wrap; nothing in the loop checks for it.  Instead every workgroup compares the sum of its fields
+// with the number of bases it counted: a wrapped low field loses 65536 and carries 1 into its neighbour, a wrapped high field
+// loses 65536, so the sum comes out short whenever anything wrapped -- the workgroup then raises a flag and the host sends the
+// chromosome through the three-pass chain (K2, K3', K4j).  It takes a cell with more than 6 % of a workgroup's million bases:
+// depth 0 has 32-bit counters of its own (s_zero: N runs and uncovered stretches put megabases into one cell), a sequence
+// without any GC variation next to a constant depth is what is left.  Depths of 255 and more ("escapes", the byte copy says
+// kByteEscape) are summed per GC count for the table (64-bit) and enter the value histogram through a pass of their own
+// (k_escape_hist), launched by the host only when the header reports any.
+constexpr int kJWaves = 12, kJThreads = 64 * kJWaves;
+constexpr int kJRowWords = 128;                                  // one GC level: values 2k (low half) and 2k + 1 (high half) in word k
+constexpr int kJPacked = kGcLevels * kJRowWords;                 // 25856 words
+constexpr int kJOffZero = kJPacked;                              // [202] bases of depth 0 per level
+constexpr int kJOffEscCnt = kJOffZero + kGcLevels;               // [202] escapes per level
+constexpr int kJOffFlags = kJOffEscCnt + kGcLevels;              // [8]: workgroups that saw a negative depth, escapes, workgroups whose counters wrapped
+constexpr int kJOffEscSum = kJOffFlags + 8;                      // [202] 64-bit sums of the escapes' depths (8-byte aligned)
+constexpr int kJSlabWords = kJOffEscSum + 2 * kGcLevels;         // 26672, a multiple of 4
+static_assert(kJSlabWords % 4 == 0 && (kJOffEscSum % 2) == 0 && kJPacked % 4 == 0, "slab layout");
+// the folded totals (global, zero before the launch): H as 32-bit counters, then the slab's tail as it is
+constexpr int kJTotH = kGcLevels * 256;
+constexpr int kJTotWords = kJTotH + (kJSlabWords - kJPacked);
+constexpr int kJRh = 8192;                                       // rescaled values the tail counts in LDS (beyond: global atomics)
+constexpr int kFixShift = 22;                                    // fraction bits of K4j's fixed-point ratios
+constexpr double kFixMaxRatio = 3.99;                            // R = ratio * 2^22 stays below 2^24
+constexpr int kJEscPerWg = 63;                                   // escapes a workgroup lists by position (entry 0 of its list: their number)
+
+// Eight 16-byte loads of other workgroups' results (sc1), all in flight at once: the thread's offsets are eight VGPRs, the base
+// is wave-uniform.  The tail of K2j walks 200 KB with them; one load and one wait at a time was 50 us of a 200 us kernel.
+__device__ inline void ld_cg_x4_batch8(u32x4 (&v)[8], unsigned long long base, const unsigned int (&off)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, %16 sc1\n\t"
+      "global_load_dwordx4 %1, %9, %16 sc1\n\t"
+      "global_load_dwordx4 %2, %10, %16 sc1\n\t"
+      "global_load_dwordx4 %3, %11, %16 sc1\n\t"
+      "global_load_dwordx4 %4, %12, %16 sc1\n\t"
+      "global_load_dwordx4 %5, %13, %16 sc1\n\t"
+      "global_load_dwordx4 %6, %14, %16 sc1\n\t"
+      "global_load_dwordx4 %7, %15, %16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "s"(base)
+      : "memory");
+}
+
+__device__ inline void st_cg_x4(void* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ inline u32x4 ld_cg_x4(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
+    const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords, unsigned int* __restrict__ slabs,
+    unsigned int* __restrict__ tot /* kJTotWords, zero before the launch */, int per_group, unsigned int* __restrict__ counters,
+    GcAccum* __restrict__ acc, double* __restrict__ table, uint8_t* __restrict__ d8, uint32_t* __restrict__ ghist,
+    ValueHistAux* __restrict__ aux, ValueMedian* __restrict__ vm, const void* head_src, void* head_dst, unsigned int head_bytes, int dbg,
+    unsigned int* __restrict__ esc_list /* gridDim.x lists of 1 + kJEscPerWg words */, unsigned int* __restrict__ rtab /* [202] */,
+    JointInfo* __restrict__ info, unsigned int escape_limit) {
+  __shared__ __align__(16) unsigned int s_j[kJSlabWords];
+  __shared__ unsigned int s_nesc;
+  __shared__ WaveGc s_gc[kJWaves];
+  __shared__ unsigned int s_flag, s_hi;
+  for (int e = threadIdx.x; e < kJSlabWords; e += kJThreads) s_j[e] = 0;
+  if (threadIdx.x == 0) s_nesc = 0u;
+  __syncthreads();
+  unsigned int* const my_list = esc_list + (size_t)blockIdx.x * (1 + kJEscPerWg);
+  unsigned int* s_zero = s_j + kJOffZero;
+  unsigned int* s_esc_cnt = s_j + kJOffEscCnt;
+  unsigned long long* s_esc_sum = reinterpret_cast<unsigned long long*>(s_j + kJOffEscSum);
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  WaveGc& G = s_gc[wave];
+  unsigned int nfast = 0, escapes = 0, negs = 0;   // per lane: values counted in the 16-bit fields; depths of 255 and more; negative depths
+  // word of the pair counter of (level g, value v): the pair index is XOR-ed with the level's low bits, so that lanes whose
+  // levels differ spread over the LDS banks (a row is 128 words: without it the bank would be a function of the value alone)
+  const unsigned swz = (dbg & 4) ? 0u : 31u;
+  auto cell = [&](uint32_t g, int v) -> unsigned int* { return &s_j[g * kJRowWords + (((unsigned)v >> 1) ^ (g & swz))]; };
+  const bool no_atomics = (dbg & 2) != 0;
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  const int64_t stride = (int64_t)gridDim.x * kJWaves;
+  auto sat8 = [](int v) -> uint32_t { return v < 0 ? 0u : (v >= kByteEscape ? (uint32_t)kByteEscape : (uint32_t)v); };
+  // one value that is not in 1 .. 254: depth 0 (32-bit counter per level), an escape, or a negative depth (refused by the host)
+  auto odd_value = [&](int val, uint32_t g, int64_t pos) {
+    if (val == 0) atomicAdd(&s_zero[g], 1u);
+    else if (val > 0) {
+      atomicAdd(&s_esc_cnt[g], 1u); atomicAdd(&s_esc_sum[g], (unsigned long long)val); ++escapes;
+      const unsigned int k = atomicAdd(&s_nesc, 1u);             // the workgroup's first few escapes by position, for the last workgroup
+      if (k < (unsigned int)kJEscPerWg) st_cg(&my_list[1 + k], (unsigned int)pos);
+    }
+    else negs = 1u;
+  };
+
+  auto trip = [&](const SubRegs& cur, SubRegs& nxt, int64_t sub) {
+    const int64_t base = sub * kSubBases;
+    const int64_t first_bit = base - kGcLeft * 64;
+    {
+      const int64_t w = base / 64 - kGcLeft + lane;
+      const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
+      if (lane < kSubLds + 1) G.word[lane] = word;
+    }
+    if (sub + stride < nsub) sub_request(nxt, depth, gcbits, nwords, (sub + stride) * kSubBases, n, lane);
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = base + 16 * (int64_t)lane;
+    const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102;   // no edge clamping in this sub-tile
+    if (interior) {
+      const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
+      uint32_t cnt = wgc_window(G, rel);
+      const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
+      const int v[16] = {cur.q[0].x, cur.q[0].y, cur.q[0].z, cur.q[0].w, cur.q[1].x, cur.q[1].y, cur.q[1].z, cur.q[1].w,
+                         cur.q[2].x, cur.q[2].y, cur.q[2].z, cur.q[2].w, cur.q[3].x, cur.q[3].y, cur.q[3].z, cur.q[3].w};
+      unsigned bad = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bad |= (unsigned)((unsigned)(v[j] - 1) >= 254u);
+      if (!bad) {   // the common case, straight-line: sixteen LDS atomics into [GC level][value pair]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (!no_atomics) atomicAdd(cell(cnt, v[j]), 1u << ((v[j] & 1) << 4));
+          cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+        }
+        nfast += 16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if ((unsigned)(v[j] - 1) < 254u) { atomicAdd(cell(cnt, v[j]), 1u << ((v[j] & 1) << 4)); ++nfast; }
+          else odd_value(v[j], cnt, i0 + j);
+          cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+        }
+      }
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = sat8(v[4 * k]) | (sat8(v[4 * k + 1]) << 8) | (sat8(v[4 * k + 2]) << 16) | (sat8(v[4 * k + 3]) << 24);
+      *reinterpret_cast<uint4*>(d8 + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only
+      for (int j = 0; j < 16; ++j) {
+        const int64_t i = i0 + j;
+        if ((i & ~(int64_t)3) + 4 > n) break;
+        int64_t lo = i - 100;
+        if (lo < 0) lo = 0;
+        if (lo > n - 202) lo = n - 202;
+        const uint32_t g = wgc_window(G, (uint32_t)(lo - first_bit));
+        const int val = depth[i];
+        if ((unsigned)(val - 1) < 254u) { atomicAdd(cell(g, val), 1u << ((val & 1) << 4)); ++nfast; }
+        else odd_value(val, g, i);
+        d8[i] = (uint8_t)sat8(val);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
+  };
+
+  SubRegs ra, rb;
+  int64_t sub = (int64_t)blockIdx.x * kJWaves + wave;
+  if (sub < nsub) sub_request(ra, depth, gcbits, nwords, sub * kSubBases, n, lane);
+  while (sub < nsub) {
+    trip(ra, rb, sub);
+    sub += stride;
+    if (sub >= nsub) break;
+    trip(rb, ra, sub);
+    sub += stride;
+  }
+  __syncthreads();
+  // ---- did a 16-bit field wrap?  The fields must add up to what the lanes counted into them ----
+  {
+    unsigned int have = 0;
+    for (int e = threadIdx.x; e < kJPacked; e += kJThreads) { const unsigned int w = s_j[e]; have += (w & 0xffffu) + (w >> 16); }
+    unsigned int diff = nfast - have;   // modulo 2^32: zero over the workgroup iff nothing wrapped (a workgroup sees < 2^31 bases)
+    for (int d = 32; d >= 1; d >>= 1) { diff += __shfl_xor(diff, d); escapes += __shfl_xor(escapes, d); negs |= __shfl_xor(negs, d); }
+    if (threadIdx.x == 0) s_flag = 0u;
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&s_flag, diff); if (escapes) atomicAdd(&s_j[kJOffFlags + 1], escapes); if (negs) atomicOr(&s_j[kJOffFlags + 0], 1u); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (s_flag != 0u) s_j[kJOffFlags + 2] = 1u;
+      st_cg(&my_list[0], s_nesc);                                   // how many escapes the workgroup saw (listed: the first kJEscPerWg)
+      if (s_nesc > (unsigned int)kJEscPerWg) s_j[kJOffFlags + 3] = 1u;   // workgroups whose list ran over
+    }
+    __syncthreads();
+  }
+  if (dbg & 1) { if (blockIdx.x == 0) export_words(head_dst, head_src, head_bytes); return; }   // DEBUG ablation: no slab, no fold, no tail
+  // ---- slab out (16-byte write-through stores), then the two-level hand-over of device_util.h with a fold of its own: the
+  // last workgroup of a group unpacks the group's slabs into 32-bit sums and adds them to the totals ----
+  {
+    unsigned int* slab = slabs + (size_t)blockIdx.x * kJSlabWords;
+    for (int q = threadIdx.x; q < kJSlabWords / 4; q += kJThreads) {
+      u32x4 v; v.x = s_j[4 * q]; v.y = s_j[4 * q + 1]; v.z = s_j[4 * q + 2]; v.w = s_j[4 * q + 3];
+      st_cg_x4(slab + 4 * q, v);
+    }
+  }
+  const int nblocks = (int)gridDim.x;
+  const int grp = (int)blockIdx.x / per_group;
+  const int ngroups = (nblocks + per_group - 1) / per_group;
+  const int members = (grp + 1) * per_group <= nblocks ? per_group : nblocks - grp * per_group;
+  drain();
+  __syncthreads();   // the slab's stores have completed
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(&counters[1 + grp], 1u);
+    const bool last = t == (unsigned int)members - 1u;
+    if (last) atomicExch(&counters[1 + grp], 0u);
+    s_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  {
+    const unsigned int* src = slabs + (size_t)grp * per_group * kJSlabWords;
+    const int last = __builtin_amdgcn_readfirstlane(members - 1);
+    for (int q = threadIdx.x; q < kJSlabWords / 4; q += kJThreads) {
+      unsigned int lo4[4] = {0, 0, 0, 0}, hi4[4] = {0, 0, 0, 0};
+      const bool packed = 4 * q < kJPacked;
+      for (int k0 = 0; k0 <= last; k0 += 8) {
+        unsigned long long b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = uniform_address(src + (size_t)(k0 + j < last ? k0 + j : last) * kJSlabWords);
+        u32x4 v[8];
+        ld_cg_x8(v, (unsigned int)q * 16u, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j <= last) {
+          const unsigned int w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (packed) { lo4[c] += w[c] & 0xffffu; hi4[c] += w[c] >> 16; }
+            else { const unsigned int o = lo4[c]; lo4[c] += w[c]; hi4[c] += lo4[c] < o; }   // plain words; hi4 = carries (the 64-bit sums' low halves)
+          }
+        }
+      }
+      if (packed) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ws = 4 * q + c;                                            // word g * 128 + (pair ^ (g & 31)) of the slab
+          const int wi = (ws & ~127) | ((ws & 127) ^ (int)((ws >> 7) & swz));     // <-> counters 2 * wi, 2 * wi + 1 of the 32-bit table
+          if (lo4[c]) atomicAdd(&tot[2 * wi], lo4[c]);
+          if (hi4[c]) atomicAdd(&tot[2 * wi + 1], hi4[c]);
+        }
+      } else if (4 * q < kJOffEscSum) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (lo4[c]) atomicAdd(&tot[kJTotH + (4 * q + c - kJPacked)], lo4[c]);
+      } else {   // the escapes' 64-bit sums: two per vector; each slab's value is below 2^63, eight of them are added as (low, high) halves
+        unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tot + kJTotH + (4 * q - kJPacked));
+        // recombine per slab pair is not needed: sum of lows with carries + sum of highs
+        const unsigned long long a = (unsigned long long)lo4[0] + ((unsigned long long)hi4[0] << 32) + ((unsigned long long)lo4[1] << 32);
+        const unsigned long long c2 = (unsigned long long)lo4[2] + ((unsigned long long)hi4[2] << 32) + ((unsigned long long)lo4[3] << 32);
+        if (a) atomicAdd(&t64[0], a);
+        if (c2) atomicAdd(&t64[1], c2);
+      }
+    }
+  }
+  drain();
+  __syncthreads();   // this group's atomics have completed
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(&counters[0], 1u);
+    const bool last = t == (unsigned int)ngroups - 1u;
+    if (last) atomicExch(&counters[0], 0u);
+    s_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+
+  if (dbg & 8) { export_words(head_dst, head_src, head_bytes); return; }   // DEBUG ablation: no tail
+  // ================= the launch's last workgroup: GC table, rescaled-value histogram, cap median, header =================
+  // scratch in the (now free) slab image
+  unsigned long long* r_sum = reinterpret_cast<unsigned long long*>(s_j);            // [202]
+  unsigned long long* r_cnt = r_sum + kGcLevels;                                     // [202]
+  double* r_tab = reinterpret_cast<double*>(r_cnt + kGcLevels);                      // [203]
+  unsigned long long* r_misc = reinterpret_cast<unsigned long long*>(r_tab + kGcLevels + 2);   // [4]: possum, poscnt
+  unsigned int* r_hist = reinterpret_cast<unsigned int*>(r_misc + 4);                // [kJRh]
+  for (int e = threadIdx.x; e < kJRh; e += kJThreads) r_hist[e] = 0;
+  for (int e = threadIdx.x; e < 2 * kGcLevels; e += kJThreads) r_sum[e] = 0;   // r_sum and r_cnt
+  if (threadIdx.x == 0) { s_hi = 0u; r_misc[0] = 0; r_misc[1] = 0; }
+  __syncthreads();
+  const unsigned int* t_zero = tot + kJTotH + (kJOffZero - kJPacked);
+  const unsigned int* t_ecnt = tot + kJTotH + (kJOffEscCnt - kJPacked);
+  const unsigned int* t_flags = tot + kJTotH + (kJOffFlags - kJPacked);
+  const unsigned long long* t_esum = reinterpret_cast<const unsigned long long*>(tot + kJTotH + (kJOffEscSum - kJPacked));
+  // ---- row sums of H (count, sum of depths per level) and the largest depth byte present: every thread takes quads of four
+  // cells, eight loads in flight ----
+  __shared__ unsigned int s_vmax, s_gmin, s_gmax;
+  if (threadIdx.x == 0) { s_vmax = 0u; s_gmin = 0xffffffffu; s_gmax = 0u; }
+  __syncthreads();
+  const unsigned long long tot_base = uniform_address(tot);
+  constexpr int kQuads = kJTotH / 4;                                   // 12928
+  constexpr int kBatches = (kQuads + 8 * kJThreads - 1) / (8 * kJThreads);   // 3
+  auto for_quads = [&](auto&& body) {
+    for (int b = 0; b < kBatches; ++b) {
+      unsigned int off[8];
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int q = (b * 8 + j) * kJThreads + (int)threadIdx.x; off[j] = (unsigned int)(q < kQuads ? q : 0) * 16u; }
+      ld_cg_x4_batch8(v, tot_base, off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = (b * 8 + j) * kJThreads + (int)threadIdx.x;
+        if (q < kQuads) body(q, v[j]);
+      }
+    }
+  };
+  for_quads([&](int q, u32x4 c4) {
+    const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+    const unsigned int any = c[0] | c[1] | c[2] | c[3];
+    if (!any) return;
+    const int g = (4 * q) >> 8, v0 = (4 * q) & 255;
+    unsigned long long cs = 0, vs = 0;
+    int top = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cs += c[k]; vs += (unsigned long long)c[k] * (unsigned long long)(v0 + k); top = c[k] ? v0 + k : top; }
+    atomicAdd(&r_cnt[g], cs); atomicAdd(&r_sum[g], vs);
+    atomicMax(&s_vmax, (unsigned int)top);
+  });
+  __syncthreads();
+  for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
+    const unsigned long long z = ld_cg(t_zero + g), ec = ld_cg(t_ecnt + g), es = ld_cg(t_esum + g);
+    const unsigned long long vs = r_sum[g], cs = r_cnt[g];
+    r_sum[g] = vs + es;
+    r_cnt[g] = cs + z + ec;
+    atomicAdd(&r_misc[0], vs + es);          // depth > 0: every counted value but the zeros
+    atomicAdd(&r_misc[1], cs + ec);
+    if (cs + z + ec) { atomicMin(&s_gmin, (unsigned int)g); atomicMax(&s_gmax, (unsigned int)g); }
+  }
+  __syncthreads();
+  // ---- the ragged last n % 4 bases: the stale-window zone i >= n-101, count of [n-202, n-2] (App. A Q1); table only (the value
+  // histogram gets them from gc_tail_fixup, as raw depths) ----
+  __shared__ unsigned int s_esc_total, s_list_over;
+  if (threadIdx.x == 0) {
+    unsigned int fl_neg = ld_cg(t_flags + 0);
+    unsigned long long esc = ld_cg(t_flags + 1);
+    if ((n & 3) != 0) {
+      const int g = gc_window_count(gcbits, n - 202);
+      for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
+        const int v = depth[i];
+        r_sum[g] += (unsigned long long)(long long)v;
+        r_cnt[g] += 1ull;
+        if (v > 0) { r_misc[0] += (unsigned long long)v; r_misc[1] += 1ull; }
+        if (v < 0) fl_neg |= 1u;
+        d8[i] = (uint8_t)sat8(v);
+        esc += v >= kByteEscape;
+      }
+    }
+    acc->possum = r_misc[0]; acc->poscnt = r_misc[1];
+    acc->negatives = (fl_neg ? 1u : 0u) | (ld_cg(t_flags + 2) ? 4u : 0u);   // bit 2: a workgroup's 16-bit counters wrapped, nothing below is valid
+    acc->escapes = esc > 0xffffffffull ? 0xffffffffu : (unsigned int)esc;
+    s_esc_total = acc->escapes;
+    s_list_over = ld_cg(t_flags + 3);
+  }
+  __syncthreads();
+  const unsigned long long ps = r_misc[0], pc = r_misc[1];
+  double rdmean = (double)ps;
+  if (pc > 0) rdmean /= (double)pc;
+  for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
+    const unsigned long long sg = r_sum[g], cg = r_cnt[g];
+    acc->sum[g] = sg; acc->cnt[g] = cg;
+    double t = cg > 0 ? (double)sg / (double)cg : rdmean;
+    if (t < 1) t = rdmean;
+    table[g] = t;
+    r_tab[g] = t;
+  }
+  if (threadIdx.x == 0) { table[kGcLevels] = rdmean; r_tab[kGcLevels] = rdmean; }
+  __syncthreads();
+  // what K4j needs to know about the table it rescales with: the levels and depth bytes that occur, whether the histogram is complete
+  const bool deep = s_esc_total > escape_limit;                    // the host takes the int32 kernels: nothing more to do here
+  const bool esc_pending = s_esc_total != 0u && (s_list_over != 0u || deep);
+  if (threadIdx.x == 0) {
+    info->gmin = s_gmin > s_gmax ? 0 : (int)s_gmin; info->gmax = s_gmin > s_gmax ? 0 : (int)s_gmax;
+    info->vmax = (int)s_vmax; info->esc_pending = esc_pending ? 1 : 0;
+  }
+  if (deep || (dbg & 16)) { sync_drained(); export_words(head_dst, head_src, head_bytes); return; }   // (dbg 16: ablation, table only)
+  // ---- K4j's rescale without floating point: per level a fixed-point ratio R (22 fraction bits: 2^-23 * 254 is the distance from
+  // a rounding boundary at which it can go wrong) with (v * R + 2^21) >> 22 == the reference's (int)(v * rdmean / table[g] + 0.5)
+  // for EVERY depth byte v = 0 .. 254 (compared saturated at kByteSat: K4j caps below that) -- checked here, cell by cell,
+  // against the reference's expression; a level where some byte disagrees, or whose ratio is 4 and more (R must stay below
+  // 2^24: the product is a 24 x 8 bit multiply in 32 bits), carries bit 31 and sends its bases through the exact expression.
+  unsigned int* r_bad = reinterpret_cast<unsigned int*>(r_hist + kJRh);   // [202]
+  for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) r_bad[g] = 0u;
+  __syncthreads();
+  for (int q = threadIdx.x; q < kGcLevels * 64; q += kJThreads) {
+    const int g = q >> 6, v0 = (q & 63) * 4;
+    if (r_cnt[g] == 0) continue;
+    const double ratio = rdmean / r_tab[g];
+    bool bad = !(ratio < kFixMaxRatio);
+    const unsigned int R = bad ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (v0 + k >= kByteEscape) continue;
+      int r = (int)((double)(v0 + k) * rdmean / r_tab[g] + 0.5);   // gccontent.cpp:89, truncation
+      r = r > kByteSat ? kByteSat : r;
+      unsigned int f = ((unsigned int)(v0 + k) * R + (1u << (kFixShift - 1))) >> kFixShift;
+      f = f > (unsigned int)kByteSat ? (unsigned int)kByteSat : f;
+      bad = bad || f != (unsigned int)r;
+    }
+    if (bad) atomicOr(&r_bad[g], 1u);
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
+    const double ratio = rdmean / r_tab[g];
+    const bool wide = !(ratio < kFixMaxRatio);
+    rtab[g] = (wide ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5)) | ((r_bad[g] || wide || r_cnt[g] == 0) ? 0x80000000u : 0u);
+  }
+  // ---- histogram of the rescaled depth from H: every (level, value) cell once ----
+  {
+    unsigned int lane_hi = 0;
+    auto count_value = [&](int r, unsigned int c) {
+      if (r >= 0 && r < kJRh) atomicAdd(&r_hist[r], c);
+      else if (r >= 0 && r < kHistValues) { atomicAdd(&ghist[r], c); lane_hi = (unsigned)r > lane_hi ? (unsigned)r : lane_hi; }
+      else if (r < 0) atomicOr(&aux->negatives, 1u);
+      else { atomicAdd(&aux->big, (unsigned long long)c); lane_hi = 0xffffffffu; }
+    };
+    for_quads([&](int q, u32x4 c4) {
+      const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+      if (!(c[0] | c[1] | c[2] | c[3])) return;
+      const int g = (4 * q) >> 8, v0 = (4 * q) & 255;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c[k]) count_value((int)((double)(v0 + k) * rdmean / r_tab[g] + 0.5), c[k]);   // gccontent.cpp:89, truncation
+    });
+    for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) { const unsigned int z = ld_cg(t_zero + g); if (z) atomicAdd(&r_hist[0], z); }   // (int)(0 * ratio + 0.5) = 0
+    // the escapes the workgroups listed by position: the reference's expression on the int32 depth, window by the clamped rule
+    if (s_esc_total != 0u && !esc_pending) {
+      const int nlists = (int)gridDim.x;
+      for (int sidx = threadIdx.x; sidx < nlists * kJEscPerWg; sidx += kJThreads) {
+        const int w = sidx / kJEscPerWg, k = sidx - w * kJEscPerWg;
+        const unsigned int* L = esc_list + (size_t)w * (1 + kJEscPerWg);
+        if ((unsigned int)k >= ld_cg(L)) continue;
+        const int64_t i = (int64_t)ld_cg(L + 1 + k);
+        int64_t lo = i - 100;
+        if (lo < 0) lo = 0;
+        if (lo > n - 202) lo = n - 202;
+        count_value((int)((double)depth[i] * rdmean / r_tab[gc_window_count(gcbits, lo)] + 0.5), 1u);
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)lane_hi, d); lane_hi = o > lane_hi ? o : lane_hi; }
+    if (lane == 0 && lane_hi) atomicMax(&s_hi, lane_hi);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kJRh; e += kJThreads) { const unsigned int c = r_hist[e]; if (c) { atomicAdd(&ghist[e], c); atomicMax(&s_hi, (unsigned int)e); } }
+  sync_drained();
+  if (threadIdx.x == 0 && s_hi >= (unsigned int)kValLds) atomicMax(&aux->vmax, s_hi >= (unsigned int)kHistValues ? (unsigned int)kHistValues : s_hi);
+  // histogram side of the tail quirks of the 20-slice write-back (App. A Q2/Q3) and the ragged bases, as K3' does it
+  if (threadIdx.x < 64) gc_tail_fixup(depth, gcbits, n, table, 1, nullptr, ghist, aux);
+  sync_drained();
+  {
+    const unsigned int hi = ld_cg(&aux->vmax);
+    int range = hi >= (unsigned int)kHistValues ? kHistValues : (int)hi + 1;
+    const int top = (int)(s_hi >= (unsigned int)kHistValues ? (unsigned int)kHistValues - 1u : s_hi) + 1;
+    range = range < top ? top : range;
+    range = range < kValLds ? kValLds : range;
+    value_median_block<kJThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
+  }
+  sync_drained();
+  export_words(head_dst, head_src, head_bytes);
+}
+
+// The escapes' share of the value histogram (depths of 255 and more: the byte copy says kByteEscape): K2j's table is known,
+// so each of them is rescaled with the reference's expression and counted.  Launched only when K2j's header reports escapes
+// (and fewer than the byte path's limit); its last workgroup walks the histogram to the cap median and hands the header over
+// once more.
+__global__ __launch_bounds__(kThreads) void k_escape_hist(const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth,
+                                                          const uint64_t* __restrict__ gcbits, int64_t n, const double* __restrict__ table,
+                                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
+                                                          unsigned int* __restrict__ counter, ValueMedian* __restrict__ vm,
+                                                          const void* head_src, void* head_dst, unsigned int head_bytes) {
+  const double rdmean = table[kGcLevels];
+  const int64_t whole = n & ~(int64_t)3;   // the ragged bases belong to the tail fixup (raw depths), as everywhere
+  int lane_hi = 0;
+  for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c * 16 < whole; c += (int64_t)gridDim.x * kThreads) {
+    const uint4 b = *reinterpret_cast<const uint4*>(d8 + 16 * c);   // the copy is padded past n
+    if (!(has_escape(b.x) || has_escape(b.y) || has_escape(b.z) || has_escape(b.w))) continue;
+    const uint32_t w4[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 16; ++j) {
+      const int64_t i = 16 * c + j;
+      if (i >= whole || ((w4[j >> 2] >> (8 * (j & 3))) & 0xffu) != (uint32_t)kByteEscape) continue;
+      int64_t lo = i - 100;
+      if (lo < 0) lo = 0;
+      if (lo > n - 202) lo = n - 202;
+      const int g = gc_window_count(gcbits, lo);
+      const int r = (int)((double)depth[i] * rdmean / table[g] + 0.5);   // gccontent.cpp:89, truncation
+      if (r >= 0 && r < kHistValues) atomicAdd(&ghist[r], 1u);
+      else if (r < 0) atomicOr(&aux->negatives, 1u);
+      else atomicAdd(&aux->big, 1ull);
+      lane_hi = r > lane_hi ? r : lane_hi;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(lane_hi, d); lane_hi = o > lane_hi ? o : lane_hi; }
+  if (lane_id() == 0 && lane_hi >= kValLds) atomicMax(&aux->vmax, (unsigned int)(lane_hi >= kHistValues ? kHistValues : lane_hi));
+  if (!last_block_done(counter)) return;
+  {
+    const unsigned int hi = ld_cg(&aux->vmax);
+    int range = hi >= (unsigned int)kHistValues ? kHistValues : (int)hi + 1;
+    range = range < kValLds ? kValLds : range;
+    value_median_block<kThreads>(ghist, (unsigned long long)n, vm, range);
   }
   sync_drained();
   export_words(head_dst, head_src, head_bytes);
@@ -743,10 +1261,6 @@ __device__ inline void sub8_request(Sub8Regs& r, const uint8_t* __restrict__ d8,
   r.b = *reinterpret_cast<const uint4*>(d8 + base + 16 * (int64_t)lane);   // the copy is padded to whole sub-tiles
   const int64_t w = base / 64 - kGcLeft + lane;
   r.gw = gcbits[(lane < kSubLds && w >= 0 && w < nwords) ? w : 0];
-}
-__device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
-  const uint32_t x = ~w;                          // a zero byte of x
-  return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
 }
 
 __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth,
@@ -1347,6 +1861,277 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   export_words(exp_dst, exp_src, exp_bytes);
 }
 
+// FIX: the rescale is (byte * R[level] + 2^15) >> 16 with K2j's per-level 16.16 ratios, each verified there against the
+// reference's expression for every depth byte; a level that failed the check carries bit 31 and its lane takes the exact
+// expression.  Without (a chromosome that went through K2 + K3'): the float form with its exactness margin (rescale_f32).
+template <int MAXC, int EPT, bool SW7, bool FIX>
+__global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
+    const uint8_t* __restrict__ d8 /* K2j's byte copy of the raw depth (kByteEscape = look at the int32 array) */, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
+    int64_t n, int64_t nwords, const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak,
+    const int64_t* __restrict__ cum, int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, uint8_t* __restrict__ rdc8 /* capped + compacted depth, one byte per base */,
+    int32_t* __restrict__ binmed,
+    int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
+    int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl,
+    const unsigned int* __restrict__ rtab /* FIX: [kGcLevels] ratios from K2j */) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
+  __shared__ unsigned int s_rt[kGcLevels];   // FIX: the levels' fixed-point ratios
+  __shared__ double s_table[kGcLevels];   // the reference's own expression: per-element path, escapes, values too close to a rounding boundary
+  __shared__ float s_ratio[kGcLevels];    // rdmean / table[g] as float (rescale_f32)
+  __shared__ uint64_t s_gw[kK4GcWords];   // GC mask words under the tile's source range (+ margins), staged per tile
+  __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(table[kGcLevels] / t); }
+  if (FIX) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_rt[e] = rtab[e];
+  if (nreg <= kRegInline) {
+    for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
+    for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
+  } else {
+    for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
+    for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  }
+  const double rdmean = table[kGcLevels];
+  __syncthreads();
+  const RegionTable R{cbreak, cum, nreg, s_break, s_cum};
+
+  const int64_t lim31 = (ncompact / 31) * 31;
+  const int64_t nb = ncompact / m;
+  const int tile_elems = TB * m;            // a multiple of 16 (TB = 64)
+  const int nchunks = tile_elems / 16;
+  const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
+  const int parts = kThreads / TB;          // threads cooperating on one bin
+  const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
+  // the 20-slice write-back's tail (App. A Q2/Q3): cells n-201 .. n-201+r-1 carry the rescaled depth of the last r bases,
+  // computed with the fresh edge window [n-201, n-1]; the last r bases keep their raw depth
+  const int64_t S20 = n / 20, r20 = n - 20 * S20;
+  const int64_t zone = n - 201;             // no fast-path tile may reach this base (also covers the clamped windows, i >= n-101)
+
+  auto rescale = [&](int d, uint32_t g) { return (int)((double)d * rdmean / s_table[g] + 0.5); };   // gccontent.cpp:89, truncation
+  auto slow_value = [&](int64_t i) -> int {   // the value K3 + its tail fixup would have left at source index i
+    if (r20 >= 2 && i >= n - 201 && i < n - 201 + r20) return rescale(depth[20 * S20 + (i - (n - 201))], (uint32_t)gc_count201(gcbits, n - 201));
+    if (i >= 20 * S20) return depth[i];
+    int64_t lo = i - 100;
+    if (lo < 0) lo = 0;
+    if (lo > n - 202) lo = n - 202;
+    return rescale(depth[i], (uint32_t)gc_count201(gcbits, lo));
+  };
+
+  int k = 0;
+  auto geometry = [&](int64_t tile, int64_t& P0, int64_t& P1, bool& fast, int64_t& soff) {
+    P0 = tile * tile_elems;
+    P1 = (P0 + tile_elems < ncompact) ? P0 + tile_elems : ncompact;
+    while (k < nreg && R.brk(k) <= P0) ++k;   // tiles are visited in increasing order
+    const bool plain = (k >= nreg) || (R.brk(k) >= P1);
+    soff = P0 + R.shift(k);
+    // fast: a whole tile, contiguous in the source, every base with an unclamped window, before the tail zone and before
+    // the last partial stride of the 31 MAD residue classes
+    fast = plain && P1 - P0 == tile_elems && P1 <= lim31 && soff >= 101 && soff + tile_elems <= zone;
+  };
+  // Chunks are aligned in the COMPACTED array (16 values = 64 aligned bytes of rdc, 16 aligned bytes of the LDS tile); in the
+  // source they start at any byte, which a 16-byte load of the byte copy does not mind.
+  uint4 regs[MAXC];
+  uint64_t gwreg = 0;          // thread t < kK4GcWords: word t of the tile's staged GC words, committed to s_gw when the tile's turn comes
+  int64_t gw0 = 0, gw0_next = 0;   // index of the first staged word of the tile being consumed / requested
+  auto request = [&](int64_t soff) {   // branch-free: chunks beyond the tile re-read chunk 0 (ignored later)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int kc = c * kThreads + (int)threadIdx.x;
+      const Bytes16 b = *reinterpret_cast<const Bytes16*>(d8 + soff + 16 * (kc < nchunks ? kc : 0));
+      regs[c] = make_uint4(b.x, b.y, b.z, b.w);
+    }
+    gw0_next = (soff - 100) >> 6;   // soff >= 101 on this path
+    const int64_t w = gw0_next + (int64_t)threadIdx.x;
+    gwreg = gcbits[(threadIdx.x < kK4GcWords && w < nwords) ? w : 0];
+  };
+
+  int64_t P0, P1, soff; bool fast;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) { geometry(tile, P0, P1, fast, soff); if (fast) request(soff); }
+  for (; tile < ntiles; tile += gridDim.x) {
+    // the staged GC words of this tile (requested with its data): nobody reads s_gw between the barrier in the middle of the
+    // previous trip and the one below
+    if (fast && threadIdx.x < kK4GcWords) { const int64_t w = gw0_next + (int64_t)threadIdx.x; s_gw[threadIdx.x] = w < nwords ? gwreg : 0; }
+    gw0 = gw0_next;
+    __syncthreads();   // s_val is free (and s_hist zeroed on the first trip); s_gw is complete
+    if (fast) {
+      const uint32_t p0mod = (uint32_t)(P0 % 31);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int kc = c * kThreads + (int)threadIdx.x;
+        if (kc >= nchunks) continue;
+        const uint32_t w4[4] = {regs[c].x, regs[c].y, regs[c].z, regs[c].w};
+        // ---- the rescale K3' did: window GC count of the chunk's first base, one leaving / entering bit pair per base ----
+        const int64_t p = soff + 16 * (int64_t)kc;                      // source index of the chunk's first base
+        const uint32_t rel = (uint32_t)(p - 100 - (gw0 << 6));
+        uint32_t cnt = gcw_window(s_gw, rel);
+        const uint32_t leave = gcw_field16(s_gw, rel), enter = gcw_field16(s_gw, rel + 201);
+        const bool esc = has_escape(w4[0]) || has_escape(w4[1]) || has_escape(w4[2]) || has_escape(w4[3]);
+        const uint32_t cnt0 = cnt;
+        bool redo = esc;
+        int v[16];
+        if (FIX) {
+          unsigned int flags = 0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const unsigned int R = s_rt[cnt];
+            flags |= R;
+            v[j] = (int)((__umul24((w4[j >> 2] >> (8 * (j & 3))) & 0xffu, R) + (1u << (kFixShift - 1))) >> kFixShift);   // the multiply looks at R's low 24 bits only
+            cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+          }
+          redo = redo || (int)flags < 0;
+        } else if (!esc) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            v[j] = (int)rescale_f32((float)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu), s_ratio[cnt], redo);
+            cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+          }
+        }
+        if (redo) {   // rare: an escape byte (the lane's values come from the int32 array) or a value too close to a rounding
+                      // boundary for the float form: the reference's own expression for the lane's sixteen bases
+          cnt = cnt0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int x = esc ? depth[p + j] : (int)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu);
+            v[j] = rescale(x, cnt);
+            cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int x = v[j] < 0 ? 0 : v[j]; v[j] = x > capval ? capval : x; }
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
+        *reinterpret_cast<uint4*>(s_val + 16 * kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(rdc8 + P0 + 16 * (int64_t)kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);   // 16-byte aligned: P0 is a multiple of 64 m
+        // sixteen LDS atomics into [value][MAD residue class]: the class of element j is cls0 + j, minus 31 from the lane's
+        // wrap point on; the element index rides in the instruction's offset field
+        const uint32_t cls0 = (p0mod + 16u * (uint32_t)kc) % 31u;
+        unsigned int* ha = s_hist + cls0;
+        unsigned int* hb = ha - 31;
+        const int jw = 31 - (int)cls0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) atomicAdd((j >= jw ? hb : ha) + v[j] * kResClasses + j, 1u);
+      }
+    } else {
+      // ---- per-element path: contiguous source segments between removed regions, values from the int32 array ----
+      int kk = k;
+      int64_t seg = P0;
+      while (seg < P1) {
+        const int64_t nxt = (kk < nreg && R.brk(kk) < P1) ? R.brk(kk) : P1;
+        const int64_t len = nxt - seg;
+        if (len > 0) {
+          const int64_t so = seg + R.shift(kk);
+          const int dst = (int)(seg - P0);
+          for (int64_t e = threadIdx.x; e < len; e += kThreads) {
+            int x = slow_value(so + e);
+            if (x > capval) x = capval;
+            if (x < 0) x = 0;   // negative depth is refused by the caller (K2's flag); keep the byte store in range
+            s_val[dst + e] = (unsigned char)x;
+            rdc8[seg + e] = (unsigned char)x;
+            const int64_t p = seg + e;
+            atomicAdd(&s_hist[x * kResClasses + (p < lim31 ? (int)((uint32_t)p % 31u) : 31)], 1u);
+          }
+        }
+        seg = nxt;
+        if (kk < nreg && R.brk(kk) == nxt) ++kk;
+      }
+    }
+    __syncthreads();
+    // ---- request the next tile now: its loads fly during the median phase ----
+    const int64_t cur_tile = tile;
+    if (tile + gridDim.x < ntiles) { geometry(tile + gridDim.x, P0, P1, fast, soff); if (fast) request(soff); }
+    // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin ----
+    const int b_local = threadIdx.x / parts, part = threadIdx.x % parts;
+    const int64_t b = cur_tile * TB + b_local;
+    const bool active = b < nb;
+    if (SW7) {
+      // Values below 128 (the cap is): four to a register, straight from the LDS bytes.  A bin is the bytes [B, B + m) of the
+      // tile; its (up to 27) dwords go round robin to the bin's four threads, bytes outside the bin masked -- to 0 for the
+      // sum (v_sad_u8 adds four bytes in one instruction), to 0xff for the counts.  #{x > mid} of four values is one
+      // subtraction and one popcount: with the top bit of every byte set, (x | 0x80) - (mid + 1) keeps that bit exactly
+      // where x > mid, and no byte borrows from its neighbour.  Bisection from [0, cap]: the same seven steps for every bin.
+      const int B = b_local * m;
+      const int d0 = B >> 2, d1 = (B + m - 1) >> 2;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(s_val);
+      uint32_t xo[7];
+      uint32_t ssum = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int d = d0 + part + parts * i;
+        const uint32_t v = w[d <= d1 ? d : d1];
+        const int lo_cut = B - 4 * d, hi_cut = 4 * d + 4 - (B + m);          // bytes of the dword before / after the bin
+        uint32_t keep = 0xffffffffu;
+        keep = lo_cut > 0 ? keep << (8 * lo_cut) : keep;
+        keep = hi_cut > 0 ? keep & (0xffffffffu >> (8 * hi_cut)) : keep;
+        keep = (d <= d1 && active) ? keep : 0u;
+        ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
+        xo[i] = (v | ~keep) | 0x80808080u;
+      }
+      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      int lo = 0, hi = capval;
+#pragma unroll 1
+      for (int it = 0; it < 7; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t sub = (uint32_t)(mid + 1) * 0x01010101u;
+        int gt = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gt += __popc((xo[i] - sub) & 0x80808080u);
+        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        // masked bytes (0xff) always count as "> mid" (mid <= 126): 28 dword slots x 4 bytes - m of them per bin
+        const int le = 4 * 7 * parts - gt;
+        if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
+      }
+      if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+    } else if (EPT == 0) {
+      // Caps of 128 .. 253 (a byte has no spare bit): the same scheme on 16-bit fields, two values to a register -- bytes 0
+      // and 2 of a dword in one, bytes 1 and 3 in another, bit 15 of every field as the guard.  #{x > mid} of four values is
+      // two subtractions and two popcounts; eight bisection steps from [0, cap].
+      const int B = b_local * m;
+      const int d0 = B >> 2, d1 = (B + m - 1) >> 2;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(s_val);
+      uint32_t xa[7], xc[7];
+      uint32_t ssum = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int d = d0 + part + parts * i;
+        const uint32_t v = w[d <= d1 ? d : d1];
+        const int lo_cut = B - 4 * d, hi_cut = 4 * d + 4 - (B + m);          // bytes of the dword before / after the bin
+        uint32_t keep = 0xffffffffu;
+        keep = lo_cut > 0 ? keep << (8 * lo_cut) : keep;
+        keep = hi_cut > 0 ? keep & (0xffffffffu >> (8 * hi_cut)) : keep;
+        keep = (d <= d1 && active) ? keep : 0u;
+        ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
+        const uint32_t xb = v | ~keep;                                       // bytes outside the bin: 0xff, above every mid
+        xa[i] = (xb & 0x00ff00ffu) | 0x80008000u;
+        xc[i] = ((xb >> 8) & 0x00ff00ffu) | 0x80008000u;
+      }
+      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      int lo = 0, hi = capval;
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t sub = (uint32_t)(mid + 1) * 0x00010001u;
+        int gt = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gt += __popc((xa[i] - sub) & 0x80008000u) + __popc((xc[i] - sub) & 0x80008000u);
+        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        const int le = 4 * 7 * parts - gt;   // masked bytes (0xff) always count as "> mid" (mid <= 252)
+        if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
+      }
+      if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+    }
+  }
+  __syncthreads();
+  // ---- per-workgroup histogram slab; the last workgroup folds them into res_hist (every value is below vr: overwrite)
+  // and hands [BinAccum | histogram] to the host ----
+  unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
+  // res_hist is zero when the launch begins (K1's FillList): the groups' sums go straight into it
+  if (!fold_slabs_add(hist_slabs, res_hist, vr * kResClasses, per_group, counters)) return;
+  export_words(exp_dst, exp_src, exp_bytes);
+}
+
 inline int grid_for(int64_t items, int per_block) {
   int64_t g = (items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1394,6 +2179,32 @@ void launch_gc_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcA
   const int pg = fold_per_group(grid);
   if (packed) RSI_LAUNCH(k_gc_hist<true>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
   else RSI_LAUNCH(k_gc_hist<false>, dim3((unsigned)grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, sl, gs, pg, counters, acc, table, depth8);
+}
+static int gc_joint_grid(int64_t n) {
+  const int64_t nsub = (n + kSubBases - 1) / kSubBases;
+  int64_t grid = (nsub + kJWaves - 1) / kJWaves;
+  if (grid > 256) grid = 256;   // one workgroup per CU: its histogram takes 107 KB of LDS
+  return (int)(grid < 1 ? 1 : grid);
+}
+size_t gc_joint_slab_bytes(int64_t n) { return (size_t)gc_joint_grid(n) * kJSlabWords * 4; }
+size_t gc_joint_totals_bytes() { return (size_t)kJTotWords * 4; }
+size_t gc_joint_esc_list_bytes() { return (size_t)256 * (1 + kJEscPerWg) * 4; }
+void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
+                          unsigned int* counters, uint8_t* depth8, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
+                          const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
+                          hipStream_t stream) {
+  const int grid = gc_joint_grid(n);
+  RSI_ALLOW_FULL_LDS(k_gc_joint_hist);
+  RSI_LAUNCH(k_gc_joint_hist, dim3((unsigned)grid), dim3(kJThreads), 0, stream, depth, gcbits, n, n / 64 + 1, static_cast<unsigned int*>(slabs),
+             static_cast<unsigned int*>(totals), fold_per_group(grid), counters, acc, table, depth8, hist, aux, vm, head_src, head_dst,
+             (unsigned int)head_bytes, getenv("RSI_HOT_K2J_DBG") ? atoi(getenv("RSI_HOT_K2J_DBG")) : 0, static_cast<unsigned int*>(esc_list), rtab, info,
+             byte_escape_limit(n));
+}
+void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
+                        ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
+                        hipStream_t stream) {
+  RSI_LAUNCH(k_escape_hist, dim3(grid_for((n + 15) / 16, kThreads)), dim3(kThreads), 0, stream, depth8, depth, gcbits, n, table, hist, aux, counter,
+             vm, head_src, head_dst, (unsigned int)head_bytes);
 }
 size_t gc_rescale_slab_bytes(int64_t n) { return (size_t)grid_for(n, kTileBases) * kDeepWidth * 4; }   // the wider of K3's two windows
 
@@ -1499,6 +2310,34 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
   if (sw7) { if (maxc == 1) RSI_K48(1, 1, true); else RSI_K48(2, 1, true); }
   else { if (maxc == 1) RSI_K48(1, 0, false); else RSI_K48(2, 0, false); }   // caps of 128 .. 253: two values to a register (EPT = 0)
 #undef RSI_K48
+}
+// K4j: the same from K2j's byte copy of the RAW depth, rescaling on the way (no K3' in front)
+void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                                 const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                                 int m, uint8_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
+                                 unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, const unsigned int* rtab,
+                                 hipStream_t stream) {
+  int vr, grid, maxc;
+  k48_geometry(m, capval, ncompact, vr, grid, maxc);
+  const int TB = k48_bins_per_tile(m);
+  const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
+  unsigned int* sl = static_cast<unsigned int*>(slabs);
+  unsigned int* gs = static_cast<unsigned int*>(gsum);
+  const int pg = fold_per_group(grid);
+#define RSI_K48J(MC, EP, SW, FX) do { RSI_ALLOW_FULL_LDS((k_rescale_compact_bin8<MC, EP, SW, FX>));                                      \
+    RSI_LAUNCH((k_rescale_compact_bin8<MC, EP, SW, FX>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
+               cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
+               exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab); } while (0)
+  const bool sw7 = capval <= 127;   // four values to a register in the median phase (SW7)
+  const bool fix = rtab != nullptr && !(getenv("RSI_HOT_K4J_FIX") && atoi(getenv("RSI_HOT_K4J_FIX")) == 0);
+  if (fix) {
+    if (sw7) { if (maxc == 1) RSI_K48J(1, 1, true, true); else RSI_K48J(2, 1, true, true); }
+    else { if (maxc == 1) RSI_K48J(1, 0, false, true); else RSI_K48J(2, 0, false, true); }
+  } else {
+    if (sw7) { if (maxc == 1) RSI_K48J(1, 1, true, false); else RSI_K48J(2, 1, true, false); }
+    else { if (maxc == 1) RSI_K48J(1, 0, false, false); else RSI_K48J(2, 0, false, false); }
+  }
+#undef RSI_K48J
 }
 unsigned int byte_escape_limit(int64_t n) { return (unsigned int)(n >> 3 > 0xffffffffll ? 0xffffffffll : n >> 3); }
 int hist_window_base(double center, int width) {   // [base, base + width) around the centre of the distribution; 0 up to ~160x

@@ -834,6 +834,14 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   ph_a1a.stop();
   Phase ph_a1b(ctx, "a1b.launch K1-K3");
   const bool want_cap = P.cap > 1;
+  // Two per-base passes behind K1 instead of three: K2j counts (GC count, depth byte) pairs, its last workgroup derives the GC
+  // table, the rescaled-value histogram and the cap median from them, K4j rescales on its way to the bins.  RSI_HOT_JOINT=0:
+  // the three-pass chain (K2, K3', K4'), which is also where a chromosome goes whose joint counters wrapped.
+  const char* joint_env = getenv("RSI_HOT_JOINT");
+  const bool joint = P.gcadjust && want_cap && !(joint_env && atoi(joint_env) == 0);
+  // one buffer: the folded pair counters (cleared by K1) | the workgroups' escape lists | the levels' fixed-point ratios for K4j
+  const size_t joint_list_off = (gc_joint_totals_bytes() + 255) & ~size_t(255), joint_lut_off = joint_list_off + ((gc_joint_esc_list_bytes() + 255) & ~size_t(255));
+  if (joint) HIPCHK(ctx->joint_tot.ensure(joint_lut_off + (size_t)kGcLevels * 4 + 64));
 
   // ---- A1-A4 are issued back to back: GC mask and N runs (K1, K1b), GC table and rescale (K2, K3), the cap
   // median walk.  K1 clears the accumulators of everything behind it, K2's last workgroup builds the GC table, K3's
@@ -845,6 +853,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     fill_add(fl, small, kHeaderBytes, 0u);
     if (P.gcadjust || want_cap) fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
     fill_add(fl, ctx->hist_res.p, kResHead + (size_t)256 * kResClasses * 4, 0u);   // BinAccum of K4 and the rows K4' adds its groups' sums to (its range is at most 256 values)
+    if (joint) fill_add(fl, ctx->joint_tot.p, gc_joint_totals_bytes(), 0u);       // K2j's folded joint histogram
     Timer t(ctx, "fasta_classify", true);
     launch_fasta_classify(d_fasta, n, ctx->gcbits.as<uint64_t>(), ctx->nbits.as<uint64_t>(), nwords, fl, st);
   }
@@ -866,9 +875,18 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   GcAccum acc;
   ValueHistAux aux;
   ValueMedian vm;
-  memset(&acc, 0, sizeof(acc)); memset(&aux, 0, sizeof(aux)); memset(&vm, 0, sizeof(vm));
+  JointInfo jinfo;
+  memset(&acc, 0, sizeof(acc)); memset(&aux, 0, sizeof(aux)); memset(&vm, 0, sizeof(vm)); memset(&jinfo, 0, sizeof(jinfo));
   // packed = 1 first; depths of 2^21 and more make the packed accumulators overflow (flag bit 1): everything from K2 on is
   // then issued once more with the two-atomic form
+  auto issue_joint = [&]() -> int {
+    HIPCHK(ctx->depth8.ensure((size_t)n + 2048));
+    Timer t(ctx, "gc_joint_hist", true);
+    launch_gc_joint_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, ctx->slabs.p, ctx->joint_tot.p, d_done, ctx->depth8.as<uint8_t>(),
+                         ctx->hist_val.as<uint32_t>(), d_aux, d_vm, small, head, head_bytes, ctx->joint_tot.as<uint8_t>() + joint_list_off,
+                         reinterpret_cast<unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off), reinterpret_cast<JointInfo*>(small + kOffJointInfo), st);
+    return RSI_OK;
+  };
   auto issue_gc_chain = [&](int packed) -> int {
     if (P.gcadjust) {
       // K2 leaves a byte copy of the depth; K3' streams that copy (1 byte per base instead of 4) and writes nothing per base
@@ -886,19 +904,44 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   };
   auto unpack_head = [&]() {
     memcpy(&acc, head + kOffGcAcc, sizeof(acc));
+    memcpy(&jinfo, head + kOffJointInfo, sizeof(jinfo));
     memcpy(&aux, head + kOffValAux, sizeof(aux));
     memcpy(&vm, head + kOffValMedian, sizeof(vm));
     memcpy(&n_trans, head + kOffCounters + 5 * 4, 4);
     memcpy(trans_raw.data(), head + kOffNtrans, (size_t)kEagerRuns * 8);
   };
   // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
-  if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(gc_hist_slab_bytes(n), std::max(gc_rescale_slab_bytes(n), value_hist8_slab_bytes(n)))));
-  int rc = issue_gc_chain(1);
+  if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(std::max(gc_hist_slab_bytes(n), joint ? gc_joint_slab_bytes(n) : 0), std::max(gc_rescale_slab_bytes(n), value_hist8_slab_bytes(n)))));
+  int rc = joint ? issue_joint() : issue_gc_chain(1);
   if (rc != RSI_OK) return rc;
   ph_a1b.stop();
   { Phase ph_a1c(ctx, "a1c.wait K1-K3"); HIPCHK(CTX_SYNC()); }
   unpack_head();
-  if (P.gcadjust && (acc.negatives & 2u)) {
+  bool joint_ok = joint;
+  if (joint && (acc.negatives & 4u)) {
+    // a workgroup's 16-bit pair counters wrapped (a sequence without GC variation under a constant depth): the three-pass
+    // chain from clean accumulators
+    Phase ph_w(ctx, "a2-3.joint wrapped: three-pass chain");
+    joint_ok = false;
+    FillList fl{};
+    fill_add(fl, small + kOffGcAcc, 4096, 0u);
+    fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
+    fill_add(fl, d_aux, 16, 0u);
+    fill_add(fl, d_vm, 32, 0u);
+    launch_fill(fl, st);
+    if ((rc = issue_gc_chain(1)) != RSI_OK) return rc;
+    HIPCHK(CTX_SYNC());
+    unpack_head();
+  }
+  if (joint_ok && !(acc.negatives & 1u) && jinfo.esc_pending && (uint64_t)acc.escapes <= (uint64_t)byte_escape_limit(n)) {
+    // depths of 255 and more are not in K2j's pair counters, and there were too many for its last workgroup to add them from the
+    // workgroups' lists: their rescaled values enter the histogram now, then the median walk
+    Phase ph_e(ctx, "a2-3.escapes");
+    { Timer t(ctx, "escape_hist", true); launch_escape_hist(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+    HIPCHK(CTX_SYNC());
+    unpack_head();
+  }
+  if (P.gcadjust && !joint_ok && (acc.negatives & 2u)) {
     Phase ph_w(ctx, "a2-3.gc wide redo");
     FillList fl{};
     fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
@@ -917,6 +960,12 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   if (P.gcadjust && (uint64_t)acc.escapes > (uint64_t)byte_escape_limit(n)) {
     Phase ph_d(ctx, "a2-3.deep coverage");
     deep = true;
+    if (joint_ok) {   // K2j's last workgroup has counted the byte-sized depths already: the int32 kernel starts from a clean histogram
+      FillList fl{};
+      fill_add(fl, ctx->hist_val.p, (size_t)kHistValues * 4, 0u);
+      fill_add(fl, d_aux, 16, 0u);
+      launch_fill(fl, st);
+    }
     HIPCHK(ctx->rd_gc.ensure((size_t)(n + 4) * 4));
     HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
     { Timer t(ctx, "gc_rescale", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, 1, ctx->rd_gc.as<int32_t>(), ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
@@ -1020,6 +1069,12 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     HIPCHK(ctx->rdc8.ensure((size_t)ncompact + 64));
     ctx->rdc_is_bytes = true;
     Timer t(ctx, "cap_compact_bin", true);
+    if (joint_ok || !(joint_env && atoi(joint_env) == 0))   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
+      launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+                                  ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
+                                  ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0,
+                                  joint_ok ? reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off) : nullptr, st);
+    else   // RSI_HOT_JOINT=0: round 2's chain to the end (K4' from K3''s rescaled bytes), kept for A/B runs
     launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                             ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                             ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);

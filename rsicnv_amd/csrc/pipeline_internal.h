@@ -141,6 +141,7 @@ struct rsi_ctx {
   DevBuf sharpen_ws;          // workspace of k_sharpen_edges, cleared when (re)allocated
   DevBuf fs_ws, fs_out;       // filterstatus' level sums on the device (kernels_fs.hip)
   DevBuf scan_tiles;          // tiles the scan's detection pass lists for the exact sweep
+  DevBuf joint_tot;           // K2j's folded joint histogram [GC count][depth byte] + escapes
   int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
@@ -286,6 +287,7 @@ inline int fail(rsi_ctx* ctx, int code, const std::string& msg) {
 
 // offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
 constexpr size_t kOffGcAcc = 0;                                   // GcAccum
+constexpr size_t kOffJointInfo = 3328;                            // JointInfo (behind GcAccum's 3256 bytes)
 constexpr size_t kOffValAux = 4096;                               // ValueHistAux
 constexpr size_t kOffMinMax = 4608;                               // MinMaxF
 constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts

@@ -1,0 +1,17 @@
+# usage: bash tools/gpu_pmc_probe.sh TAG "<perbase_probe variants...>"  -> gpurun_out/pmcp_TAG/summary.txt  (SQ counters of the per-base kernels)
+set -e
+cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcp_$TAG
+mkdir -p $OUT
+cd /tmp
+i=0
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  timeout -k 10 500 rocprofv3 --pmc $C --output-format csv -d $OUT/pass$i -o p -- python3 $GRAFT_REPO_ROOT/tools/perbase_probe.py "$@" > $OUT/pass$i.log 2> $OUT/pass$i.err || { tail -5 $OUT/pass$i.err; exit 1; }
+  echo "pass $i done"
+done
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt
+grep -E "^kernel|k_gc_joint|k_rescale_compact|k_cap_compact_bin8|k_gc_hist|k_value_hist8|k_fasta" $OUT/summary.txt
