@@ -38,9 +38,21 @@ void launch_fill(const FillList& fill, hipStream_t stream);   // the same cleari
 // Scratch for the in-kernel folds of the per-workgroup slabs (device_util.h, fold_slabs): group sums of the widest slab.
 // counters: kFoldGroups + 1 arrival counters per kernel, zero before the launch (every launch leaves them zero).
 size_t fold_scratch_bytes();
+// What the per-base kernels hand each other on the device, so that K4j can be queued behind K2j without the host in between:
+// the regions K4j removes (K1b's last workgroup), the cap (K2j's last workgroup), and K4j's verdict on its launch configuration.
+struct PhaseParams {
+  int32_t nreg;        // padded, merged N regions (cbreak / cum in device memory)
+  int32_t capval;      // (int)(cap median * cap), or < 0: not known on the device (escapes pending, deep coverage, wrapped counters)
+  int64_t ncompact;    // n minus the removed bases
+  int32_t regions_ok;  // 0: the boundary list was too long or malformed for the device: the host's regions count
+  int32_t redo;        // set by K4j: launched with a configuration that does not fit the cap -- nothing written, launch again
+  int32_t pad[2];
+};
 // ---- K1b: run boundaries of the N bitmask -> unordered list of (pos << 1 | is_end) ----
-void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
-                          hipStream_t stream);
+// pp != NULL: the last workgroup also builds cbreak[4100] / cum[4097] (regions padded by dx, merged) and fills pp's region fields;
+// counter: an arrival counter, zero before and after.
+void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap, int64_t n, int dx,
+                          PhaseParams* pp, int64_t* cbreak, int64_t* cum, unsigned int* counter, hipStream_t stream);
 
 // ---- K2: GC table accumulation (checkgccontent pass 1, gccontent.cpp:105-145) ----
 struct GcAccum {
@@ -95,7 +107,7 @@ size_t gc_joint_esc_list_bytes();
 void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
                           unsigned int* counters, uint8_t* depth8 /* n + 2048 bytes */, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
                           const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
-                          hipStream_t stream);
+                          PhaseParams* pp /* capval (and redo = 0) for a K4j queued behind */, double cap_mult, hipStream_t stream);
 void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
                         ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
                         hipStream_t stream);
@@ -174,6 +186,8 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
                                  int m, uint8_t* rdc8, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
                                  unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes,
                                  const unsigned int* rtab /* K2j's fixed-point ratios, or NULL: the float form with its exactness margin */,
+                                 PhaseParams* pp /* NULL, or: nreg / ncompact / capval are read from it on the device (cbreak / cum from device
+                                                    memory); the arguments of those names only shape the launch (capval: a guess, checked) */,
                                  hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----

@@ -63,10 +63,16 @@ __global__ __launch_bounds__(kThreads) void k_fasta_classify(const uint8_t* __re
   }
 }
 
-// K1b n_transitions: run starts and (exclusive) ends of the N mask.
+// K1b n_transitions: run starts and (exclusive) ends of the N mask.  With `pp` the launch's last workgroup also turns the list
+// into what K4j needs -- the padded, merged regions of get_noseq_regions (loaddata.cpp:243-273) as compacted break points
+// and removed lengths (cbreak / cum) -- so that K4j can be queued behind K2j without the host in between; the host builds
+// the same regions from the same list for its own stages.  Lists of more than kRegSortMax entries are left to the host.
+constexpr int kRegSortMax = 1024;
 __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __restrict__ nbits, int64_t nwords,
                                                             uint64_t* __restrict__ list, uint32_t* __restrict__ count,
-                                                            uint32_t cap) {
+                                                            uint32_t cap, int64_t n, int dx, PhaseParams* __restrict__ pp,
+                                                            int64_t* __restrict__ cbreak, int64_t* __restrict__ cum,
+                                                            unsigned int* __restrict__ counter) {
   for (int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * kThreads) {
     const uint64_t cur = nbits[w];
     const uint64_t prev_top = w > 0 ? (nbits[w - 1] >> 63) : 0;
@@ -76,14 +82,45 @@ __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __re
       const int b = __ffsll((long long)starts) - 1;
       starts &= starts - 1;
       const uint32_t k = atomicAdd(count, 1u);
-      if (k < cap) list[k] = ((uint64_t)(w * 64 + b) << 1);
+      if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1));
     }
     while (ends) {
       const int b = __ffsll((long long)ends) - 1;
       ends &= ends - 1;
       const uint32_t k = atomicAdd(count, 1u);
-      if (k < cap) list[k] = ((uint64_t)(w * 64 + b) << 1) | 1u;
+      if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1) | 1ull);
     }
+  }
+  if (!pp) return;
+  if (!last_block_done(counter)) return;
+  __shared__ unsigned long long s_e[kRegSortMax], s_s[kRegSortMax];
+  const unsigned int cnt = ld_cg(count);
+  if (cnt > (unsigned int)kRegSortMax || (cnt & 1u)) { if (threadIdx.x == 0) { pp->regions_ok = 0; pp->nreg = 0; pp->ncompact = n; } return; }
+  for (unsigned int k = threadIdx.x; k < cnt; k += kThreads) s_e[k] = ld_cg(reinterpret_cast<const unsigned long long*>(&list[k]));
+  __syncthreads();
+  for (unsigned int k = threadIdx.x; k < cnt; k += kThreads) {   // rank sort: the entries are distinct
+    const unsigned long long e = s_e[k];
+    unsigned int rank = 0;
+    for (unsigned int j = 0; j < cnt; ++j) rank += s_e[j] < e;
+    s_s[rank] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int nreg = 0, ok = 1;
+    int64_t removed = 0, cur_s = 0, cur_e = -2;   // the open (padded) region
+    bool open = false;
+    for (unsigned int i = 0; i < cnt; i += 2) {
+      const unsigned long long a = s_s[i], b = s_s[i + 1];
+      if ((a & 1ull) || !(b & 1ull)) { ok = 0; break; }            // a start, then its end
+      int64_t gs = (int64_t)(a >> 1) - dx, ge = (int64_t)(b >> 1) - 1 + dx;   // inclusive run, padded by dx each side
+      gs = gs < 0 ? 0 : gs; ge = ge > n - 1 ? n - 1 : ge;
+      if (open && gs <= cur_e + 1) { cur_e = ge > cur_e ? ge : cur_e; continue; }
+      if (open) { cbreak[nreg] = cur_s - removed; removed += cur_e - cur_s + 1; ++nreg; cum[nreg] = removed; }
+      cur_s = gs; cur_e = ge; open = true;
+    }
+    cum[0] = 0;
+    if (open) { cbreak[nreg] = cur_s - removed; removed += cur_e - cur_s + 1; ++nreg; cum[nreg] = removed; }
+    pp->nreg = nreg; pp->ncompact = n - removed; pp->regions_ok = ok;
   }
 }
 
@@ -717,7 +754,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     GcAccum* __restrict__ acc, double* __restrict__ table, uint8_t* __restrict__ d8, uint32_t* __restrict__ ghist,
     ValueHistAux* __restrict__ aux, ValueMedian* __restrict__ vm, const void* head_src, void* head_dst, unsigned int head_bytes, int dbg,
     unsigned int* __restrict__ esc_list /* gridDim.x lists of 1 + kJEscPerWg words */, unsigned int* __restrict__ rtab /* [202] */,
-    JointInfo* __restrict__ info, unsigned int escape_limit) {
+    JointInfo* __restrict__ info, unsigned int escape_limit, PhaseParams* __restrict__ pp, double cap_mult) {
   __shared__ __align__(16) unsigned int s_j[kJSlabWords];
   __shared__ unsigned int s_nesc;
   __shared__ WaveGc s_gc[kJWaves];
@@ -1020,6 +1057,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     info->gmin = s_gmin > s_gmax ? 0 : (int)s_gmin; info->gmax = s_gmin > s_gmax ? 0 : (int)s_gmax;
     info->vmax = (int)s_vmax; info->esc_pending = esc_pending ? 1 : 0;
   }
+  if (threadIdx.x == 0) { pp->capval = -1; pp->redo = 0; }         // until the median is known (and when it will not be: K4j then declines)
   if (deep || (dbg & 16)) { sync_drained(); export_words(head_dst, head_src, head_bytes); return; }   // (dbg 16: ablation, table only)
   // ---- K4j's rescale without floating point: per level a fixed-point ratio R (22 fraction bits: 2^-23 * 254 is the distance from
   // a rounding boundary at which it can go wrong) with (v * R + 2^21) >> 22 == the reference's (int)(v * rdmean / table[g] + 0.5)
@@ -1100,6 +1138,18 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     range = range < top ? top : range;
     range = range < kValLds ? kValLds : range;
     value_median_block<kJThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
+  }
+  sync_drained();
+  // the cap as apply_cap takes it (loaddata.cpp:233-238: median of the uncompacted array, RD = median * cap truncated), for a
+  // K4j queued right behind this launch; the host derives the same number from the header and checks everything else
+  if (threadIdx.x == 0 && !esc_pending && cap_mult > 1.0) {
+    const int lo = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->lo)), hi = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->hi));
+    const int med = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->med));
+    double qm = (double)lo;
+    if (lo <= hi && (double)hi - (double)lo >= 1.0 && med >= 0) qm = (double)med;
+    const unsigned long long inr = ld_cg(&vm->inrange);
+    const bool ok = inr + aux->big == (unsigned long long)n && (unsigned long long)n / 2 <= inr && !(ld_cg(t_flags + 2)) && !(ld_cg(t_flags + 0));
+    pp->capval = ok ? (int32_t)(qm * cap_mult) : -1;
   }
   sync_drained();
   export_words(head_dst, head_src, head_bytes);
@@ -1872,11 +1922,21 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
     int32_t* __restrict__ binmed,
     int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
     int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl,
-    const unsigned int* __restrict__ rtab /* FIX: [kGcLevels] ratios from K2j */) {
+    const unsigned int* __restrict__ rtab /* FIX: [kGcLevels] ratios from K2j */,
+    PhaseParams* __restrict__ pp /* not NULL: regions, length and cap come from the device (K1b's and K2j's last workgroups), launched behind
+                                   K2j without the host in between; the launch configuration (vr, SW7) was a guess to be checked here */) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
   __shared__ unsigned int s_rt[kGcLevels];   // FIX: the levels' fixed-point ratios
+  if (pp) {
+    nreg = pp->nreg; ncompact = pp->ncompact; capval = pp->capval;
+    // does the configuration this launch was given fit what the device found?  (wave-uniform: every workgroup decides alike)
+    if (!pp->regions_ok || capval < 1 || capval >= kByteSat || capval >= vr || SW7 != (capval <= 127) || ncompact < (int64_t)m * 8) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) pp->redo = 1;
+      return;
+    }
+  }
   __shared__ double s_table[kGcLevels];   // the reference's own expression: per-element path, escapes, values too close to a rounding boundary
   __shared__ float s_ratio[kGcLevels];    // rdmean / table[g] as float (rescale_f32)
   __shared__ uint64_t s_gw[kK4GcWords];   // GC mask words under the tile's source range (+ margins), staged per tile
@@ -1884,7 +1944,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
   for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(table[kGcLevels] / t); }
   if (FIX) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_rt[e] = rtab[e];
-  if (nreg <= kRegInline) {
+  if (nreg <= kRegInline && !pp) {
     for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
     for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
   } else {
@@ -2156,10 +2216,10 @@ void launch_fill(const FillList& fill, hipStream_t stream) {
   if (units == 0) return;
   RSI_LAUNCH(k_fill, dim3(grid_for((int64_t)units, kThreads)), dim3(kThreads), 0, stream, fill);
 }
-void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap,
-                          hipStream_t stream) {
+void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap, int64_t n, int dx,
+                          PhaseParams* pp, int64_t* cbreak, int64_t* cum, unsigned int* counter, hipStream_t stream) {
   RSI_LAUNCH(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
-                     count, cap);
+                     count, cap, n, dx, pp, cbreak, cum, counter);
 }
 static int gc_hist_grid(int64_t n) {
   const int64_t nsub = (n + kSubBases - 1) / kSubBases;
@@ -2192,13 +2252,13 @@ size_t gc_joint_esc_list_bytes() { return (size_t)256 * (1 + kJEscPerWg) * 4; }
 void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
                           unsigned int* counters, uint8_t* depth8, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
                           const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
-                          hipStream_t stream) {
+                          PhaseParams* pp, double cap_mult, hipStream_t stream) {
   const int grid = gc_joint_grid(n);
   RSI_ALLOW_FULL_LDS(k_gc_joint_hist);
   RSI_LAUNCH(k_gc_joint_hist, dim3((unsigned)grid), dim3(kJThreads), 0, stream, depth, gcbits, n, n / 64 + 1, static_cast<unsigned int*>(slabs),
              static_cast<unsigned int*>(totals), fold_per_group(grid), counters, acc, table, depth8, hist, aux, vm, head_src, head_dst,
              (unsigned int)head_bytes, getenv("RSI_HOT_K2J_DBG") ? atoi(getenv("RSI_HOT_K2J_DBG")) : 0, static_cast<unsigned int*>(esc_list), rtab, info,
-             byte_escape_limit(n));
+             byte_escape_limit(n), pp, cap_mult);
 }
 void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
                         ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
@@ -2316,9 +2376,9 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
                                  const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
                                  int m, uint8_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
                                  unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, const unsigned int* rtab,
-                                 hipStream_t stream) {
+                                 PhaseParams* pp, hipStream_t stream) {
   int vr, grid, maxc;
-  k48_geometry(m, capval, ncompact, vr, grid, maxc);
+  k48_geometry(m, capval, ncompact, vr, grid, maxc);   // pp != NULL: capval is the caller's guess (it fixes vr and SW7), ncompact an upper bound
   const int TB = k48_bins_per_tile(m);
   const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
@@ -2327,7 +2387,7 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
 #define RSI_K48J(MC, EP, SW, FX) do { RSI_ALLOW_FULL_LDS((k_rescale_compact_bin8<MC, EP, SW, FX>));                                      \
     RSI_LAUNCH((k_rescale_compact_bin8<MC, EP, SW, FX>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
                cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
-               exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab); } while (0)
+               exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab, pp); } while (0)
   const bool sw7 = capval <= 127;   // four values to a register in the median phase (SW7)
   const bool fix = rtab != nullptr && !(getenv("RSI_HOT_K4J_FIX") && atoi(getenv("RSI_HOT_K4J_FIX")) == 0);
   if (fix) {

@@ -142,6 +142,9 @@ struct rsi_ctx {
   DevBuf fs_ws, fs_out;       // filterstatus' level sums on the device (kernels_fs.hip)
   DevBuf scan_tiles;          // tiles the scan's detection pass lists for the exact sweep
   DevBuf joint_tot;           // K2j's folded joint histogram [GC count][depth byte] + escapes
+  // K4j queued behind K2j without a host round trip needs its launch configuration before the cap is known: the cap of the
+  // context's previous chromosome under the same flags (one sample: one depth), checked on the device and again by the host
+  int32_t spec_capval = -1; int32_t spec_m = 0; double spec_cap = 0.0;
   int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;
@@ -288,6 +291,7 @@ inline int fail(rsi_ctx* ctx, int code, const std::string& msg) {
 // offsets into the `small` buffer (accumulators and little lists), all 256-byte aligned
 constexpr size_t kOffGcAcc = 0;                                   // GcAccum
 constexpr size_t kOffJointInfo = 3328;                            // JointInfo (behind GcAccum's 3256 bytes)
+constexpr size_t kOffPhase = 3344;                                // PhaseParams (32 bytes)
 constexpr size_t kOffValAux = 4096;                               // ValueHistAux
 constexpr size_t kOffMinMax = 4608;                               // MinMaxF
 constexpr size_t kOffCounters = 4864;                             // uint32[8]: scan counters, list counts
