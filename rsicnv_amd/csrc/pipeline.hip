@@ -292,7 +292,7 @@ class DeviceTester : public rsih::NeighbourTester {
     // several workgroups per test when the chip has room for them: a stand-alone context, or a pool run over a few
     // chromosomes only (a rank's share of a sharded genome); one workgroup per test when a dozen chromosomes share the chip
     const char* split_env = getenv("RSI_HOT_CAND_SPLIT");
-    const bool split = split_env ? atoi(split_env) != 0 : (ctx->gate == nullptr || ctx->gate->few_chromosomes);
+    const bool split = split_env ? atoi(split_env) != 0 : true;
     size_t first = 0;
     while (first < n) {
       std::vector<CandJob> jobs;
