@@ -182,9 +182,45 @@ def main():
     scan_evals = [0]
     id_offset = 0 if sharded else rank * len(plans)   # weak-scaling mode: every rank's sample keeps its own ids
 
+    # A step = the pool's pass over this rank's chromosomes, then `finish_step` (pack, gather, rank 0's rows in order, hash).
+    # finish_step of step k runs on a second host thread while the pool is already on step k + 1: the GPU never waits for
+    # Python, every step's rows are still produced (and hashed) inside the timed region -- `drain()` joins the thread before a
+    # timer is read.  One thread, one queue: the collectives stay in step order on every rank.
+    import queue
+    import threading
+    post_q = queue.Queue(maxsize=2)
+    post_err = []
+    last_rows = [0]
+
+    def post_worker():
+        while True:
+            item = post_q.get()
+            try:
+                if item is None:
+                    return
+                if not post_err:
+                    last_rows[0] = finish_step(*item)
+            except Exception as e:   # surfaces at the next drain()
+                post_err.append(e)
+            finally:
+                post_q.task_done()
+
+    post_thread = threading.Thread(target=post_worker, daemon=True)
+    post_thread.start()
+
+    def drain():
+        post_q.join()
+        if post_err:
+            raise post_err[0]
+        return last_rows[0]
+
     def step(timed=False):
-        """One genome: this rank's chromosomes through the pool, the gather, rank 0's rows in chromosome order."""
+        """One genome: this rank's chromosomes through the pool; the rest of the step is queued for the second thread."""
         results = pool.run(params, chrom_args, collect_times=timed) if chrom_args else []
+        post_q.put((results, timed))
+
+    def finish_step(results, timed):
+        """The gather, rank 0's rows in chromosome order."""
         if timed:   # window evaluations of the scan this step: 2 sweeps x Lmax x bins x 2 passes per chromosome
             scan_evals[0] = sum(4 * int(r.stats["Lmax"]) * int(r.stats["nbins"]) for r in results)
         block = rd.pack_results(mine, results, nslots, id_offset)
@@ -208,6 +244,7 @@ def main():
         return len(rows)
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -234,11 +271,11 @@ def main():
     pool.reset_times()
     fence()
     t_start = time.perf_counter()
-    ncalls = 0
     for _ in range(args.steps):
-        ncalls = step(timed=True)
-    fence()
+        step(timed=True)
+    fence()                                   # joins the second thread: all K steps' rows exist
     elapsed = time.perf_counter() - t_start
+    ncalls = last_rows[0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -365,6 +402,9 @@ def main():
         if side:
             out.update(side)
         print(json.dumps(out), flush=True)
+    drain()
+    post_q.put(None)
+    post_thread.join(timeout=10)
     pool.close()
     if world > 1:
         dist.destroy_process_group()

@@ -107,11 +107,15 @@ constexpr uint32_t kLdsBins = 12288;   // 48 KB of LDS counters: covers a value 
 // one-atomic-per-element histogram serialises on it (271 ms per 3 Gb step with global atomics).
 constexpr int kHistRun = 8;
 
+// PACK16: two 16-bit LDS counters to a word (half the LDS: the kernel then fits beside four resident per-base workgroups
+// instead of waiting for one to leave); the caller guarantees that a workgroup counts fewer than 65536 values in all.
+template <bool PACK16 = false>
 __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int32_t* __restrict__ mask, int64_t nb, int use_abs,
                                           double center, double ymin, uint32_t* __restrict__ hist, uint32_t np, int use_lds,
                                           unsigned int* s_h) {
   const uint32_t nl = use_lds ? (np < (uint32_t)use_lds ? np : (uint32_t)use_lds) : 0;   // buckets counted in LDS (use_lds = how many fit)
-  if (use_lds) { for (uint32_t e = threadIdx.x; e < nl; e += kThreads) s_h[e] = 0; __syncthreads(); }
+  auto lds_add = [&](uint32_t k, uint32_t c) { if (PACK16) atomicAdd(&s_h[k >> 1], c << ((k & 1u) << 4)); else atomicAdd(&s_h[k], c); };
+  if (use_lds) { for (uint32_t e = threadIdx.x; e < (PACK16 ? (nl + 1) / 2 : nl); e += kThreads) s_h[e] = 0; __syncthreads(); }
   const int64_t nchunks = (nb + kHistRun - 1) / kHistRun;
   for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
     uint32_t pend_k = 0xffffffffu, pend_c = 0;
@@ -123,16 +127,19 @@ __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int
       uint32_t k = (uint32_t)(unsigned long long)idx;
       if (k >= np) k = np - 1;                                 // cannot happen (np = range/dy + 2)
       if (k != pend_k) {
-        if (pend_c) { if (pend_k < nl) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+        if (pend_c) { if (pend_k < nl) lds_add(pend_k, pend_c); else atomicAdd(&hist[pend_k], pend_c); }
         pend_k = k; pend_c = 0;
       }
       ++pend_c;
     }
-    if (pend_c) { if (pend_k < nl) atomicAdd(&s_h[pend_k], pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+    if (pend_c) { if (pend_k < nl) lds_add(pend_k, pend_c); else atomicAdd(&hist[pend_k], pend_c); }
   }
   if (use_lds) {
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < nl; e += kThreads) { const unsigned int c = s_h[e]; if (c) atomicAdd(&hist[e], c); }
+    for (uint32_t e = threadIdx.x; e < nl; e += kThreads) {
+      const unsigned int c = PACK16 ? (s_h[e >> 1] >> ((e & 1u) << 4)) & 0xffffu : s_h[e];
+      if (c) atomicAdd(&hist[e], c);
+    }
   }
 }
 
@@ -240,6 +247,7 @@ __device__ inline void grid_walk_block(const uint32_t* __restrict__ hist, GridMe
   }
 }
 
+template <bool PACK16>
 __global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                         int64_t nb, int use_abs, double center,
                                                         const double* __restrict__ center_ptr,
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_walk(const float* __restrict_
   fill_ranges(fill);   // for the kernels behind this one (the scan's first-L arrays, its counters)
   if (!g->flags) {
     const uint32_t np = g->np;
-    hist_body(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, (int)lds_bins, s_h);   // the first lds_bins buckets in LDS
+    hist_body<PACK16>(x, mask, nb, use_abs, center_ptr ? *center_ptr : center, g->ymin, hist, np, (int)lds_bins, s_h);   // the first lds_bins buckets in LDS
   }
   if (!last_block_done(counter)) return;
   if (!g->flags) grid_walk_block(hist, g);
@@ -1131,15 +1139,17 @@ void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use
 void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
                       const GridChain& c, GridMedian* out, const GridExport* ex, const FillList* fill, hipStream_t stream) {
   const uint32_t bins = kLdsBins;
-  const size_t lds = (size_t)bins * 4;
-  RSI_ALLOW_FULL_LDS(k_hist_walk);
   int grid = grid_for(nb, kThreads * kHistRun * 8);
   if (grid > 128) grid = 128;
+  // 16-bit LDS counters while a workgroup's share of the bins cannot make one wrap
+  const bool pack16 = (nb + grid - 1) / grid + kHistRun < 65536;
+  const size_t lds = pack16 ? (size_t)bins * 2 : (size_t)bins * 4;
   ExportPair e{};
   if (ex) for (int k = 0; k < 2; ++k) { e.src[k] = ex->src[k]; e.dst[k] = ex->dst[k]; e.bytes[k] = (unsigned int)ex->bytes[k]; }
   FillList f{};
   if (fill) f = *fill;
-  RSI_LAUNCH(k_hist_walk, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
+  if (pack16) RSI_LAUNCH(k_hist_walk<true>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
+  else { RSI_ALLOW_FULL_LDS(k_hist_walk<false>); RSI_LAUNCH(k_hist_walk<false>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins); }
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, uint32_t* tiles, hipStream_t stream) {
