@@ -459,6 +459,18 @@ def side_measurements(lib, pool, dev, args):
             host_case = (fasta_np.copy(), depth_np.copy())
         del h_rd, h_fa
     hot.close()
+    # ---- the genome from pinned host memory through the pool (rsi_pool_run_host): every worker moves its chromosome over its
+    # own stream, transfers of some chromosomes beside the kernels of others; PCIe-bound at 5 B/base ----
+    try:
+        out["t_device_h2d_genome"] = genome_from_host(lib, pool, dev, args)
+    except Exception as e:
+        out["t_device_h2d_genome"] = {"error": str(e)[:200]}
+    # ---- the envelope the byte path does not cover, on one 60 Mb chromosome each: -NOGC (no GC pass: 13.7
+    # algorithmic B/base), wide bins (m = 201: the int32 K4), 300x coverage (int32 K3 / K4 with windows that follow the depth) ----
+    try:
+        out["fallback_envelope"] = fallback_envelope(lib, pool, dev)
+    except Exception as e:
+        out["fallback_envelope"] = {"error": str(e)[:200]}
     # ---- configs[4] (3 Gb at 60x, -m 51 -MED -cap 4) as a side pass: a driver-timed number for the other 3 Gb
     # configuration, with its scan kernel's rate (Lmax 196 there) ----
     try:
@@ -486,6 +498,108 @@ def side_measurements(lib, pool, dev, args):
                             "note": "rsicnv rsi -f REF -d RDFILE -c chrS on configs[1] (process start, FASTA, depth text parse, device path, output file)"}
     except Exception as e:   # a side measurement must not take the bench line down
         out["t_e2e"] = {"error": str(e)[:200]}
+    return out
+
+
+def host_memory_budget():
+    """Bytes of host memory this process may still take (cgroup limit and MemAvailable), or 0 when unknown."""
+    avail = 0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        return 0
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+        if lim != "max":
+            avail = min(avail, int(lim) - cur)
+    except (OSError, ValueError):
+        pass
+    return max(avail, 0)
+
+
+def genome_from_host(lib, pool, dev, args):
+    """configs[3]'s chromosomes in pinned host memory -> results on the host: as much of the genome as a third of the free host
+    memory holds (5 bytes per base pinned), longest chromosomes first."""
+    import torch
+    from rsicnv_amd import api, synth
+    budget = host_memory_budget() // 3
+    plans = sorted((synth.config_plan(4, chrom=c) for c in range(24)), key=lambda p: -p["n"])
+    params = api.make_params(**synth.config_flags(4))
+    host, total = [], 0
+    for p in plans:
+        need = 5 * p["n"] + 4096
+        if budget < need:
+            break
+        budget -= need
+        d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device=dev)
+        d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device=dev)
+        synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
+        h_rd = torch.empty(p["n"], dtype=torch.int32, pin_memory=True)
+        h_fa = torch.empty(p["n"], dtype=torch.uint8, pin_memory=True)
+        h_rd.copy_(d_rd[:p["n"]]); h_fa.copy_(d_fa[:p["n"]])
+        torch.cuda.synchronize()
+        del d_fa, d_rd
+        host.append((h_rd, h_fa, p["n"]))
+        total += p["n"]
+    if not host:
+        return {"skipped": "not enough free host memory for one chromosome"}
+    chroms = [(a.data_ptr(), b.data_ptr(), n) for a, b, n in host]
+    pool.set_timing(0)
+    pool.run(params, chroms, host=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        res = pool.run(params, chroms, host=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"chromosomes": len(host), "bases": total, "ms": round(dt * 1e3, 2), "bases_per_s": round(total / dt, 1),
+            "h2d_GBps": round(5.0 * total / dt / 1e9, 1), "calls": sum(len(r.calls("calls")) for r in res),
+            "note": "rsi_pool_run_host: pinned host depth + FASTA of the 3 Gb genome's chromosomes (as many as a third of the free host memory "
+                    "holds, longest first) -> results on the host; 12 workers, each chromosome's transfer on its worker's stream"}
+
+
+def fallback_envelope(lib, pool, dev):
+    """One 60 Mb chromosome alone through the pool under flags / coverage that leave the byte kernels: ms, bases/s, and the
+    per-base kernels' HIP-event times (one extra pass)."""
+    import torch
+    from rsicnv_amd import api, synth
+    out = {}
+    cases = (("30x default (-m 101 -NB): the byte path, for comparison", dict(mean=30.0), dict()),
+             ("-NOGC", dict(mean=30.0), dict(gcadjust=0)),
+             ("-m 201", dict(mean=30.0), dict(m=201)),
+             ("300x coverage", dict(mean=300.0), dict()))
+    for label, plan_kw, flag_kw in cases:
+        p = synth.make_plan(60_000_000, 0x5EED0E00, model=1, n_events=9, gaps=1, **plan_kw)
+        d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device=dev)
+        d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device=dev)
+        synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
+        torch.cuda.synchronize()
+        params = api.make_params(**flag_kw)
+        one = [(d_rd.data_ptr(), d_fa.data_ptr(), p["n"])]
+        pool.set_timing(0)
+        for _ in range(2):
+            pool.run(params, one)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            r = pool.run(params, one)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        saved = pool.times
+        pool.reset_times()
+        pool.set_timing(2)
+        pool.run(params, one, collect_times=True)
+        torch.cuda.synchronize()
+        kt = {k: round(v[0] * 1e3) for k, v in pool.kernel_table().items()}
+        pool.times = saved
+        pool.set_timing(0)
+        out[label] = {"ms": round(dt * 1e3, 3), "bases_per_s": round(p["n"] / dt, 1), "calls": len(r[0].calls("calls")), "per_base_kernel_us": kt}
+        del d_fa, d_rd
     return out
 
 

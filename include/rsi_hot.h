@@ -249,6 +249,23 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
                  const void* const* d_fasta, const int64_t* n, rsi_result** out, int* status,
                  rsi_batch_times* times);
 
+/* ---- Plot files (plotcnv.cpp:245-610; host only) ---------------------------------------------------------
+ * The gnuplot data (.dat) and script (.gp) file of one call as plot_icnv writes them.  rd: the capped, GC-adjusted per-base
+ * depth with the removed N regions back in as zeros (expand_data, loaddata.cpp:140; rsi_plot_expand builds it from
+ * rsi_hot_fetch_i32("rd_concat") and rsi_result_noncode); chrom_median: _median of that array (plot::RDmed).  The reference
+ * pipes the script through gnuplot and deletes both files; the writer stops at the files. */
+int rsi_plot_expand(const int32_t* rdc, int64_t ncompact, const int32_t* regions, int npairs, int32_t* out, int64_t n);
+int rsi_plot_write_files(const rsi_call* c, const char* title, const int32_t* rd, int64_t n, double chrom_median, int m,
+                         double minmlen, double chklen, const char* format, double gnuplot_version, const char* datfile,
+                         const char* gpfile, const char* imgfile);
+
+/* The same from host memory (load_data_from_text / load_data_from_bam leave the reference's RD in host memory, loaddata.cpp:473-539):
+ * every worker moves its chromosome over its own stream (pinned buffers: asynchronous DMA; pageable ones work, staged by
+ * the runtime), so the transfers of some chromosomes overlap the kernels of others.  PCIe-bound at 5 bytes per base. */
+int rsi_pool_run_host(rsi_pool* pool, const rsi_params* p, int nchrom, const int32_t* const* depth,
+                      const uint8_t* const* fasta, const int64_t* n, rsi_result** out, int* status,
+                      rsi_batch_times* times);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_l
            "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_summary_format_rows", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
-           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
+           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_pool_run_host", "rsi_plot_expand", "rsi_plot_write_files", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
 
 
 class RsiParams(C.Structure):
@@ -150,6 +150,8 @@ def load_library():
     L.rsi_pool_last_error.argtypes = [C.c_void_p]
     L.rsi_pool_last_error.restype = C.c_char_p
     L.rsi_pool_run.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(RsiBatchTimes)]
+    L.rsi_pool_run_host.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(RsiBatchTimes)]
     _lib = L
     return L
@@ -398,16 +400,17 @@ class RsiPool:
     def reset_times(self):
         self.times = RsiBatchTimes()
 
-    def run(self, params, chroms, collect_times=False):
-        """chroms: list of (d_depth_ptr, d_fasta_ptr, n).  Returns a list of Result in input order."""
+    def run(self, params, chroms, collect_times=False, host=False):
+        """chroms: list of (d_depth_ptr, d_fasta_ptr, n): device pointers, or with host=True host pointers (pinned for
+        asynchronous transfers).  Returns a list of Result in input order."""
         k = len(chroms)
         dp = (C.c_void_p * k)(*[C.c_void_p(c[0]) for c in chroms])
         fp = (C.c_void_p * k)(*[C.c_void_p(c[1]) for c in chroms])
         nn = (C.c_int64 * k)(*[c[2] for c in chroms])
         out = (C.c_void_p * k)()
         st = (C.c_int * k)()
-        rc = self.lib.rsi_pool_run(self.pool, C.byref(params), k, dp, fp, nn, out, st,
-                                   C.byref(self.times) if collect_times else None)
+        fn = self.lib.rsi_pool_run_host if host else self.lib.rsi_pool_run
+        rc = fn(self.pool, C.byref(params), k, dp, fp, nn, out, st, C.byref(self.times) if collect_times else None)
         if rc != RSI_OK:
             for i in range(k):
                 if out[i]:

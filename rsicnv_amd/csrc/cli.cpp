@@ -31,7 +31,7 @@ struct Options {
   int minq = 0, min_baseQ = 13, device = 0;
   int gpus = 0;      // -gpus N: chromosomes spread over N devices, several in flight per device (0: one context, one at a time)
   int workers = 4;   // -workers W: chromosomes in flight per device with -gpus
-  bool saverd = false, plot = true;
+  bool saverd = false, plot = true, plotfiles = false;
 };
 
 int usage() {
@@ -90,6 +90,7 @@ void parse(int argc, char** argv, Options& o) {
     else if (s == "-L") { need(i); ++i; }
     else if (s == "-p") { o.plotfolder = need(i); ++i; }
     else if (s == "-np") o.plot = false;
+    else if (s == "-plotfiles") o.plotfiles = true;
     else if (s == "-threshold") { o.P.threshold = atof(need(i).c_str()); ++i; }
     else if (s == "-e") { o.P.epsilon = atof(need(i).c_str()); ++i; }
     else if (s == "-cap") { o.P.cap = atof(need(i).c_str()); ++i; }
@@ -230,6 +231,43 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
   for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
     rsi_result_format_row(res, i, chr.c_str(), row, (int)sizeof(row));
     co.rows.push_back(row);
+  }
+  // ---- plots (rsi.cpp:2213-2216: expand_data, plot_cnv): the data / script files of every written call, piped through gnuplot
+  // and deleted, as the reference does -- and like the reference only when there is a gnuplot.  -plotfiles (not a reference
+  // flag) writes and keeps the files without one. ----
+  double gv = 0;
+  if (o.plot && rsi_result_ncalls(res, 0) > 0) {
+    if (FILE* pp = popen("gnuplot -V 2>/dev/null | cut -d' ' -f2", "r")) { char b[64] = {0}; if (fgets(b, sizeof(b), pp)) gv = atof(b); pclose(pp); }
+    if (gv <= 0 && !o.plotfiles) info << "gnuplot not found\n";
+  }
+  if (o.plot && rsi_result_ncalls(res, 0) > 0 && (gv > 0 || o.plotfiles)) {
+    const int64_t nc = S->n_compact, nfull = S->n;
+    std::vector<int32_t> rdc((size_t)nc), full((size_t)nfull), pairs((size_t)S->n_noncode * 2 + 2);
+    const int np = rsi_result_noncode(res, pairs.data(), S->n_noncode);
+    if (rsi_hot_fetch_i32(ctx, "rd_concat", rdc.data(), nc) == nc && rsi_plot_expand(rdc.data(), nc, pairs.data(), np, full.data(), nfull) == RSI_OK) {
+      (void)!system(("mkdir -p " + o.plotfolder).c_str());
+      // plot::RDmed = _median over the expanded array (plotcnv.cpp:625): zeros of the N regions included
+      std::vector<uint64_t> hist(65536, 0);
+      for (int32_t v : full) if (v >= 0 && v < 65536) ++hist[(size_t)v];
+      double med = 0;
+      { uint64_t seen = 0; const uint64_t r2 = (uint64_t)nfull / 2; for (size_t v = 0; v < hist.size(); ++v) { if (seen < r2 && seen + hist[v] >= r2) { med = (double)v; break; } seen += hist[v]; } }
+      if (gv <= 0) info << "plot data and scripts are left in " << o.plotfolder << "\n";
+      const rsi_call* calls = rsi_result_calls(res, 0);
+      static const char* kT[3] = {"DEL", "DUP", "UNKNOWN"};
+      for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
+        const rsi_call& c = calls[i];
+        std::ostringstream base, title;
+        base << o.plotfolder << "/rsi_" << chr << "_" << c.start << "_" << c.end << "_" << kT[c.type < 0 || c.type > 2 ? 2 : c.type];
+        title << chr << ":" << c.start << "-" << c.end << " " << c.end - c.start + 1 << " " << kT[c.type < 0 || c.type > 2 ? 2 : c.type];
+        const std::string dat = base.str() + ".dat", gp = base.str() + ".gp", img = base.str() + ".ps";
+        info << "plotting: " << title.str() << "\n";
+        if (rsi_plot_write_files(&c, title.str().c_str(), full.data(), nfull, med, o.P.m, o.P.minmlen, o.P.chklen, "ps", gv, dat.c_str(), gp.c_str(), img.c_str()) != RSI_OK) {
+          info << "CNV exceeds reference length\n";
+          continue;
+        }
+        if (gv > 0) { (void)!system(("gnuplot < " + gp).c_str()); remove(dat.c_str()); remove(gp.c_str()); }
+      }
+    } else info << "plots skipped: the per-base depth could not be fetched\n";
   }
   co.log = info.str();
   rsi_result_free(res);

@@ -242,9 +242,12 @@ struct ScanParams {
   double lim_del;    // 0.75 * RDmedian
   double lim_dup;    // 1.25 * RDmedian
 };
-// Longest scan the kernel's LDS tile holds: 256 bins + a halo of Lmax/2 + 1 each side must stay below 4096 staged bins (12-bit
-// staged indices) and 160 KB; the reference's Lmax is max(20, 10000/m, cal_max) (rsi.cpp:1830-1831): 3333 at -m 3.
-constexpr int kMaxScanL = 3800;
+// Longest scan: the reference's Lmax is max(20, 10000/m, cal_max) (rsi.cpp:1830-1831): 10000 at -m 1.  Up to kScanLdsL the exact
+// sweep's tile (256 bins + a halo of Lmax/2 + 1 each side, staged with its rank and mark tables) fits the 160 KB of LDS; longer
+// scans keep the same code on a tile in device memory (a workspace slice per workgroup): slow per tile, but the detection pass
+// in front sends only the tiles that can hit there.  Staged indices are 16 bits.
+constexpr int kMaxScanL = 10400;
+constexpr int kScanLdsL = 3800;
 constexpr int kScanPad = 8;   // thr_del / thr_dup carry this many unreachable entries (-inf / +inf) after index Lmax
 // thr_del[L], thr_dup[L] (L = 1..Lmax, index L): a window of length L is a DEL hit iff
 // sum <= thr_del[L], a DUP hit iff sum >= thr_dup[L] (host-derived, see scan_thresholds()).
@@ -260,12 +263,14 @@ struct ScanThr { double del[kThrInline]; double dup[kThrInline]; };
 // breaking the exact-sum precondition, [8] tiles listed, [9] the exact sweep's task counter.
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp, const double* thr_del,
                      const double* thr_dup, const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters,
-                     uint32_t* tiles, hipStream_t stream);
+                     uint32_t* tiles, void* tile_ws /* scan_tile_workspace_bytes(Lmax) when that is not 0 */, hipStream_t stream);
+size_t scan_tile_workspace_bytes(int Lmax);   // 0: the exact sweep's tile fits LDS
 // Stop levels of the two sweeps (rsi.cpp:1225, 1255; DEL marks win, App. A Q14) in one launch.
-// work: [16 uint32: escapes, inexact (the scan's), ldel, ldup, both-count, ...][hist_del kMaxLevels][hist_dup kMaxLevels], zero
+// work: [16 uint32: escapes, inexact (the scan's), ldel, ldup, both-count, ...][hist_del][hist_dup] (scan_level_stride(Lmax) words each), zero
 // before the scan; both: scratch for kBothCap (first_del, first_dup) pairs.  The last workgroup copies host_bytes of work to
 // host_copy (mapped host memory).
-constexpr int kMaxLevels = 4112;   // >= kMaxScanL + 1 + kScanPad, a multiple of 4
+constexpr int kMaxLevels = 10416;   // >= kMaxScanL + 1 + kScanPad, a multiple of 4
+inline int scan_level_stride(int Lmax) { return (Lmax + 1 + kScanPad + 3) & ~3; }   // hist_dup sits this many words behind hist_del
 constexpr size_t kScanWorkBytes = 64 + 2 * (size_t)kMaxLevels * 4;
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream);

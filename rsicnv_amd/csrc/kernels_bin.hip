@@ -398,10 +398,10 @@ __device__ inline void scan_mark(const ScanLds& S, int side, int lo, int hi, int
 // walk left the staged range.  Out of line: it is the rare case; it finds the tile's LDS through the
 // kernel's dynamic LDS symbol, so every access stays an LDS access.
 __device__ __noinline__ int scan_hit_slow(int count, int kcap, int w0, int L, int side, int vlo, int vhi, int ends,
-                                          uint32_t* counters) {
+                                          uint32_t* counters, double* gtile /* NULL: the tile is the kernel's dynamic LDS */) {
   extern __shared__ __align__(16) double sm[];
   ScanLds S;
-  scan_lds_carve(S, sm, count, kcap);
+  if (gtile) scan_lds_carve(S, gtile, count, kcap); else scan_lds_carve(S, sm, count, kcap);
   const int qm = side ? kCG : kCL, qt = side ? kCTu : kCTd;
   // the four trim walks in the reference's order (rsi.cpp:1211-1214 / 1241-1244), bounded to the chromosome
   int i1 = scan_next(S, qt, w0, vhi);
@@ -415,10 +415,10 @@ __device__ __noinline__ int scan_hit_slow(int count, int kcap, int w0, int L, in
     return -1;
   }
   if (i1 <= i2) scan_mark(S, side, i1, i2, L);
-  return i1 | (i2 << 12);
+  return i1 | (i2 << 16);
 }
 
-struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; };
+struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; double* gtile; };
 
 // One lane's walk over L = 1..Lmax in groups of kScanPad (8): the eight prefix values a group needs
 // are independent LDS reads issued together, the sixteen thresholds are wave-uniform (scalar)
@@ -509,8 +509,8 @@ __device__ inline void scan_hits_side(const ScanLds& S, const ScanTile& t, unsig
       }
       if (lo_m <= hi_m) scan_mark(S, SIDE, lo_m, hi_m, L);
     } else if (pass) {
-      const int r = scan_hit_slow(S.count, S.kcap, w0, L, SIDE, t.vlo, t.vhi, t.ends, counters);
-      if (r >= 0) { now.lastL = L; now.i1 = r & 0xfff; now.i2 = (r >> 12) & 0xfff; }
+      const int r = scan_hit_slow(S.count, S.kcap, w0, L, SIDE, t.vlo, t.vhi, t.ends, counters, t.gtile);
+      if (r >= 0) { now.lastL = L; now.i1 = r & 0xffff; now.i2 = (r >> 16) & 0x7fff; }
     }
     run = now;
   }
@@ -695,21 +695,26 @@ __global__ __launch_bounds__(kThreads) void k_scan_detect(const float* __restric
 // groups of kScanPad lengths -- the chain of hits a lane inside an event walks through is cut in `parts`, the tile's marks are
 // atomicMin whoever makes them.  Workgroups pull tasks from a counter (counters[9]) until it runs past the list; tiles ==
 // NULL: every tile of the chromosome is a task list of its own (no detection pass in front).
-template <bool INL>
+// GTILE: the tile lives in device memory (gws + blockIdx.x * gbytes) instead of LDS -- scans longer than kScanLdsL.  Same code;
+// the waves of a workgroup share a CU and its L1, so what one wave stored is what another loads once every wave's stores are
+// done (drain) and the workgroup has met at the barrier.
+template <bool INL, bool GTILE>
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
                                                        ScanParams sp, const double* __restrict__ thr_del_mem,
                                                        const double* __restrict__ thr_dup_mem,
                                                        uint32_t* __restrict__ first_del, uint32_t* __restrict__ first_dup,
                                                        uint32_t* __restrict__ counters, const uint32_t* __restrict__ tiles, int parts,
-                                                       ScanThr inl) {
+                                                       ScanThr inl, unsigned char* __restrict__ gws, unsigned long long gbytes) {
   extern __shared__ __align__(16) double sm[];
   const double* __restrict__ thr_del = INL ? inl.del : thr_del_mem;
   const double* __restrict__ thr_dup = INL ? inl.dup : thr_dup_mem;
   const int Lmax = sp.Lmax, kcap = sp.kcap;
   const int halo = Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;          // staged bins
+  auto tile_sync = [&]() { if (GTILE) drain(); __syncthreads(); };
   ScanLds S;
-  scan_lds_carve(S, sm, count, kcap);
+  double* const gtile = GTILE ? reinterpret_cast<double*>(gws + (size_t)blockIdx.x * gbytes) : nullptr;
+  if (GTILE) scan_lds_carve(S, gtile, count, kcap); else scan_lds_carve(S, sm, count, kcap);
   __shared__ int s_c[4][kThreads];
   __shared__ unsigned int s_task;
   // integer forms of the median limits: x > lim_del <=> x > fl_del ; x < lim_dup <=> x < ce_dup
@@ -719,9 +724,9 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   const unsigned int ntiles = tiles ? counters[8] : (unsigned int)((sp.nb + kScanTile - 1) / kScanTile);
   const unsigned int ntasks = ntiles * (unsigned int)parts;
   for (;;) {
-    __syncthreads();   // the previous task's LDS is no longer read
+    tile_sync();   // the previous task's LDS is no longer read
     if (threadIdx.x == 0) s_task = atomicAdd(&counters[9], 1u);
-    __syncthreads();
+    tile_sync();
     const unsigned int task = s_task;
     if (task >= ntasks) break;   // every wave reaches this: the grid drains
     const unsigned int tslot = task / (unsigned int)parts;
@@ -764,7 +769,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) s_c[q][threadIdx.x] = rc[q];
     if (threadIdx.x == 0) { S.P[0] = 0.0; for (int q = 0; q < 4; ++q) S.C(q, 0) = 0; }
-    __syncthreads();
+    tile_sync();
     if (threadIdx.x < 64) {   // wave 0 turns the 256 totals into exclusive offsets
       double carry = 0.0;
       int car[4] = {0, 0, 0, 0};
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
         for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += __shfl(i4[q], 63); }
       }
     }
-    __syncthreads();
+    tile_sync();
     {
       const double off = S.tot[threadIdx.x];
       int o4[4];
@@ -814,13 +819,14 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
     }
     for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
     if (lane_id() == 0 && inexact) atomicAdd(&counters[1], inexact);
-    __syncthreads();
+    tile_sync();
 
     // ---- every (bin, L) of the tile within this task's lengths.  Going from L-1 to L the window gains one bin -- on the left for
     // even L, on the right for odd L -- so one prefix value per step is new.  ----
     ScanTile tile;
     tile.vlo = vlo; tile.vhi = vhi; tile.fl_del = fl_del; tile.ce_dup = ce_dup;
     tile.lim_del = sp.lim_del; tile.lim_dup = sp.lim_dup; tile.ends = (at_start ? 1 : 0) | (at_end ? 2 : 0);
+    tile.gtile = gtile;
     const bool edge_tile = at_start || at_end;   // only there can a lane's L range be cut short
     static_assert(kScanTile == kThreads, "one bin per lane");
     {
@@ -834,7 +840,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
       if (edge_tile) scan_sweep<true>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
       else scan_sweep<false>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
     }
-    __syncthreads();
+    tile_sync();
     // ---- push the block levels down to single bins ----
     for (int k = kcap; k >= 1; --k) {
       const int half = 1 << (k - 1);
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
         if (d != kUnmarked) { atomicMin(&ld[e], d); atomicMin(&ld[e + half], d); }
         if (u != kUnmarked) { atomicMin(&lu[e], u); atomicMin(&lu[e + half], u); }
       }
-      __syncthreads();
+      tile_sync();
     }
     // ---- merge the tile's marks into HBM (halo bins are shared with the neighbouring tiles and with the tile's other parts) ----
     for (int e = vlo + threadIdx.x; e < vhi; e += kThreads) {
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
 // listed bins the DEL sweep really marked out of the DUP histogram (or, if the list overflowed, recounts them itself),
 // walks that one, and leaves the levels, the per-L counts (what the reference logs per L, rsi.cpp:1221-1224, 1251-1254)
 // and the pass counters in `work`, a copy of which goes to mapped host memory.
-// work: [ScanPassHead (64 bytes)] [hist_del: kMaxLevels uint32] [hist_dup: kMaxLevels uint32]
+// work: [ScanPassHead (64 bytes)] [hist_del] [hist_dup], scan_level_stride(Lmax) words each
 constexpr int kBothCap = 16384;
 __device__ inline uint32_t stop_level_walk(const unsigned int* s_l, int32_t Lmax, int64_t nb) {
   unsigned long long cum = 0;
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   unsigned int* s_u = s_l + (Lmax + 1);
   uint32_t* head = work;                  // [0] escapes [1] inexact (the scan) [2] ldel [3] ldup [4] both-count [5] last run start + 1
   uint32_t* hist_d = work + 16;
-  uint32_t* hist_u = hist_d + kMaxLevels;
+  uint32_t* hist_u = hist_d + ((Lmax + 1 + kScanPad + 3) & ~3);   // scan_level_stride(Lmax)
   for (int e = threadIdx.x; e < 2 * (Lmax + 1); e += kThreads) s_l[e] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
@@ -1151,17 +1157,32 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
   if (pack16) RSI_LAUNCH(k_hist_walk<true>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
   else { RSI_ALLOW_FULL_LDS(k_hist_walk<false>); RSI_LAUNCH(k_hist_walk<false>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins); }
 }
+constexpr int kGTileGrid = 256;   // workgroups of the device-memory-tile form (one workspace slice each)
+static void scan_tile_shape(int Lmax, int& count, int& kcap, bool& gtile) {
+  const int halo = Lmax / 2 + 1;
+  count = kScanTile + 2 * halo;
+  // block-level cap: floor(log2(Lmax)), at most 6
+  kcap = 0;
+  while ((2 << kcap) <= Lmax && kcap < 6) ++kcap;
+  gtile = Lmax > kScanLdsL;
+  // in LDS: lowered until the tile fits
+  if (!gtile) while (kcap > 0 && scan_lds_bytes(count, kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --kcap;
+}
+size_t scan_tile_workspace_bytes(int Lmax) {
+  int count, kcap; bool gtile;
+  scan_tile_shape(Lmax, count, kcap, gtile);
+  return gtile ? (size_t)kGTileGrid * ((scan_lds_bytes(count, kcap) + 255) & ~size_t(255)) : 0;
+}
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
-                     const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, uint32_t* tiles, hipStream_t stream) {
+                     const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, uint32_t* tiles, void* tile_ws,
+                     hipStream_t stream) {
   ScanParams sp = sp_in;
-  const int halo = sp.Lmax / 2 + 1;
-  const int count = kScanTile + 2 * halo;
-  // block-level cap: floor(log2(Lmax)), at most 6, lowered until the tile fits in LDS
-  int kcap = 0;
-  while ((2 << kcap) <= sp.Lmax && kcap < 6) ++kcap;
-  while (kcap > 0 && scan_lds_bytes(count, kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --kcap;
+  int count, kcap; bool gtile;
+  scan_tile_shape(sp.Lmax, count, kcap, gtile);
   sp.kcap = kcap;
-  const size_t lds = scan_lds_bytes(count, kcap);
+  const size_t tile_bytes = scan_lds_bytes(count, kcap);
+  const size_t lds = gtile ? 0 : tile_bytes;
+  const unsigned long long gbytes = (tile_bytes + 255) & ~size_t(255);
   const int64_t ntiles = (sp.nb + kScanTile - 1) / kScanTile;
   static const ScanThr none{};
   // RSI_HOT_SCAN_DETECT=0: no detection pass, every tile through the exact sweep in one piece (A/B runs; same marks)
@@ -1180,14 +1201,20 @@ void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp
   }
   // workgroups pull (tile, share) tasks from a counter: as many as can be resident, never more than there can be tasks
   int64_t grid = ntiles * parts;
-  const int64_t resident = 256 * (int64_t)(lds > 80 * 1024 ? 1 : lds > 52 * 1024 ? 2 : lds > 39 * 1024 ? 3 : 4);
-  if (detect && grid > resident) grid = resident;
+  const int64_t resident = gtile ? kGTileGrid : 256 * (int64_t)(lds > 80 * 1024 ? 1 : lds > 52 * 1024 ? 2 : lds > 39 * 1024 ? 3 : 4);
+  if ((detect || gtile) && grid > resident) grid = resident;
   const uint32_t* list = detect ? tiles : nullptr;
-  if (inl) { RSI_ALLOW_FULL_LDS(k_rsi_scan<true>); RSI_LAUNCH(k_rsi_scan<true>, dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, nullptr, nullptr, first_del, first_dup, counters, list, parts, *inl); }
-  else { RSI_ALLOW_FULL_LDS(k_rsi_scan<false>); RSI_LAUNCH(k_rsi_scan<false>, dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, thr_del, thr_dup, first_del, first_dup, counters, list, parts, none); }
+  unsigned char* gws = static_cast<unsigned char*>(tile_ws);
+#define RSI_SCAN(INL_, GT_, ...) do { RSI_ALLOW_FULL_LDS((k_rsi_scan<INL_, GT_>));                                                     \
+    RSI_LAUNCH((k_rsi_scan<INL_, GT_>), dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, __VA_ARGS__, first_del, first_dup, \
+               counters, list, parts, inl ? *inl : none, gws, gbytes); } while (0)
+  if (gtile) { if (inl) RSI_SCAN(true, true, nullptr, nullptr); else RSI_SCAN(false, true, thr_del, thr_dup); }
+  else { if (inl) RSI_SCAN(true, false, nullptr, nullptr); else RSI_SCAN(false, false, thr_del, thr_dup); }
+#undef RSI_SCAN
 }
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream) {
+  RSI_ALLOW_FULL_LDS(k_level_stop);   // (Lmax + 1) * 8 bytes: 80 KB at -m 1
   RSI_LAUNCH(k_level_stop, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 8, stream, first_del, first_dup, nb,
                      Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
 }

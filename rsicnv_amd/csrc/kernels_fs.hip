@@ -390,6 +390,7 @@ void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lm
   float* clist_t = reinterpret_cast<float*>(p);
   RSI_LAUNCH(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
   RSI_LAUNCH(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
+  RSI_ALLOW_FULL_LDS(k_fs_chunk_fns);   // (2 Lmax + 1) * 4 bytes: 80 KB at -m 1
   RSI_LAUNCH(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), (size_t)(2 * Lmax + 1) * 4, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap, Lmax, level_count);
   RSI_LAUNCH(k_fs_level_sums, dim3((2 * Lmax + 1 + kThreads / 64 - 1) / (kThreads / 64) + 1), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, level_count,
                      clist_cap, Lmax, out, counter, host_copy);

@@ -462,14 +462,15 @@ int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint,
   uint32_t* d_first_dup = d_first_del + ((nb + 3) & ~int64_t(3));
   unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone) + 3 * kDoneStride;
   uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
-  const size_t work_bytes = 64 + ((size_t)kMaxLevels + (size_t)Lmax + 1) * 4;
+  const size_t work_bytes = 64 + ((size_t)scan_level_stride(Lmax) + (size_t)Lmax + 1) * 4;
+  if (scan_tile_workspace_bytes(Lmax)) HIPCHK(ctx->scan_ws.ensure(scan_tile_workspace_bytes(Lmax)));   // scans too long for an LDS tile
   uint32_t* wslot = static_cast<uint32_t*>(mb_alloc(ctx, work_bytes));
   uint32_t* rslot = static_cast<uint32_t*>(mb_alloc(ctx, 8 + (size_t)kEagerBounds * 8));
   if (!wslot || !rslot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
   ScanParams sp;
   sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
   sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
-  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->scan_tiles.as<uint32_t>(), ctx->stream); }
+  { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->scan_tiles.as<uint32_t>(), ctx->scan_ws.p, ctx->stream); }
   { Timer t(ctx, "level_stop"); launch_level_stop(d_first_del, d_first_dup, nb, Lmax, work, ctx->runs.p, d_done + 2, wslot, work_bytes, ctx->stream); }
   { Timer t(ctx, "resolve_runs"); launch_resolve_runs(d_first_del, d_first_dup, work + 2, nb, d_status, d_copy, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, d_done + 3, rslot, kEagerBounds, ctx->stream); }
   *work_slot = wslot; *runs_slot = rslot;
@@ -536,7 +537,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   int Lmax = LmaxBase;
   if (Lmax < cal_max) Lmax = cal_max;
-  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond the LDS tile limit (3800: bins of 3 bases and more)");
+  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond 10400 (the reference's own ceiling without a larger computed length is 10000, at -m 1)");
   if (Lmax > nb) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length (the reference exits in runmean)");
   out.tmedian1 = tmedian; out.tsigma1 = tsigma; out.tlamda1 = tlamda; out.Lmax = Lmax;
 
@@ -563,7 +564,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
   out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[0].assign(wslot + 16, wslot + 16 + Lmax + 1);
-  out.level_log[1].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
+  out.level_log[1].assign(wslot + 16 + scan_level_stride(Lmax), wslot + 16 + scan_level_stride(Lmax) + Lmax + 1);
   out.stop_levels[0] = wslot[2]; out.stop_levels[1] = wslot[3];
   {
     Phase phs(ctx, "fs.sums");
@@ -661,7 +662,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
   out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
-  out.level_log[3].assign(wslot + 16 + kMaxLevels, wslot + 16 + kMaxLevels + Lmax + 1);
+  out.level_log[3].assign(wslot + 16 + scan_level_stride(Lmax), wslot + 16 + scan_level_stride(Lmax) + Lmax + 1);
   out.stop_levels[2] = wslot[2]; out.stop_levels[3] = wslot[3];
   out.status2 = rsih::IntSpan();
   out.segs.clear();

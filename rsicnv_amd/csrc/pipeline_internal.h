@@ -141,6 +141,7 @@ struct rsi_ctx {
   DevBuf sharpen_ws;          // workspace of k_sharpen_edges, cleared when (re)allocated
   DevBuf fs_ws, fs_out;       // filterstatus' level sums on the device (kernels_fs.hip)
   DevBuf scan_tiles;          // tiles the scan's detection pass lists for the exact sweep
+  DevBuf scan_ws;             // the exact sweep's tiles in device memory, for scans too long for LDS (scan_tile_workspace_bytes)
   DevBuf joint_tot;           // K2j's folded joint histogram [GC count][depth byte] + escapes
   // K4j queued behind K2j without a host round trip needs its launch configuration before the cap is known: the cap of the
   // context's previous chromosome under the same flags (one sample: one depth), checked on the device and again by the host

@@ -118,8 +118,8 @@ const char* rsi_pool_last_error(const rsi_pool* pool) {
   return copy.c_str();
 }
 
-int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
-                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+static int pool_run_impl(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                         const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times, bool host_inputs) {
   if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
   std::vector<int> order((size_t)nchrom);
   for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
@@ -151,7 +151,10 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
       const int i = order[(size_t)k];
       out[i] = nullptr;
       const double t_a = now_ms();
-      rcs[(size_t)i] = rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
+      // host inputs: the worker's own stream carries its chromosome's transfer (pinned memory: a plain DMA), so the transfers of
+      // some chromosomes run beside the kernels of others -- H2D double-buffered against compute across the pool's workers
+      rcs[(size_t)i] = host_inputs ? rsi_hot_run(ctx, p, static_cast<const int32_t*>(d_depth[i]), static_cast<const uint8_t*>(d_fasta[i]), n[i], &out[i])
+                                   : rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
       if (trace) {
         std::lock_guard<std::mutex> lk(trace_mu);
         fprintf(stderr, "[trace] worker %zu chrom %d n %lld start %.2f end %.2f :", w, i, (long long)n[i], t_a - t_run0, now_ms() - t_run0);
@@ -190,6 +193,15 @@ int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* co
     }
   }
   return worst;
+}
+
+int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+  return pool_run_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false);
+}
+int rsi_pool_run_host(rsi_pool* pool, const rsi_params* p, int nchrom, const int32_t* const* depth, const uint8_t* const* fasta,
+                      const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+  return pool_run_impl(pool, p, nchrom, reinterpret_cast<const void* const*>(depth), reinterpret_cast<const void* const*>(fasta), n, out, status, times, true);
 }
 
 }  // extern "C"

@@ -117,6 +117,31 @@ def test_cli_output_file_matches_reference_binary(hotlib, tmp_path, extra):
         assert len(nbl) == 2 and all(l in ref for l in nbl), nbl
 
 
+def test_cli_plot_files(hotlib, tmp_path):
+    """-p FOLDER -plotfiles: one data file and one gnuplot script per written call (plotcnv.cpp:613-672), each with the
+    eleven data blocks plot_icnv writes, the call's block holding the capped, GC-adjusted depth at its positions."""
+    _, fasta, depth = make_case(hotlib, dict(n=400_007, seed=0xC12, model=1, n_events=5, gaps=1, max_len=20000, end_n=5000, gap_len=8000))
+    fa, rd = _write_case(str(tmp_path), fasta, depth)
+    out, folder = str(tmp_path / "out.txt"), str(tmp_path / "plots")
+    exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+    subprocess.run([exe, "rsi", "-f", fa, "-d", rd, "-c", "chrS", "-o", out, "-p", folder, "-plotfiles"], check=True, capture_output=True, timeout=300)
+    rows = [l.split("\t") for l in open(out).read().splitlines() if not l.startswith("#")]
+    assert len(rows) >= 3
+    import shutil
+    if shutil.which("gnuplot"):
+        pytest.skip("gnuplot present: the files are piped through it and deleted, as in the reference")
+    for r in rows:
+        base = os.path.join(folder, f"rsi_chrS_{r[1]}_{r[2]}_{r[3]}")
+        blocks = open(base + ".dat").read().split("\n\n\n")
+        assert len(blocks) >= 11 and blocks[0].startswith(f"#{r[1]} ~ {r[2]}  {r[5]}  {r[3]}")
+        body = [l.split("\t") for l in blocks[1].strip().split("\n")]
+        # positions from START on, thinned to at most 30 000 points over the whole figure (plotcnv.cpp:382)
+        assert int(body[0][0]) == int(r[1]) and int(r[2]) - 2 * max(1, 6 * int(r[5]) // 30000 + 1) <= int(body[-1][0]) <= int(r[2])
+        assert all(x[2] == "NaN" for x in body)
+        script = open(base + ".gp").read()
+        assert f"chrS:{r[1]}-{r[2]} {r[5]} {r[3]}" in script and script.rstrip().endswith("quit")
+
+
 def test_error_behaviour(hot, hotlib):
     from rsicnv_amd import api
     _, fasta, depth = make_case(hotlib, dict(n=300_000, seed=0xE44, model=0, n_events=3, gaps=0, max_len=9000, end_n=0))
@@ -380,10 +405,11 @@ def test_bin_size_extremes(hot, hotlib, oracle_cls):
     assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
     ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
     assert ok, why
-    # -m 3 (Lmax 3333) runs since the scan tile holds 3800 (golden case wide_m3_nb); -m 1 would need Lmax = 10000
+    # -m 3 (Lmax 3333) fits the scan's LDS tile (golden case wide_m3_nb); -m 1 (Lmax 10000) runs on tiles in device memory
+    # (golden case wide_m1_nb); a chromosome with fewer bins than the scan is long is refused as the reference refuses it
     with pytest.raises(api.RsiError) as e:
-        hot.run(api.make_params(m=1), depth[:200_000], fasta[:200_000])
-    assert e.value.code == -5 and "3800" in str(e.value)
+        hot.run(api.make_params(m=1), depth[:9_000], fasta[:9_000])
+    assert e.value.code != 0
 
 
 def test_many_n_runs(hot, hotlib, oracle_cls):
