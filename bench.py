@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
     ap.add_argument("--workers", type=int, default=12, help="host threads / HIP streams per GPU (chromosomes in flight)")
+    ap.add_argument("--inflight", type=int, default=2, help="steps (genomes) queued in the pool at once: 2 = the next genome's first chromosomes "
+                    "run beside the last ones of the current genome (rsi_pool_submit); 1 = one genome at a time")
     args = ap.parse_args()
 
     import numpy as np
@@ -183,14 +185,17 @@ def main():
     id_offset = 0 if sharded else rank * len(plans)   # weak-scaling mode: every rank's sample keeps its own ids
 
     # A step = the pool's pass over this rank's chromosomes, then `finish_step` (pack, gather, rank 0's rows in order, hash).
-    # finish_step of step k runs on a second host thread while the pool is already on step k + 1: the GPU never waits for
-    # Python, every step's rows are still produced (and hashed) inside the timed region -- `drain()` joins the thread before a
-    # timer is read.  One thread, one queue: the collectives stay in step order on every rank.
+    # A step is SUBMITTED to the pool (rsi_pool_submit) and waited for on a second host thread, which then runs finish_step:
+    # up to --inflight steps are queued in the pool at once, so the first chromosomes of genome k + 1 run beside the last ones
+    # of genome k (samples back to back, the way a sequencing centre runs them), and the GPU never waits for Python.  Every
+    # step's rows are still produced (and hashed) inside the timed region -- `drain()` joins the thread before a timer is read.
+    # One thread, one queue: the collectives stay in step order on every rank.
     import queue
     import threading
-    post_q = queue.Queue(maxsize=2)
+    post_q = queue.Queue()
     post_err = []
     last_rows = [0]
+    slots = threading.Semaphore(max(1, args.inflight))
 
     def post_worker():
         while True:
@@ -198,11 +203,14 @@ def main():
             try:
                 if item is None:
                     return
+                handle, timed = item
+                results = pool.wait(handle) if handle is not None else []
                 if not post_err:
-                    last_rows[0] = finish_step(*item)
+                    last_rows[0] = finish_step(results, timed)
             except Exception as e:   # surfaces at the next drain()
                 post_err.append(e)
             finally:
+                slots.release()
                 post_q.task_done()
 
     post_thread = threading.Thread(target=post_worker, daemon=True)
@@ -216,8 +224,9 @@ def main():
 
     def step(timed=False):
         """One genome: this rank's chromosomes through the pool; the rest of the step is queued for the second thread."""
-        results = pool.run(params, chrom_args, collect_times=timed) if chrom_args else []
-        post_q.put((results, timed))
+        slots.acquire()   # at most --inflight steps between submission and their rows
+        handle = pool.submit(params, chrom_args, collect_times=timed) if chrom_args else None
+        post_q.put((handle, timed))
 
     def finish_step(results, timed):
         """The gather, rank 0's rows in chromosome order."""
@@ -393,7 +402,7 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload_name(args), "chromosomes": len(plans), "genome_bases": genome_bases,
                        "bases_on_rank0": my_bases, "flags": flag_string(flags), "calls_per_genome": ncalls, "shard": args.shard,
-                       "parallelism": par},
+                       "parallelism": par, "steps_in_flight": max(1, args.inflight)},
             "roofline": roofline, "cpu_baseline": cpu,
             "steps_identical": steps_identical, "rows_sha256": step_hashes[0] if step_hashes else None,
             "kernel_ms_all_launches_extra_pass": kernel_ms_all,
@@ -625,8 +634,13 @@ def config5_side_pass(lib, pool, dev, args, steps=6, warmup=2):
         pool.run(params, chrom_args)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        res = pool.run(params, chrom_args)
+    pending = []
+    for _ in range(steps):   # as the main line: at most --inflight genomes queued in the pool
+        pending.append(pool.submit(params, chrom_args))
+        if len(pending) >= max(1, args.inflight):
+            res = pool.wait(pending.pop(0))
+    while pending:
+        res = pool.wait(pending.pop(0))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ncalls = sum(len(r.calls("calls")) for r in res)

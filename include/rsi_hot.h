@@ -214,9 +214,9 @@ void rsi_hot_set_timing_kernel(rsi_ctx* ctx, const char* name);
 
 /* ---- Pool: several chromosomes in flight on one GPU ------------------------------------------
  * The reference's per-chromosome loop (rsi.cpp:2189-2217) has independent iterations.  A pool owns
- * `nworkers` host threads (created with the pool, asleep between runs; worker 0 is the calling thread), each with its
- * own context (stream + workspace); rsi_pool_run hands the chromosomes out longest first (the first `nworkers` to fixed
- * workers).  One rsi_pool_run at a time per pool; several pools (one per GPU, or per host thread) are independent.  At most two HBM-bound
+ * `nworkers` host threads (created with the pool, asleep while no run is queued; worker 0 is a thread waiting for a run),
+ * each with its own context (stream + workspace); the chromosomes of a run are handed out longest first.  Runs may be queued
+ * (rsi_pool_submit / rsi_pool_wait below) and are worked on in submission order; several pools (one per GPU) are independent.  At most two HBM-bound
  * per-base phases are in flight per GPU (rsi_pool_set_schedule); bin-level and candidate kernels,
  * copies and the host stages of different chromosomes overlap. */
 typedef struct rsi_pool rsi_pool;
@@ -265,6 +265,19 @@ int rsi_plot_write_files(const rsi_call* c, const char* title, const int32_t* rd
 int rsi_pool_run_host(rsi_pool* pool, const rsi_params* p, int nchrom, const int32_t* const* depth,
                       const uint8_t* const* fasta, const int64_t* n, rsi_result** out, int* status,
                       rsi_batch_times* times);
+
+/* Samples back to back (the reference is started once per sample; a sequencing centre runs them one after the other): queue a
+ * run and return at once.  The pool's workers take chromosomes in submission order, so a worker that finds no chromosome left
+ * in one run starts on the next -- the last, short chromosomes of one sample run beside the first, long ones of the next
+ * instead of leaving most of the GPU idle.  The pointer arrays are copied; `out`, `status`, `times` and the data they point
+ * to must stay valid until rsi_pool_wait has returned for the ticket.  Returns 0 for bad arguments.  rsi_pool_wait returns
+ * the run's worst status; the calling thread works as one of the pool's workers while it waits (on the runs up to its own).
+ * rsi_pool_run is submit + wait; any number of threads may call the three.  Every ticket must be waited for before
+ * rsi_pool_destroy. */
+uint64_t rsi_pool_submit(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth,
+                         const void* const* d_fasta, const int64_t* n, rsi_result** out, int* status,
+                         rsi_batch_times* times);
+int rsi_pool_wait(rsi_pool* pool, uint64_t ticket);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_l
            "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_summary_format_rows", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
-           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_pool_run_host", "rsi_plot_expand", "rsi_plot_write_files", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
+           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_pool_run_host", "rsi_pool_submit", "rsi_pool_wait", "rsi_plot_expand", "rsi_plot_write_files", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
 
 
 class RsiParams(C.Structure):
@@ -153,6 +153,9 @@ def load_library():
                                C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(RsiBatchTimes)]
     L.rsi_pool_run_host.argtypes = [C.c_void_p, C.POINTER(RsiParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(RsiBatchTimes)]
+    L.rsi_pool_submit.argtypes = L.rsi_pool_run.argtypes
+    L.rsi_pool_submit.restype = C.c_uint64
+    L.rsi_pool_wait.argtypes = [C.c_void_p, C.c_uint64]
     _lib = L
     return L
 
@@ -411,6 +414,30 @@ class RsiPool:
         st = (C.c_int * k)()
         fn = self.lib.rsi_pool_run_host if host else self.lib.rsi_pool_run
         rc = fn(self.pool, C.byref(params), k, dp, fp, nn, out, st, C.byref(self.times) if collect_times else None)
+        if rc != RSI_OK:
+            for i in range(k):
+                if out[i]:
+                    self.lib.rsi_result_free(out[i])
+            raise RsiError(rc, self.lib.rsi_pool_last_error(self.pool).decode())
+        return [Result(self.lib, C.c_void_p(out[i])) for i in range(k)]
+
+    def submit(self, params, chroms, collect_times=False):
+        """Queue a run (rsi_pool_submit) and return a handle for wait(): the chromosomes of queued runs go to the workers in
+        submission order, so consecutive samples overlap.  chroms as for run() (device pointers)."""
+        k = len(chroms)
+        h = {"k": k, "params": params,
+             "dp": (C.c_void_p * k)(*[C.c_void_p(c[0]) for c in chroms]), "fp": (C.c_void_p * k)(*[C.c_void_p(c[1]) for c in chroms]),
+             "nn": (C.c_int64 * k)(*[c[2] for c in chroms]), "out": (C.c_void_p * k)(), "st": (C.c_int * k)()}
+        h["ticket"] = self.lib.rsi_pool_submit(self.pool, C.byref(params), k, h["dp"], h["fp"], h["nn"], h["out"], h["st"],
+                                               C.byref(self.times) if collect_times else None)
+        if not h["ticket"]:
+            raise RsiError(-2, "rsi_pool_submit: bad arguments")
+        return h
+
+    def wait(self, h):
+        """The results of a submitted run, in input order (the calling thread works as one of the pool's workers meanwhile)."""
+        rc = self.lib.rsi_pool_wait(self.pool, h["ticket"])
+        k, out = h["k"], h["out"]
         if rc != RSI_OK:
             for i in range(k):
                 if out[i]:

@@ -1,9 +1,11 @@
 // pool.hip -- several chromosomes at once on one GPU (the reference's loop over chromosomes, rsi.cpp:2189-2217, whose
-// iterations are independent): `nworkers` host threads, each with its own context (stream + workspace), and the gate
-// that lets at most two per-base phases stream at a time.
+// iterations are independent): `nworkers` host threads, each with its own context (stream + workspace), the gate that
+// lets at most two per-base phases stream at a time, and a queue of runs (samples) whose chromosomes the workers take in
+// submission order.
 #include "pipeline_internal.h"
 #include <condition_variable>
-#include <functional>
+#include <deque>
+#include <memory>
 #include <thread>
 
 using namespace rsik;
@@ -17,50 +19,121 @@ extern "C" {
 // hands them out longest first.
 constexpr int kFewChromosomes = 4;   // up to here a run's candidate tests use the multi-workgroup form
 
+// One call's worth of chromosomes.  Runs queue up in submission order; a worker takes the next unclaimed chromosome of the
+// oldest run that has one, so a worker that finds nothing left in one run starts on the next: consecutive samples overlap, and
+// the last chromosomes of a run do not leave eleven workers idle.
+struct PoolRun {
+  uint64_t id = 0;
+  rsi_params params;
+  int nchrom = 0;
+  std::vector<const void*> depth, fasta;
+  std::vector<int64_t> n;
+  rsi_result** out = nullptr;
+  int* status = nullptr;
+  rsi_batch_times* times = nullptr;
+  bool host_inputs = false;
+  std::vector<int> order, rcs;
+  int claimed = 0, completed = 0;   // under the pool's mutex
+  bool done = false;
+  int worst = RSI_OK;
+  double t0 = 0;
+  std::vector<std::vector<std::pair<const char*, float>>> ktimes;
+  std::vector<std::vector<std::pair<const char*, double>>> ptimes;
+  std::vector<std::vector<int64_t>> kbases;
+};
+
 struct rsi_pool {
   int device = 0;
   std::vector<rsi_ctx*> workers;
   GpuGate gate;
   std::string err;
-  // Workers 1 .. W-1 are threads that live as long as the pool and sleep between runs (worker 0 is the caller's thread):
-  // starting eleven threads per run took 0.3 ms before the last chromosome of the first wave was under way.
+  // Workers 1 .. W-1 are threads that live as long as the pool and sleep while no run is queued; worker 0's context is used by
+  // whichever caller is waiting for a run (rsi_pool_run, rsi_pool_wait): starting eleven threads per run took 0.3 ms before
+  // the last chromosome of the first wave was under way.
   std::vector<std::thread> threads;
   std::mutex jm;
   std::condition_variable jcv, dcv;
-  const std::function<void(size_t)>* job = nullptr;
-  uint64_t generation = 0;
-  int pending = 0;
+  std::deque<std::shared_ptr<PoolRun>> active;                 // runs with unfinished chromosomes, oldest first
+  std::vector<std::shared_ptr<PoolRun>> unwaited;              // submitted, rsi_pool_wait not yet returned
+  uint64_t next_id = 1;
   bool quit = false;
-  void worker_loop(size_t w) {
-    uint64_t seen = 0;
-    for (;;) {
-      const std::function<void(size_t)>* f;
-      {
-        std::unique_lock<std::mutex> lk(jm);
-        jcv.wait(lk, [&] { return quit || generation != seen; });
-        if (quit) return;
-        seen = generation;
-        f = job;
-      }
-      (*f)(w);
-      {
-        std::lock_guard<std::mutex> lk(jm);
-        if (--pending == 0) dcv.notify_one();
-      }
+  std::mutex w0m;                                              // worker 0's context: one waiting caller at a time
+  std::mutex trace_mu;
+
+  // under jm: the next chromosome to work on, from the oldest run that has one (no younger than `upto`, 0 = any)
+  bool claim(std::shared_ptr<PoolRun>& r, int& k, uint64_t upto) {
+    for (auto& a : active) {
+      if (upto && a->id > upto) break;
+      if (a->claimed < a->nchrom) { r = a; k = a->claimed++; return true; }
+    }
+    return false;
+  }
+  void process(size_t w, PoolRun& R, int k) {
+    static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
+    rsi_ctx* ctx = workers[w];
+    const int i = R.order[(size_t)k];
+    R.out[i] = nullptr;
+    const double t_a = now_ms();
+    // host inputs: the worker's own stream carries its chromosome's transfer (pinned memory: a plain DMA), so the transfers of
+    // some chromosomes run beside the kernels of others -- H2D double-buffered against compute across the pool's workers
+    R.rcs[(size_t)i] = R.host_inputs ? rsi_hot_run(ctx, &R.params, static_cast<const int32_t*>(R.depth[(size_t)i]), static_cast<const uint8_t*>(R.fasta[(size_t)i]), R.n[(size_t)i], &R.out[i])
+                                     : rsi_hot_run_device(ctx, &R.params, R.depth[(size_t)i], R.fasta[(size_t)i], R.n[(size_t)i], &R.out[i]);
+    if (trace) {
+      std::lock_guard<std::mutex> lk(trace_mu);
+      fprintf(stderr, "[trace] run %llu worker %zu chrom %d n %lld start %.2f end %.2f :", (unsigned long long)R.id, w, i, (long long)R.n[(size_t)i], t_a - R.t0, now_ms() - R.t0);
+      for (const auto& ph : ctx->phases) fprintf(stderr, " %s=%.2f", ph.first, ph.second);
+      fprintf(stderr, "\n");
+    }
+    if (R.times) {   // this worker's own rows: nobody else touches them
+      for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); R.ktimes[w].push_back({t.name, ms}); R.kbases[w].push_back(R.n[(size_t)i]); }
+      for (const auto& ph : ctx->phases) R.ptimes[w].push_back(ph);
     }
   }
-  void run_on_all(const std::function<void(size_t)>& f) {   // f(w) on every worker, w = 0 on the calling thread; returns when all are done
-    {
-      std::lock_guard<std::mutex> lk(jm);
-      job = &f;
-      pending = (int)threads.size();
-      ++generation;
+  // under jm: one more chromosome of the run is finished; the last one closes the run
+  void completed_one(const std::shared_ptr<PoolRun>& r) {
+    if (++r->completed < r->nchrom) return;
+    finish(*r);
+    for (auto it = active.begin(); it != active.end(); ++it) if (it->get() == r.get()) { active.erase(it); break; }
+    dcv.notify_all();
+  }
+  void finish(PoolRun& R) {
+    static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[trace] run %llu: all chromosomes done at %.2f ms\n", (unsigned long long)R.id, now_ms() - R.t0);
+    for (int i = 0; i < R.nchrom; ++i) {
+      if (R.status) R.status[i] = R.rcs[(size_t)i];
+      if (R.rcs[(size_t)i] != RSI_OK && R.worst == RSI_OK) { R.worst = R.rcs[(size_t)i]; std::lock_guard<std::mutex> lk(g_err_mu); err = g_last_error; }
     }
-    jcv.notify_all();
-    f(0);
-    std::unique_lock<std::mutex> lk(jm);
-    dcv.wait(lk, [&] { return pending == 0; });
-    job = nullptr;
+    if (rsi_batch_times* times = R.times) {   // accumulate into the caller's table (names are static strings)
+      for (size_t w = 0; w < workers.size(); ++w) {
+        for (size_t e = 0; e < R.ktimes[w].size(); ++e) {
+          int slot = -1;
+          for (int q = 0; q < times->nkernels; ++q) if (times->kernel_name[q] == R.ktimes[w][e].first) { slot = q; break; }
+          if (slot < 0 && times->nkernels < RSI_MAX_TIMED) { slot = times->nkernels++; times->kernel_name[slot] = R.ktimes[w][e].first; times->kernel_ms[slot] = 0; times->kernel_launches[slot] = 0; times->kernel_bases[slot] = 0; }
+          if (slot >= 0) { times->kernel_ms[slot] += R.ktimes[w][e].second; times->kernel_launches[slot] += 1; times->kernel_bases[slot] += R.kbases[w][e]; }
+        }
+        for (const auto& ph : R.ptimes[w]) {
+          int slot = -1;
+          for (int q = 0; q < times->nphases; ++q) if (times->phase_name[q] == ph.first) { slot = q; break; }
+          if (slot < 0 && times->nphases < RSI_MAX_TIMED) { slot = times->nphases++; times->phase_name[slot] = ph.first; times->phase_ms[slot] = 0; }
+          if (slot >= 0) times->phase_ms[slot] += ph.second;
+        }
+      }
+    }
+    R.done = true;
+  }
+  void worker_loop(size_t w) {
+    for (;;) {
+      std::shared_ptr<PoolRun> r;
+      int k = 0;
+      {
+        std::unique_lock<std::mutex> lk(jm);
+        jcv.wait(lk, [&] { return quit || claim(r, k, 0); });
+        if (quit) return;
+      }
+      process(w, *r, k);
+      std::lock_guard<std::mutex> lk(jm);
+      completed_one(r);
+    }
   }
 };
 
@@ -118,90 +191,81 @@ const char* rsi_pool_last_error(const rsi_pool* pool) {
   return copy.c_str();
 }
 
-static int pool_run_impl(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
-                         const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times, bool host_inputs) {
-  if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return RSI_ERR_BAD_ARG;
-  std::vector<int> order((size_t)nchrom);
-  for (int i = 0; i < nchrom; ++i) order[(size_t)i] = i;
+static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times, bool host_inputs) {
+  if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return 0;
+  auto R = std::make_shared<PoolRun>();
+  R->params = *p;
+  R->nchrom = nchrom;
+  R->depth.assign(d_depth, d_depth + nchrom);
+  R->fasta.assign(d_fasta, d_fasta + nchrom);
+  R->n.assign(n, n + nchrom);
+  R->out = out; R->status = status; R->times = times; R->host_inputs = host_inputs;
+  R->order.resize((size_t)nchrom);
+  for (int i = 0; i < nchrom; ++i) R->order[(size_t)i] = i;
+  std::stable_sort(R->order.begin(), R->order.end(), [&](int a, int b) { return n[a] > n[b]; });   // longest first
+  R->rcs.assign((size_t)nchrom, RSI_OK);
+  R->ktimes.resize(pool->workers.size()); R->ptimes.resize(pool->workers.size()); R->kbases.resize(pool->workers.size());
+  R->t0 = now_ms();
+  int64_t largest = 0;
+  for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
   {
-    int64_t largest = 0;
-    for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
+    std::lock_guard<std::mutex> lk(pool->jm);
+    R->id = pool->next_id++;
+    // a context sizes its workspace for the largest chromosome the pool has seen (read when a chromosome starts)
     for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
+    pool->gate.few_chromosomes = nchrom <= kFewChromosomes && pool->active.empty();
+    pool->unwaited.push_back(R);
+    if (nchrom == 0) pool->finish(*R);
+    else pool->active.push_back(R);
   }
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
-  pool->gate.few_chromosomes = nchrom <= kFewChromosomes;
-  std::atomic<int> next(std::min<int>(nchrom, (int)pool->workers.size()));
-  std::vector<int> rcs((size_t)nchrom, RSI_OK);
-  std::vector<std::vector<std::pair<const char*, float>>> ktimes(pool->workers.size());
-  std::vector<std::vector<std::pair<const char*, double>>> ptimes(pool->workers.size());
-  std::vector<std::vector<int64_t>> kbases(pool->workers.size());
-  static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
-  const double t_run0 = now_ms();
-  std::mutex trace_mu;
-  auto work = [&](size_t w) {
-    rsi_ctx* ctx = pool->workers[w];
-    bool first = true;
+  pool->jcv.notify_all();
+  return R->id;
+}
+
+static int pool_wait_impl(rsi_pool* pool, uint64_t ticket) {
+  if (!pool || !ticket) return RSI_ERR_BAD_ARG;
+  std::shared_ptr<PoolRun> mine;
+  {
+    std::lock_guard<std::mutex> lk(pool->jm);
+    for (auto& r : pool->unwaited) if (r->id == ticket) { mine = r; break; }
+  }
+  if (!mine) return RSI_ERR_BAD_ARG;
+  // the caller is worker 0 while it waits (when nobody else is): chromosomes of its own run and of the runs ahead of it
+  if (pool->w0m.try_lock()) {
     for (;;) {
-      // the W longest chromosomes always go to the same workers (rank k -> worker k): a context then
-      // meets its biggest workload in the first batch and never has to grow its workspace again
-      int k;
-      if (first && (int)w < nchrom) { k = (int)w; first = false; }
-      else { first = false; k = next.fetch_add(1); }
-      if (k >= nchrom) break;
-      const int i = order[(size_t)k];
-      out[i] = nullptr;
-      const double t_a = now_ms();
-      // host inputs: the worker's own stream carries its chromosome's transfer (pinned memory: a plain DMA), so the transfers of
-      // some chromosomes run beside the kernels of others -- H2D double-buffered against compute across the pool's workers
-      rcs[(size_t)i] = host_inputs ? rsi_hot_run(ctx, p, static_cast<const int32_t*>(d_depth[i]), static_cast<const uint8_t*>(d_fasta[i]), n[i], &out[i])
-                                   : rsi_hot_run_device(ctx, p, d_depth[i], d_fasta[i], n[i], &out[i]);
-      if (trace) {
-        std::lock_guard<std::mutex> lk(trace_mu);
-        fprintf(stderr, "[trace] worker %zu chrom %d n %lld start %.2f end %.2f :", w, i, (long long)n[i], t_a - t_run0, now_ms() - t_run0);
-        for (const auto& ph : ctx->phases) fprintf(stderr, " %s=%.2f", ph.first, ph.second);
-        fprintf(stderr, "\n");
+      std::shared_ptr<PoolRun> r;
+      int k = 0;
+      {
+        std::lock_guard<std::mutex> lk(pool->jm);
+        if (mine->done || !pool->claim(r, k, ticket)) break;
       }
-      if (times) {
-        for (const KernelTime& t : ctx->ktimes) { float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b); ktimes[w].push_back({t.name, ms}); kbases[w].push_back(n[i]); }
-        for (const auto& ph : ctx->phases) ptimes[w].push_back(ph);
-      }
+      pool->process(0, *r, k);
+      std::lock_guard<std::mutex> lk(pool->jm);
+      pool->completed_one(r);
     }
-  };
-  double t_work = 0;
-  const std::function<void(size_t)> job = [&](size_t w) { work(w); if (w == 0) t_work = now_ms() - t_run0; };
-  pool->run_on_all(job);
-  if (trace) fprintf(stderr, "[trace] pool_run: own work done at %.2f ms, all workers joined at %.2f ms\n", t_work, now_ms() - t_run0);
-  int worst = RSI_OK;
-  for (int i = 0; i < nchrom; ++i) {
-    if (status) status[i] = rcs[(size_t)i];
-    if (rcs[(size_t)i] != RSI_OK && worst == RSI_OK) { worst = rcs[(size_t)i]; pool->err = g_last_error; }
+    pool->w0m.unlock();
   }
-  if (times) {   // accumulate into the caller's table (names are static strings)
-    for (size_t w = 0; w < pool->workers.size(); ++w) {
-      for (size_t e = 0; e < ktimes[w].size(); ++e) {
-        int slot = -1;
-        for (int q = 0; q < times->nkernels; ++q) if (times->kernel_name[q] == ktimes[w][e].first) { slot = q; break; }
-        if (slot < 0 && times->nkernels < RSI_MAX_TIMED) { slot = times->nkernels++; times->kernel_name[slot] = ktimes[w][e].first; times->kernel_ms[slot] = 0; times->kernel_launches[slot] = 0; times->kernel_bases[slot] = 0; }
-        if (slot >= 0) { times->kernel_ms[slot] += ktimes[w][e].second; times->kernel_launches[slot] += 1; times->kernel_bases[slot] += kbases[w][e]; }
-      }
-      for (const auto& ph : ptimes[w]) {
-        int slot = -1;
-        for (int q = 0; q < times->nphases; ++q) if (times->phase_name[q] == ph.first) { slot = q; break; }
-        if (slot < 0 && times->nphases < RSI_MAX_TIMED) { slot = times->nphases++; times->phase_name[slot] = ph.first; times->phase_ms[slot] = 0; }
-        if (slot >= 0) times->phase_ms[slot] += ph.second;
-      }
-    }
-  }
-  return worst;
+  std::unique_lock<std::mutex> lk(pool->jm);
+  pool->dcv.wait(lk, [&] { return mine->done; });
+  for (auto it = pool->unwaited.begin(); it != pool->unwaited.end(); ++it) if (it->get() == mine.get()) { pool->unwaited.erase(it); break; }
+  return mine->worst;
 }
 
 int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
                  const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
-  return pool_run_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false);
+  const uint64_t t = pool_submit_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false);
+  return t ? pool_wait_impl(pool, t) : RSI_ERR_BAD_ARG;
 }
 int rsi_pool_run_host(rsi_pool* pool, const rsi_params* p, int nchrom, const int32_t* const* depth, const uint8_t* const* fasta,
                       const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
-  return pool_run_impl(pool, p, nchrom, reinterpret_cast<const void* const*>(depth), reinterpret_cast<const void* const*>(fasta), n, out, status, times, true);
+  const uint64_t t = pool_submit_impl(pool, p, nchrom, reinterpret_cast<const void* const*>(depth), reinterpret_cast<const void* const*>(fasta), n, out, status, times, true);
+  return t ? pool_wait_impl(pool, t) : RSI_ERR_BAD_ARG;
 }
+uint64_t rsi_pool_submit(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
+                         const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
+  return pool_submit_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false);
+}
+int rsi_pool_wait(rsi_pool* pool, uint64_t ticket) { return pool_wait_impl(pool, ticket); }
 
 }  // extern "C"

@@ -62,6 +62,31 @@ def test_pool_equals_single_context(hot, hotlib):
             for k, c in enumerate(calls[:2]):
                 assert list(row[8 + 8 * k: 16 + 8 * k]) == [c["start"], c["end"], c["type"], c["qscore"], c["cnvmed"], c["cnviqr"], c["refmed"], c["refiqr"]]
             assert (row[8 + 8 * min(len(calls), 2):] == -7.0).all()
+    # queued runs (rsi_pool_submit / rsi_pool_wait): three samples in the queue at once, different flags and chromosome subsets,
+    # waited for out of order and from two threads; every run's results equal the single-context ones
+    import threading
+    p2 = api.make_params(m=51, trans=1)
+    single2 = [hot.run_device(p2, c[0], c[1], c[2]) for c in chroms[:3]]
+    for _ in range(3):
+        h1 = pool.submit(p, chroms)
+        h2 = pool.submit(p2, chroms[:3])
+        h3 = pool.submit(p, chroms[::-1])
+        got = {}
+        th = threading.Thread(target=lambda: got.__setitem__("h3", pool.wait(h3)))
+        th.start()
+        got["h2"] = pool.wait(h2)
+        got["h1"] = pool.wait(h1)
+        th.join()
+        for want, have in ((single, got["h1"]), (single2, got["h2"]), (single[::-1], got["h3"])):
+            assert len(want) == len(have)
+            for a, b in zip(want, have):
+                ok, why = calls_equal(a.calls("calls_raw"), b.calls("calls_raw"), rtol=0)
+                assert ok, why
+                assert a.stats["RDmedian"] == b.stats["RDmedian"] and a.stats["RDsd"] == b.stats["RDsd"]
+    empty = pool.submit(p, [])
+    assert pool.wait(empty) == []
+    with pytest.raises(api.RsiError):
+        pool.wait({"ticket": 987654321, "k": 0, "out": None})
     pool.close()
 
 
