@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
-    ap.add_argument("--workers", type=int, default=12, help="host threads / HIP streams per GPU (chromosomes in flight)")
+    ap.add_argument("--workers", type=int, default=16, help="host threads / HIP streams per GPU (chromosomes in flight)")
     ap.add_argument("--inflight", type=int, default=2, help="steps (genomes) queued in the pool at once: 2 = the next genome's first chromosomes "
                     "run beside the last ones of the current genome (rsi_pool_submit); 1 = one genome at a time")
     args = ap.parse_args()
@@ -568,7 +568,7 @@ def genome_from_host(lib, pool, dev, args):
     return {"chromosomes": len(host), "bases": total, "ms": round(dt * 1e3, 2), "bases_per_s": round(total / dt, 1),
             "h2d_GBps": round(5.0 * total / dt / 1e9, 1), "calls": sum(len(r.calls("calls")) for r in res),
             "note": "rsi_pool_run_host: pinned host depth + FASTA of the 3 Gb genome's chromosomes (as many as a third of the free host memory "
-                    "holds, longest first) -> results on the host; 12 workers, each chromosome's transfer on its worker's stream"}
+                    "holds, longest first) -> results on the host; the pool of the main line, each chromosome's transfer on its worker's stream"}
 
 
 def fallback_envelope(lib, pool, dev):

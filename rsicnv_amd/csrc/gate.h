@@ -7,9 +7,10 @@
 namespace rsip {
 
 // One GPU, several workers.  The per-base phase of a chromosome is HBM-bound, so running many of
-// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (two: the
-// phase has host round trips -- N-run list, cap median, bin statistics -- and the second one's kernels
-// fill them).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
+// them at once gains nothing and costs L2 locality: at most `max_streamers` are in flight (three: the
+// phase has a host round trip -- N-run list, cap median, bin statistics -- and its big kernels end in one-workgroup tails;
+// the others' kernels fill both.  Two was the measured optimum while a pool ran one genome at a time; with genomes queued
+// back to back, 16 workers and three phases take 14.2-14.9 ms per genome against 15.2 for 12 and two).  Bin-level work of other chromosomes overlaps freely.  With RSI_HOT_ISOLATE_STREAMING=1
 // a per-base phase runs alone on the chip (bin-level sections wait, waiting streamers hold back new
 // sharers): every streaming launch is then a clean roofline sample, at about 20 % less throughput.
 struct GpuGate {
@@ -17,7 +18,7 @@ struct GpuGate {
   std::condition_variable cv;
   int sharers = 0, streamers_waiting = 0, streaming = 0;
   bool few_chromosomes = false;   // set per rsi_pool_run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
-  int max_streamers = 2;   // per-base phases in flight: one fills the host gaps (syncs, small decisions) of the other
+  int max_streamers = 3;   // per-base phases in flight: the others fill the host gaps (syncs, small decisions) and one-workgroup tails of one
   void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
   void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }
   void lock(bool exclude_sharers) {

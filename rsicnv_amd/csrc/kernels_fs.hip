@@ -168,15 +168,15 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
 //    step, and keeps the values of ITS level in order without a barrier: ballot of the matches, a lane's slot is the number
 //    of matching lanes below it, values into the wave's LDS queue; lane 0 adds the queue to the level's float sum whenever
 //    it fills up.  A level no bin carries (most of them) returns at once.
-//  * The last workgroup carries the unmarked level's float sum over the chunks: the chunk records are staged in LDS a batch at
-//    a time, lane 0 applies them one after the other and stops at the first chunk it cannot take in one step (a binade
-//    crossing, or the start of the sum).  The workgroup then stages that chunk's bins in LDS, every thread composes the step
-//    functions of its eight bins for the sum's current binade and the next, and lane 0 walks those 256 functions, going bin by
-//    bin only through the eight where the sum actually crosses.
+//  * The last workgroup carries the unmarked level's float sum over the chunks, 256 chunk records at a time: one record per
+//    thread, an ordered scan of the functions that fit the sum's binade, and the first chunk that cannot be taken in one step (a
+//    binade crossing, or the start of the sum) is a count (a serial walk over the records by one lane took 0.2 us per chunk:
+//    240 of the kernel's 340 us on a 250 Mb chromosome).  The workgroup then stages that chunk's bins in LDS, every thread
+//    composes the step functions of its eight bins for the sum's current binade and the next, and the same scan finds the eight
+//    bins where the sum actually crosses; lane 0 adds those one by one.
 // out: [2 Lmax + 1] float sums then [2 Lmax + 1] int counts (index = level + Lmax); the workgroup that finishes last copies
 // them to mapped host memory.  A count of -1 at the unmarked level tells the host to do the sums itself (more marked bins
 // than the compact list holds, or a negative / non-finite value: the integer-step argument needs x >= 0).
-constexpr int kFnBatch = 512;   // 20 KB: the kernel fits on a CU next to three K3' workgroups
 __device__ inline bool fs_apply(float& s, int ue, StepFn f) {   // one step of a function valid for unit exponent ue; false: not applicable
   const uint32_t bits = __float_as_uint(s);
   const int ex = (int)((bits >> 23) & 0xff);
@@ -192,11 +192,10 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
                                                             const float* __restrict__ clist_t, const int32_t* __restrict__ total_marked,
                                                             const unsigned int* __restrict__ level_count, int32_t clist_cap, int Lmax,
                                                             float* __restrict__ out, unsigned int* __restrict__ counter, void* host_copy) {
-  __shared__ ChunkFn s_fn[kFnBatch];
-  __shared__ float s_x[kChunk];
+  __shared__ __align__(16) float s_x[kChunk];
   __shared__ StepFn s_ta[kThreads], s_tb[kThreads];
-  __shared__ int s_stop, s_ue, s_t0, s_wcnt[kThreads / 64];
-  __shared__ unsigned int s_sbits;
+  __shared__ int s_t0, s_wcnt[kThreads / 64];
+  __shared__ unsigned int s_sbits, s_cur;
   __shared__ StepFn s_sc[2][kThreads];
   const int nlev = 2 * Lmax + 1;
   unsigned int* out_bits = reinterpret_cast<unsigned int*>(out);
@@ -204,48 +203,57 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
   const int M = total_marked[0];
   const bool bad = total_marked[1] != 0 || M > clist_cap;
   if (blockIdx.x == gridDim.x - 1) {
-    float s = 0.0f;
-    for (int b0 = 0; b0 < nchunks; b0 += kFnBatch) {
-      const int bn = nchunks - b0 < kFnBatch ? nchunks - b0 : kFnBatch;
-      __syncthreads();
-      for (int e = threadIdx.x; e < bn; e += kThreads) s_fn[e] = fns[b0 + e];
-      __syncthreads();
+    // The sum walks the chunk records kThreads at a time: every thread holds one record, the ordered composition (a scan) of the
+    // functions that fit the sum's binade gives every thread the sum AFTER its chunk; the results are monotone, so the first
+    // chunk that takes the sum out of its binade (or whose candidate binades do not fit: a saturated increment stands in for it)
+    // is a count.  That chunk goes through the bin-by-bin machinery below, and the walk continues behind it.
+    if (threadIdx.x == 0) s_cur = 0u;   // 0.0f
+    for (int b0 = 0; b0 < nchunks; b0 += kThreads) {
+      const int bn = nchunks - b0 < kThreads ? nchunks - b0 : kThreads;
+      ChunkFn R;
+      R.ue0 = 0; R.f0 = StepFn{0, 0}; R.f1 = StepFn{0, 0};
+      if ((int)threadIdx.x < bn) R = fns[b0 + threadIdx.x];
+      __syncthreads();   // s_cur
       int c = 0;
       while (c < bn) {
-        if (threadIdx.x == 0) {
-          // the sum as (unit exponent, 24-bit integer) while it walks the chunk records: a handful of integer operations per chunk,
-          // the next record's LDS reads issued before this one's are used
-          const uint32_t bits = __float_as_uint(s);
+        {
+          const uint32_t bits = s_cur;
           const int ex = (int)((bits >> 23) & 0xff);
           if (ex != 0 && ex != 255) {
-            const int ue = ex - 150;
-            long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
-            ChunkFn F = s_fn[c];
-            while (c < bn) {
-              const ChunkFn Fn = s_fn[c + 1 < bn ? c + 1 : c];
-              const int d = ue - F.ue0;
-              if (d != 0 && d != 1) break;
-              const StepFn f = d == 0 ? F.f0 : F.f1;
-              const long long S2 = S + ((S & 1) ? f.a1 : f.a0);
-              if (S2 >= (1ll << 24)) break;                    // the sum leaves the binade inside this chunk
-              S = S2;
-              F = Fn;
-              ++c;
+            const int d = (ex - 150) - R.ue0;
+            StepFn F = {0, 0};
+            if ((int)threadIdx.x >= c && (int)threadIdx.x < bn) F = d == 0 ? R.f0 : (d == 1 ? R.f1 : StepFn{kStepSat, kStepSat});
+            int cur = 0;
+            s_sc[0][threadIdx.x] = F;
+            __syncthreads();
+            for (int dd = 1; dd < kThreads; dd <<= 1) {
+              StepFn G = s_sc[cur][threadIdx.x];
+              if ((int)threadIdx.x >= dd) G = fs_compose(s_sc[cur][threadIdx.x - dd], G);
+              s_sc[cur ^ 1][threadIdx.x] = G;
+              cur ^= 1;
+              __syncthreads();
             }
-            s = __uint_as_float(((uint32_t)ex << 23) | ((uint32_t)S & 0x7fffffu));
+            F = s_sc[cur][threadIdx.x];
+            const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
+            const long long St = S + ((S & 1) ? F.a1 : F.a0);
+            const unsigned long long okm = __ballot(St < (1ll << 24));
+            if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = __popcll(okm);
+            __syncthreads();
+            int tfail = 0;   // chunks taken in one step each (threads below c and from bn on carry the identity)
+            for (int w = 0; w < kThreads / 64; ++w) tfail += s_wcnt[w];
+            if (tfail > 0 && (int)threadIdx.x == tfail - 1) s_cur = ((uint32_t)ex << 23) | ((uint32_t)St & 0x7fffffu);
+            __syncthreads();
+            c = tfail < bn ? tfail : bn;
           }
-          s_stop = c;
-          s_ue = (int)((__float_as_uint(s) >> 23) & 0xff) - 150;
         }
-        __syncthreads();
-        c = s_stop;
         if (c >= bn) break;
+        float s = __uint_as_float(s_cur);
         // chunk b0 + c crosses a binade (or starts the sum): its unmarked values into LDS (marked ones as -1), per-thread
         // step functions for the sum's binade and the one above.  Then, in rounds: an ordered parallel composition (scan) of
         // the 256 functions from the first thread not yet consumed gives every thread the sum AFTER its bins as an integer; the
         // results are monotone, so the first thread whose result leaves the binade is a count; lane 0 adds that thread's eight
         // bins one by one in float (the crossing itself), and the next round continues behind it in the new binade.
-        int ue = s_ue;
+        int ue = 0;   // set when the functions are built
         const int64_t i0 = (int64_t)(b0 + c) * kChunk + (int64_t)threadIdx.x * kPerThread;
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -256,6 +264,20 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
         bool staged = false;
         if (threadIdx.x == 0) { s_sbits = __float_as_uint(s); s_t0 = 0; }
         __syncthreads();
+        // The chromosome's first chunk takes the sum from zero through a dozen binades (one round of the machinery below for
+        // each): lane 0 adds its bins one after the other instead -- the loop itself, 2048 dependent additions, about one round's time.
+        if (b0 + c == 0) {
+          if (threadIdx.x == 0) {
+            float sv = __uint_as_float(s_sbits);
+            for (int j = 0; j < kChunk; j += 4) {
+              const float4 x = *reinterpret_cast<const float4*>(&s_x[j]);
+              sv = x.x >= 0.0f ? sv + x.x : sv; sv = x.y >= 0.0f ? sv + x.y : sv;
+              sv = x.z >= 0.0f ? sv + x.z : sv; sv = x.w >= 0.0f ? sv + x.w : sv;
+            }
+            s_sbits = __float_as_uint(sv); s_t0 = kThreads;
+          }
+          __syncthreads();
+        }
         while (true) {
           if (threadIdx.x == 0) {   // a sum that is not a normal number yet (the start: zeros) takes bins one by one
             float sv = __uint_as_float(s_sbits);
@@ -318,12 +340,12 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
           }
           __syncthreads();
         }
-        if (threadIdx.x == 0) s = __uint_as_float(s_sbits);
+        if (threadIdx.x == 0) s_cur = s_sbits;
         ++c;
         __syncthreads();
       }
     }
-    if (threadIdx.x == 0) { st_cg(&out_bits[Lmax], __float_as_uint(s)); st_cg(&out_cnt[Lmax], bad ? 0xffffffffu : (unsigned int)(nb - M)); }
+    if (threadIdx.x == 0) { st_cg(&out_bits[Lmax], s_cur); st_cg(&out_cnt[Lmax], bad ? 0xffffffffu : (unsigned int)(nb - M)); }
   } else {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = (int)blockIdx.x * (kThreads / 64) + wave, l = li - Lmax;

@@ -1542,7 +1542,7 @@ int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status
   const int nlev = 2 * Lmax + 1;
   uint32_t* slot = static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
   if (!slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
-  launch_level_sums(ctx->tnb.as<float>(), ctx->status1.as<int32_t>(), nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(), counter, slot, ctx->stream);
+  { Timer t(ctx, "level_sums"); launch_level_sums(ctx->tnb.as<float>(), ctx->status1.as<int32_t>(), nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(), counter, slot, ctx->stream); }
   HIPCHK(CTX_SYNC());
   memcpy(sums, slot, (size_t)nlev * 4);
   memcpy(counts, slot + nlev, (size_t)nlev * 4);
