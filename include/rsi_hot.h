@@ -198,6 +198,10 @@ int64_t rsi_hot_fetch_i64(rsi_ctx* ctx, const char* name, int64_t* out, int64_t 
  * T[nb], status[nb] (values in [-Lmax, Lmax]) through the device's exact parallel form; sums / counts: 2 Lmax + 1 entries, index
  * = level + Lmax.  counts[Lmax] == -1: the device declined the input (the pipeline then runs the sequential loop itself). */
 int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status, int64_t nb, int Lmax, float* sums, int32_t* counts);
+/* Test hook: one scan pass (rsistatus) over host arrays with the caller's thresholds; status[nb] out, info[4] = tiles the
+ * detection pass listed, trimming walks that left the array, inexact-threshold flags, 0. */
+int rsi_hot_debug_scan(rsi_ctx* ctx, const float* T, const int32_t* medint, int64_t nb, double RDmedian, double tmedian, double tlamda,
+                       int Lmax, int32_t* status, int32_t* info);
 
 /* Timing hooks for bench.py: per-kernel HIP-event times (ms) of the last run, by kernel name.
  * names/ms receive up to cap entries; returns the number of timed launches. */

@@ -28,7 +28,7 @@ EXPORTS = ["rsi_default_params", "rsi_hot_create", "rsi_hot_destroy", "rsi_hot_l
            "rsi_hot_run_device", "rsi_hot_load_depth_text", "rsi_hot_run_text", "rsi_hot_load_depth_bam", "rsi_hot_run_bam", "rsi_bam_references", "rsi_result_annotate_bam", "rsi_result_summary", "rsi_summary_format_row", "rsi_summary_format_rows", "rsi_result_pairs", "rsi_result_ncalls", "rsi_result_calls", "rsi_result_stats", "rsi_result_noncode",
            "rsi_result_format_row", "rsi_result_free", "rsi_hot_fetch_i32", "rsi_hot_fetch_f32", "rsi_hot_fetch_i64",
            "rsi_hot_kernel_times", "rsi_hot_phase_times", "rsi_hot_set_timing", "rsi_pool_create", "rsi_pool_destroy", "rsi_pool_workers", "rsi_pool_worker",
-           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_pool_run_host", "rsi_pool_submit", "rsi_pool_wait", "rsi_plot_expand", "rsi_plot_write_files", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
+           "rsi_pool_set_timing", "rsi_pool_set_timing_kernel", "rsi_hot_set_timing_kernel", "rsi_pool_set_schedule", "rsi_pool_last_error", "rsi_pool_run", "rsi_pool_run_host", "rsi_pool_submit", "rsi_pool_wait", "rsi_plot_expand", "rsi_plot_write_files", "rsi_result_log_line", "rsi_hot_debug_level_sums", "rsi_hot_debug_scan", "rsi_synth_generate_host", "rsi_synth_generate_device", "rsi_synth_write_depth_text", "rsi_synth_write_fasta"]
 
 
 class RsiParams(C.Structure):
@@ -290,6 +290,19 @@ class RsiHot:
         self.lib.rsi_hot_debug_level_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         self._check(self.lib.rsi_hot_debug_level_sums(self.ctx, t.ctypes.data, s.ctypes.data, t.size, int(Lmax), sums.ctypes.data, counts.ctypes.data))
         return sums, counts
+
+    def debug_scan(self, T, medint, RDmedian, tmedian, tlamda, Lmax):
+        """One scan pass (rsistatus) over host arrays on the device (test hook): (status, info)."""
+        t = np.ascontiguousarray(T, dtype=np.float32)
+        mi = np.ascontiguousarray(medint, dtype=np.int32)
+        assert t.size == mi.size
+        st = np.zeros(t.size, dtype=np.int32)
+        info = np.zeros(4, dtype=np.int32)
+        self.lib.rsi_hot_debug_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+        self._check(self.lib.rsi_hot_debug_scan(self.ctx, t.ctypes.data, mi.ctypes.data, t.size, float(RDmedian), float(tmedian), float(tlamda),
+                                                int(Lmax), st.ctypes.data, info.ctypes.data))
+        return st, info
 
     def run(self, params, depth, fasta):
         """depth: int32[n] raw per-base depth, fasta: uint8[n] sequence bytes (host arrays)."""

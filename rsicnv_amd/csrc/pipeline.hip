@@ -1549,6 +1549,46 @@ int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status
   return RSI_OK;
 }
 
+// Test hook: one scan pass (rsistatus, rsi.cpp:1191-1259: detection, exact sweep, level stop, first-mark resolution) over host
+// arrays -- the transformed bins, the integer bin medians, and the thresholds the caller chose.  For window lengths no whole
+// run reaches in test time (-m 1: the stages behind the scan take the reference, and this library's host side, hours).
+int rsi_hot_debug_scan(rsi_ctx* ctx, const float* T, const int32_t* medint, int64_t nb, double RDmedian, double tmedian, double tlamda,
+                       int Lmax, int32_t* status, int32_t* info /* [4]: tiles listed, trim escapes, inexact, 0 */) {
+  if (!ctx || !T || !medint || !status || nb <= 0 || nb >= (1ll << 31) - 4096 || Lmax < 1 || Lmax > kMaxL || Lmax > nb) return fail(ctx, RSI_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx_enter(ctx)) return RSI_ERR_HIP;
+  mailbox_reset(ctx);
+  ctx->nb = nb;
+  HIPCHK(ctx->small.ensure(kSmallBytes));
+  HIPCHK(ctx->tnb.ensure((size_t)nb * 4));
+  HIPCHK(ctx->binmed.ensure((size_t)nb * 4));
+  HIPCHK(ctx->first_del.ensure((size_t)(2 * nb + 8) * 4));
+  HIPCHK(ctx->status1.ensure((size_t)nb * 4));
+  HIPCHK(ctx->status1f.ensure((size_t)nb * 4));
+  HIPCHK(ctx->runs.ensure((size_t)kMaxRunEntries * 8));
+  HIPCHK(ctx->scan_tiles.ensure((size_t)(nb / 256 + 2) * 4));
+  HIPCHK(hipMemcpyAsync(ctx->tnb.p, T, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->binmed.p, medint, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->small.p, 0, kHeaderBytes, ctx->stream));   // arrival counters, list counts
+  {
+    FillList fl{};
+    void* keep = ctx->fs_ws.p;
+    ctx->fs_ws.p = nullptr;            // no level sums behind this pass
+    scan_fill_list(ctx, 0, nb, fl);
+    ctx->fs_ws.p = keep;
+    launch_fill(fl, ctx->stream);
+  }
+  const uint32_t* wslot = nullptr;
+  const uint32_t* rslot = nullptr;
+  const int rc = scan_pass(ctx, 0, ctx->tnb.as<float>(), ctx->binmed.as<int32_t>(), nb, RDmedian, tmedian, tlamda, Lmax, ctx->status1.as<int32_t>(),
+                           ctx->status1f.as<int32_t>(), &wslot, &rslot);
+  if (rc != RSI_OK) return rc;
+  HIPCHK(hipMemcpyAsync(status, ctx->status1.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(CTX_SYNC());
+  if (info) { info[0] = (int32_t)wslot[8]; info[1] = (int32_t)wslot[0]; info[2] = (int32_t)wslot[1]; info[3] = 0; }
+  return RSI_OK;
+}
+
 int rsi_hot_phase_times(const rsi_ctx* ctx, const char** names, double* ms, int cap) {
   if (!ctx) return 0;
   int k = 0;

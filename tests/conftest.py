@@ -56,10 +56,6 @@ def wide_scan_cases():
         ("wide_m5_nb", dict(n=60_001, seed=0x5CA3, model=0, mean=40.0, n_events=3, gaps=0, max_len=2500, end_n=1000), dict(m=5)),
         # -m 3: Lmax = 3333, beyond the 2048 the scan kernel used to stop at (one 256-bin tile + 2 x 1667 halo bins in LDS)
         ("wide_m3_nb", dict(n=45_003, seed=0x5CA4, model=0, mean=40.0, n_events=3, gaps=0, max_len=2000, end_n=900), dict(m=3)),
-        # -m 1: Lmax = 10000, the reference's longest scan without a larger computed length -- beyond what an LDS tile holds (3800):
-        # the exact sweep runs on tiles in device memory
-        # (one short event: at -m 1 the reference sorts up to 10000 values for every hit, an event of a thousand bases takes it hours)
-        ("wide_m1_nb", dict(n=24_001, seed=0x5CA5, model=0, mean=40.0, n_events=1, gaps=0, min_len=80, max_len=120, end_n=500), dict(m=1)),
     ]
 
 

@@ -41,3 +41,19 @@ def test_oracle_matches_reference_golden(hotlib, oracle_cls, name):
     for which in ("calls_raw", "calls"):
         ok, why = calls_equal(O.calls(which), gu.calls_from_array(g[which]), rtol=0)
         assert ok, f"{which}: {why}"
+
+
+def test_rsistatus_restatement_equals_the_oracle(hotlib, oracle_cls):
+    """CPU: rsistatus_numpy (tests/scan_restatement.py, the checker of the -m 1 scan in test_hot_extra.py) against the oracle's own rsistatus where the oracle is fast
+    enough (-m 11, Lmax 909; the oracle itself is pinned by the golden file of the same case)."""
+    import oracle
+    from conftest import make_case
+    from scan_restatement import rsistatus_numpy
+    name, plan_kw, flag_kw = wide_scan_cases()[0]
+    _, fasta, depth = make_case(hotlib, plan_kw)
+    O = oracle_cls()
+    O.run(oracle.make_params(**flag_kw), depth, fasta)
+    sc = O.f64("scan_nb")
+    exp = rsistatus_numpy(O.f32("binnb"), O.i32("binmedint"), O.f64("chrom")[0], sc[0], sc[2], int(sc[7]), O.exact_median)
+    assert np.count_nonzero(exp) > 100
+    assert np.array_equal(exp, O.i32("nb_status1"))

@@ -431,10 +431,30 @@ def test_bin_size_extremes(hot, hotlib, oracle_cls):
     ok, why = calls_equal(res.calls("calls"), O.calls("calls"))
     assert ok, why
     # -m 3 (Lmax 3333) fits the scan's LDS tile (golden case wide_m3_nb); -m 1 (Lmax 10000) runs on tiles in device memory
-    # (golden case wide_m1_nb); a chromosome with fewer bins than the scan is long is refused as the reference refuses it
+    # (test_scan_of_ten_thousand_lengths); a chromosome with fewer bins than the scan is long is refused as the reference refuses it
     with pytest.raises(api.RsiError) as e:
         hot.run(api.make_params(m=1), depth[:9_000], fasta[:9_000])
     assert e.value.code != 0
+
+
+def test_scan_of_ten_thousand_lengths(hot, oracle_cls):
+    """-m 1: Lmax = 10000 (rsi.cpp:1830), beyond what an LDS tile of the scan kernel holds -- the exact sweep runs on tiles in
+    device memory behind the detection pass.  At that bin size the stages BEHIND the scan take the reference, the oracle and
+    this library's host side hours for any chromosome with more bins than the scan is long (the oracle: 400 s for 5500 bins),
+    so the scan pass is driven alone (rsi_hot_debug_scan) over synthetic bins, and its status array compared with a
+    restatement of rsistatus that advances all window lengths together (tests/scan_restatement.py, itself checked against the
+    oracle on the CPU, test_golden_oracle.py)."""
+    from scan_restatement import long_scan_case, rsistatus_numpy
+    T, medint, RDmedian, tmedian, tlamda, Lmax = long_scan_case()
+    exp = rsistatus_numpy(T, medint, RDmedian, tmedian, tlamda, Lmax, oracle_cls().exact_median)
+    assert np.count_nonzero(exp == -4980) > 4000 and (exp[3000:3040] < 0).all() and (exp[7000:7050] > 0).all()
+    got, info = hot.debug_scan(T, medint, RDmedian, tmedian, tlamda, Lmax)
+    assert np.array_equal(got, exp), f"{np.count_nonzero(got != exp)} bins differ; first at {np.nonzero(got != exp)[0][:5]}"
+    assert info[0] > 0 and info[1] == 0 and info[2] == 0     # tiles listed by the detection pass; no escaped walk, no inexact threshold
+    # the same bins at a length an LDS tile holds: the two sweeps agree with the restatement there too
+    exp3 = rsistatus_numpy(T, medint, RDmedian, tmedian, tlamda, 3333, oracle_cls().exact_median)
+    got3, _ = hot.debug_scan(T, medint, RDmedian, tmedian, tlamda, 3333)
+    assert np.array_equal(got3, exp3) and not np.array_equal(exp3, exp)
 
 
 def test_many_n_runs(hot, hotlib, oracle_cls):
