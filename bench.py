@@ -612,7 +612,7 @@ def fallback_envelope(lib, pool, dev):
     return out
 
 
-def config5_side_pass(lib, pool, dev, args, steps=6, warmup=2):
+def config5_side_pass(lib, pool, dev, args, steps=10, warmup=5):
     """BASELINE.json configs[4] through the same pool: ms per genome, whole-path fraction (24.3 B/base at m = 51), the scan
     kernel's window evaluations per second.  Never part of `value`."""
     import torch
