@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
     ap.add_argument("--workers", type=int, default=16, help="host threads / HIP streams per GPU (chromosomes in flight)")
-    ap.add_argument("--inflight", type=int, default=2, help="steps (genomes) queued in the pool at once: 2 = the next genome's first chromosomes "
-                    "run beside the last ones of the current genome (rsi_pool_submit); 1 = one genome at a time")
+    ap.add_argument("--inflight", type=int, default=0, help="steps (genomes) queued in the pool at once (rsi_pool_submit): the next genome's first "
+                    "chromosomes run beside the last ones of the current genome.  0 = as many as keep the pool's workers busy with this rank's "
+                    "share (2 for a whole genome, more for the few chromosomes of one rank among eight, at most 6); 1 = one genome at a time")
     args = ap.parse_args()
 
     import numpy as np
@@ -195,6 +196,8 @@ def main():
     post_q = queue.Queue()
     post_err = []
     last_rows = [0]
+    if args.inflight <= 0:   # enough queued genomes that every worker has a chromosome of this rank's share
+        args.inflight = max(2, min(6, (args.workers + max(1, len(mine)) - 1) // max(1, len(mine))))
     slots = threading.Semaphore(max(1, args.inflight))
 
     def post_worker():

@@ -1,6 +1,8 @@
 """What one rank of a sharded-genome run does, measured on ONE GPU: for world sizes 2 / 4 / 8 every rank's share of the
-24-chromosome genome (rsicnv_amd.dist.lpt_assign) goes through the same 12-worker pool, one share after the other; the
-slowest share is the step time an N-GPU run would see (without the all_gather, ~0.1 ms).  Usage:
+24-chromosome genome (rsicnv_amd.dist.lpt_assign) goes through the same 16-worker pool, one share after the other, queued
+the way bench.py queues its steps (as many genomes in flight as keep the workers busy: 2 for a whole genome, up to 6 for a
+rank's share); the slowest share is the step time an N-GPU run would see (without the all_gather, ~0.1 ms).  --serial: one
+run at a time (the latency of a share, what bench.py measured before round 3).  Usage:
   python tools/rank_probe.py [--worlds 2 4 8] [--rounds 5] [--env KEY=VALUE ...]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +14,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--env", nargs="*", default=[])
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--serial", action="store_true")
     args = ap.parse_args()
     for kv in args.env:
         k, _, v = kv.partition("=")
@@ -30,36 +34,38 @@ def main():
         data.append((d_rd, d_fa, p["n"]))
         lengths.append(p["n"])
     torch.cuda.synchronize()
-    pool = api.RsiPool(0, 12)
+    pool = api.RsiPool(0, args.workers)
     pool.set_timing(0)
     allc = [(a.data_ptr(), b.data_ptr(), n) for a, b, n in data]
-    for _ in range(2):
-        pool.run(params, allc)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.rounds):
-        pool.run(params, allc)
-    torch.cuda.synchronize()
-    whole = (time.perf_counter() - t0) / args.rounds * 1e3
-    print(f"world 1: {whole:.2f} ms per genome", flush=True)
+
+    def per_genome_ms(chroms, rounds):
+        """rounds genomes of `chroms`, queued as bench.py queues its steps; ms per genome"""
+        infl = 1 if args.serial else max(2, min(6, (args.workers + len(chroms) - 1) // len(chroms)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = []
+        for _ in range(rounds):
+            pending.append(pool.submit(params, chroms))
+            if len(pending) >= infl:
+                pool.wait(pending.pop(0))
+        while pending:
+            pool.wait(pending.pop(0))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / rounds * 1e3, infl
+
+    per_genome_ms(allc, 3)
+    whole, infl = per_genome_ms(allc, 4 * args.rounds)
+    print(f"world 1: {whole:.2f} ms per genome ({infl} in flight)", flush=True)
     for world in args.worlds:
         parts = rd.lpt_assign(lengths, world)
         worst, per = 0.0, []
         for part in parts:
             mine = [allc[i] for i in part]
-            pool.run(params, mine)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(args.rounds):
-                t0 = time.perf_counter()
-                pool.run(params, mine)
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t0) * 1e3)
-            ts.sort()
-            med = ts[len(ts) // 2]
-            per.append((len(part), sum(lengths[i] for i in part) / 1e6, med))
-            worst = max(worst, med)
-        print(f"world {world}: slowest share {worst:.2f} ms -> x{whole / worst:.2f} of one GPU; shares (chromosomes, Mb, ms): "
+            per_genome_ms(mine, 3)
+            ms, infl = per_genome_ms(mine, 4 * args.rounds)
+            per.append((len(part), sum(lengths[i] for i in part) / 1e6, ms))
+            worst = max(worst, ms)
+        print(f"world {world}: slowest share {worst:.2f} ms per genome ({infl} in flight) -> x{whole / worst:.2f} of one GPU; shares (chromosomes, Mb, ms): "
               + " ".join(f"({k},{mb:.0f},{ms:.2f})" for k, mb, ms in per), flush=True)
 
 
