@@ -2331,11 +2331,13 @@ size_t cap_compact_slab_bytes(int m, int32_t capval, int64_t ncompact, int vbase
   return (size_t)grid * vr * kResClasses * 4;
 }
 // K4' applies when the cap keeps every value in a byte below the escape code and the bin fits the register median phase.
-int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteSat && m <= 104 ? 1 : 0; }
+int cap_compact8_applies(int m, int32_t capval) { return capval >= 1 && capval < kByteSat && m <= 440 ? 1 : 0; }
 // Bins per tile: 64 with four threads per bin; 128 with two threads per bin for small bins (m <= 52: a bin is at most 14 dwords,
 // seven per thread), so that a tile still holds ~6500 values -- at -m 51 tiles of 64 bins were half as long, twice as many
-// barriers and median phases per base.
-static int k48_bins_per_tile(int m) { return m <= 52 ? 128 : 64; }
+// barriers and median phases per base.  Wide bins the other way: 32 bins with eight threads per bin up to m = 216 (a bin spans at
+// most (m + 3) / 4 + 1 = 55 dwords, seven per thread), 16 bins with sixteen threads up to m = 440 -- round 2 sent everything
+// above m = 104 through the int32 kernels (-m 201: 299 us of K3 + K4 per 60 Mb against 109).
+static int k48_bins_per_tile(int m) { return m <= 52 ? 128 : (m <= 104 ? 64 : (m <= 216 ? 32 : 16)); }
 static void k48_geometry(int m, int32_t capval, int64_t ncompact, int& vr, int& grid, int& maxc) {
   vr = 64;
   while (vr < 256 && vr <= capval) vr <<= 1;

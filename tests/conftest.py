@@ -43,6 +43,10 @@ def small_cases():
         ("poisson_no_n_tail13", dict(n=300_013, seed=0xA11D4, model=0, n_events=4, gaps=0, max_len=15000, end_n=0), dict()),
         ("gampois_no_n_tail1", dict(n=320_001, seed=0xB0E, model=1, n_events=4, gaps=1, max_len=15000, end_n=0, gap_len=5000), dict(m=51, trans=1)),
         ("gampois_no_n_tail19", dict(n=280_019, seed=0xB0F, model=1, mean=45.0, n_events=4, gaps=0, max_len=15000, end_n=0), dict()),
+        # wide bins through the byte kernels: 32 bins per tile with eight threads per bin (m <= 216), 16 with sixteen (m <= 440)
+        ("gampois_nb_m201", dict(n=700_000, seed=0xB10, model=1, n_events=5, gaps=1, max_len=40000, end_n=5000, gap_len=8000), dict(m=201)),
+        ("poisson_med_m301_tail5", dict(n=900_005, seed=0xA11D5, model=0, mean=50.0, n_events=5, gaps=1, max_len=60000, end_n=6000, gap_len=9000), dict(m=301, trans=1)),
+        ("gampois_nb_m439_cap3", dict(n=1_200_003, seed=0xB11, model=1, mean=35.0, n_events=5, gaps=1, max_len=80000, end_n=6000, gap_len=9000), dict(m=439, cap=3.0)),
     ]
 
 
