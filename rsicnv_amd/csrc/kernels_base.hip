@@ -740,7 +740,10 @@ __device__ inline void ld_cg_x4_batch8(u32x4 (&v)[8], unsigned long long base, c
 }
 
 __device__ inline void st_cg_x4(void* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  // s_nop: a store of more than 64 bits reads its data registers over several cycles, and the compiler, which does not know that
+  // this is one, may overwrite them in the very next instruction (seen in round 3: a 16-byte store written this way inside K4j's
+  // tile loop stored the NEXT values; the slab loops below only got away with it because an LDS read sits in between)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
 }
 __device__ inline u32x4 ld_cg_x4(const void* p) {
   u32x4 v;
