@@ -1,6 +1,7 @@
 // gate.h -- GpuGate, the turnstile of a pool's per-base phases.  Plain C++ (no HIP): tests/sanitize/gate_tsan.cpp drives it
 // from a dozen threads under ThreadSanitizer.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 
@@ -17,7 +18,7 @@ struct GpuGate {
   std::mutex m;
   std::condition_variable cv;
   int sharers = 0, streamers_waiting = 0, streaming = 0;
-  bool few_chromosomes = false;   // set per rsi_pool_run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
+  std::atomic<bool> few_chromosomes{false};   // set per submitted run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
   int max_streamers = 3;   // per-base phases in flight: the others fill the host gaps (syncs, small decisions) and one-workgroup tails of one
   void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
   void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }

@@ -1348,7 +1348,7 @@ int run_device_impl(rsi_ctx* ctx, const rsi_params* Pp, const int32_t* d_depth, 
   ctx->ktimes.clear();
   ctx->event_next = 0;
   ctx->phases.clear();
-  tl_grow = ctx->reserve_n > n ? (double)ctx->reserve_n / (double)n : 1.0;
+  { const int64_t reserve = ctx->reserve_n.load(); tl_grow = reserve > n ? (double)reserve / (double)n : 1.0; }
   tl_grow_ms = 0.0;
   if (!ctx_enter(ctx)) return RSI_ERR_HIP;
   mailbox_reset(ctx);

@@ -167,7 +167,7 @@ struct rsi_ctx {
   int32_t* mirror = nullptr;  // pinned host mirror of the compacted depth (DepthPager), grow-only
   size_t mirror_cap = 0;
   GpuGate* gate = nullptr;
-  int64_t reserve_n = 0;      // largest chromosome the pool has seen: workspace growth is sized for it
+  std::atomic<int64_t> reserve_n{0};   // largest chromosome the pool has seen: workspace growth is sized for it (written at submission, read when a chromosome starts)
   bool poisoned = false;      // a wait hit its deadline with work still queued (ctx_sync): no further runs
   bool gate_shared = false;   // RSI_HOT_ISOLATE_STREAMING=1: bin-level kernels wait while a per-base phase runs (clean kernel timings, ~20 % less throughput)
 };

@@ -3,8 +3,7 @@
 // lets at most two per-base phases stream at a time, and a queue of runs (samples) whose chromosomes the workers take in
 // submission order.
 #include "pipeline_internal.h"
-#include <condition_variable>
-#include <deque>
+#include "run_queue.h"
 #include <memory>
 #include <thread>
 
@@ -22,10 +21,8 @@ constexpr int kFewChromosomes = 4;   // up to here a run's candidate tests use t
 // One call's worth of chromosomes.  Runs queue up in submission order; a worker takes the next unclaimed chromosome of the
 // oldest run that has one, so a worker that finds nothing left in one run starts on the next: consecutive samples overlap, and
 // the last chromosomes of a run do not leave eleven workers idle.
-struct PoolRun {
-  uint64_t id = 0;
+struct PoolRun : rsip::RunBase {   // nitems = chromosomes
   rsi_params params;
-  int nchrom = 0;
   std::vector<const void*> depth, fasta;
   std::vector<int64_t> n;
   rsi_result** out = nullptr;
@@ -33,8 +30,6 @@ struct PoolRun {
   rsi_batch_times* times = nullptr;
   bool host_inputs = false;
   std::vector<int> order, rcs;
-  int claimed = 0, completed = 0;   // under the pool's mutex
-  bool done = false;
   int worst = RSI_OK;
   double t0 = 0;
   std::vector<std::vector<std::pair<const char*, float>>> ktimes;
@@ -51,23 +46,10 @@ struct rsi_pool {
   // whichever caller is waiting for a run (rsi_pool_run, rsi_pool_wait): starting eleven threads per run took 0.3 ms before
   // the last chromosome of the first wave was under way.
   std::vector<std::thread> threads;
-  std::mutex jm;
-  std::condition_variable jcv, dcv;
-  std::deque<std::shared_ptr<PoolRun>> active;                 // runs with unfinished chromosomes, oldest first
-  std::vector<std::shared_ptr<PoolRun>> unwaited;              // submitted, rsi_pool_wait not yet returned
-  uint64_t next_id = 1;
-  bool quit = false;
+  rsip::RunQueue<PoolRun> queue;                               // run_queue.h: runs in submission order, items claimed oldest run first
   std::mutex w0m;                                              // worker 0's context: one waiting caller at a time
   std::mutex trace_mu;
 
-  // under jm: the next chromosome to work on, from the oldest run that has one (no younger than `upto`, 0 = any)
-  bool claim(std::shared_ptr<PoolRun>& r, int& k, uint64_t upto) {
-    for (auto& a : active) {
-      if (upto && a->id > upto) break;
-      if (a->claimed < a->nchrom) { r = a; k = a->claimed++; return true; }
-    }
-    return false;
-  }
   void process(size_t w, PoolRun& R, int k) {
     static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
     rsi_ctx* ctx = workers[w];
@@ -89,17 +71,10 @@ struct rsi_pool {
       for (const auto& ph : ctx->phases) R.ptimes[w].push_back(ph);
     }
   }
-  // under jm: one more chromosome of the run is finished; the last one closes the run
-  void completed_one(const std::shared_ptr<PoolRun>& r) {
-    if (++r->completed < r->nchrom) return;
-    finish(*r);
-    for (auto it = active.begin(); it != active.end(); ++it) if (it->get() == r.get()) { active.erase(it); break; }
-    dcv.notify_all();
-  }
-  void finish(PoolRun& R) {
+  void finish(PoolRun& R) {   // under the queue's mutex, once per run: statuses, error text, the caller's timing table
     static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;
     if (trace) fprintf(stderr, "[trace] run %llu: all chromosomes done at %.2f ms\n", (unsigned long long)R.id, now_ms() - R.t0);
-    for (int i = 0; i < R.nchrom; ++i) {
+    for (int i = 0; i < R.nitems; ++i) {
       if (R.status) R.status[i] = R.rcs[(size_t)i];
       if (R.rcs[(size_t)i] != RSI_OK && R.worst == RSI_OK) { R.worst = R.rcs[(size_t)i]; std::lock_guard<std::mutex> lk(g_err_mu); err = g_last_error; }
     }
@@ -119,20 +94,14 @@ struct rsi_pool {
         }
       }
     }
-    R.done = true;
   }
   void worker_loop(size_t w) {
     for (;;) {
       std::shared_ptr<PoolRun> r;
       int k = 0;
-      {
-        std::unique_lock<std::mutex> lk(jm);
-        jcv.wait(lk, [&] { return quit || claim(r, k, 0); });
-        if (quit) return;
-      }
+      if (!queue.next(r, k)) return;
       process(w, *r, k);
-      std::lock_guard<std::mutex> lk(jm);
-      completed_one(r);
+      queue.item_done(r, [this](PoolRun& R) { finish(R); });
     }
   }
 };
@@ -164,11 +133,7 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
 
 void rsi_pool_destroy(rsi_pool* pool) {
   if (!pool) return;
-  {
-    std::lock_guard<std::mutex> lk(pool->jm);
-    pool->quit = true;
-  }
-  pool->jcv.notify_all();
+  pool->queue.shutdown();
   for (std::thread& t : pool->threads) t.join();
   for (rsi_ctx* c : pool->workers) rsi_hot_destroy(c);
   delete pool;
@@ -196,7 +161,7 @@ static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom
   if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return 0;
   auto R = std::make_shared<PoolRun>();
   R->params = *p;
-  R->nchrom = nchrom;
+  R->nitems = nchrom;
   R->depth.assign(d_depth, d_depth + nchrom);
   R->fasta.assign(d_fasta, d_fasta + nchrom);
   R->n.assign(n, n + nchrom);
@@ -209,46 +174,28 @@ static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom
   R->t0 = now_ms();
   int64_t largest = 0;
   for (int i = 0; i < nchrom; ++i) largest = std::max(largest, n[i]);
-  {
-    std::lock_guard<std::mutex> lk(pool->jm);
-    R->id = pool->next_id++;
+  return pool->queue.submit(R, [pool](PoolRun& r) { pool->finish(r); }, [pool, largest, nchrom](PoolRun&) {
     // a context sizes its workspace for the largest chromosome the pool has seen (read when a chromosome starts)
-    for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n, largest);
-    pool->gate.few_chromosomes = nchrom <= kFewChromosomes && pool->active.empty();
-    pool->unwaited.push_back(R);
-    if (nchrom == 0) pool->finish(*R);
-    else pool->active.push_back(R);
-  }
-  pool->jcv.notify_all();
-  return R->id;
+    for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n.load(), largest);
+    pool->gate.few_chromosomes = nchrom <= kFewChromosomes && pool->queue.empty_locked();
+  });
 }
 
 static int pool_wait_impl(rsi_pool* pool, uint64_t ticket) {
   if (!pool || !ticket) return RSI_ERR_BAD_ARG;
-  std::shared_ptr<PoolRun> mine;
-  {
-    std::lock_guard<std::mutex> lk(pool->jm);
-    for (auto& r : pool->unwaited) if (r->id == ticket) { mine = r; break; }
-  }
+  std::shared_ptr<PoolRun> mine = pool->queue.find(ticket);
   if (!mine) return RSI_ERR_BAD_ARG;
   // the caller is worker 0 while it waits (when nobody else is): chromosomes of its own run and of the runs ahead of it
   if (pool->w0m.try_lock()) {
-    for (;;) {
-      std::shared_ptr<PoolRun> r;
-      int k = 0;
-      {
-        std::lock_guard<std::mutex> lk(pool->jm);
-        if (mine->done || !pool->claim(r, k, ticket)) break;
-      }
+    std::shared_ptr<PoolRun> r;
+    int k = 0;
+    while (pool->queue.try_next(mine, r, k)) {
       pool->process(0, *r, k);
-      std::lock_guard<std::mutex> lk(pool->jm);
-      pool->completed_one(r);
+      pool->queue.item_done(r, [pool](PoolRun& R) { pool->finish(R); });
     }
     pool->w0m.unlock();
   }
-  std::unique_lock<std::mutex> lk(pool->jm);
-  pool->dcv.wait(lk, [&] { return mine->done; });
-  for (auto it = pool->unwaited.begin(); it != pool->unwaited.end(); ++it) if (it->get() == mine.get()) { pool->unwaited.erase(it); break; }
+  pool->queue.wait_done(mine);
   return mine->worst;
 }
 

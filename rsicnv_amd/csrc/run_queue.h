@@ -1,0 +1,96 @@
+// run_queue.h -- the pool's queue of runs.  Plain C++ (no HIP): tests/sanitize/queue_tsan.cpp drives it from a dozen
+// threads under ThreadSanitizer.
+//
+// A run is one call's worth of items (chromosomes).  Runs queue up in submission order; whoever asks for work gets the next
+// unclaimed item of the OLDEST run that has one, so a worker that finds nothing left in one run starts on the next: consecutive
+// samples overlap, and the last items of a run do not leave the other workers idle.  A run is finished when all of its items
+// have been reported done; `finish(run)` is called once, under the queue's mutex, by the thread that reports the last one,
+// before any waiter of that run wakes up.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace rsip {
+
+struct RunBase {
+  uint64_t id = 0;
+  int nitems = 0;
+  int claimed = 0, completed = 0;   // under the queue's mutex
+  bool done = false;
+};
+
+template <class Run>   // Run derives from RunBase
+struct RunQueue {
+  std::mutex m;
+  std::condition_variable work_cv, done_cv;
+  std::deque<std::shared_ptr<Run>> active;      // runs with unfinished items, oldest first
+  std::vector<std::shared_ptr<Run>> unwaited;   // submitted, wait() not yet returned
+  uint64_t next_id = 1;
+  bool quit = false;
+
+  // under m: the next item to work on, from the oldest run that has one (no younger than `upto`; 0 = any)
+  bool claim_locked(std::shared_ptr<Run>& r, int& k, uint64_t upto) {
+    for (auto& a : active) {
+      if (upto && a->id > upto) break;
+      if (a->claimed < a->nitems) { r = a; k = a->claimed++; return true; }
+    }
+    return false;
+  }
+  // Queues the run and returns its ticket.  `before_publish(run)` runs under the mutex before any worker can see the run.
+  template <class Finish, class Before>
+  uint64_t submit(const std::shared_ptr<Run>& r, Finish&& finish, Before&& before_publish) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      r->id = next_id++;
+      before_publish(*r);
+      unwaited.push_back(r);
+      if (r->nitems == 0) { finish(*r); r->done = true; }
+      else active.push_back(r);
+    }
+    work_cv.notify_all();
+    return r->id;
+  }
+  bool empty_locked() const { return active.empty(); }
+  // Blocks until there is an item to work on (true) or the queue is shut down (false).
+  bool next(std::shared_ptr<Run>& r, int& k) {
+    std::unique_lock<std::mutex> lk(m);
+    work_cv.wait(lk, [&] { return quit || claim_locked(r, k, 0); });
+    return !quit;
+  }
+  // Without blocking: an item of the runs up to `upto`, unless that run is finished already.
+  bool try_next(const std::shared_ptr<Run>& mine, std::shared_ptr<Run>& r, int& k) {
+    std::lock_guard<std::mutex> lk(m);
+    return !mine->done && claim_locked(r, k, mine->id);
+  }
+  // One item of the run has been processed; the last one closes the run.
+  template <class Finish>
+  void item_done(const std::shared_ptr<Run>& r, Finish&& finish) {
+    std::lock_guard<std::mutex> lk(m);
+    if (++r->completed < r->nitems) return;
+    finish(*r);
+    r->done = true;
+    for (auto it = active.begin(); it != active.end(); ++it) if (it->get() == r.get()) { active.erase(it); break; }
+    done_cv.notify_all();
+  }
+  std::shared_ptr<Run> find(uint64_t ticket) {
+    std::lock_guard<std::mutex> lk(m);
+    for (auto& r : unwaited) if (r->id == ticket) return r;
+    return nullptr;
+  }
+  // Blocks until the run is finished; the ticket is spent afterwards.
+  void wait_done(const std::shared_ptr<Run>& mine) {
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return mine->done; });
+    for (auto it = unwaited.begin(); it != unwaited.end(); ++it) if (it->get() == mine.get()) { unwaited.erase(it); break; }
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(m); quit = true; }
+    work_cv.notify_all();
+  }
+};
+
+}  // namespace rsip

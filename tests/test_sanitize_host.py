@@ -44,3 +44,20 @@ def test_pool_gate_under_tsan(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "gate_tsan")], capture_output=True, text=True, timeout=250)
     assert r.returncode == 0 and "gate harness ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
+
+
+@pytest.mark.timeout(300)
+def test_pool_run_queue_under_tsan(tmp_path):
+    """The pool's queue of runs (rsicnv_amd/csrc/run_queue.h: rsi_pool_submit / rsi_pool_wait) under ThreadSanitizer: eleven
+    workers, three clients submitting and waiting out of order and helping while they wait -- every item once, finish once per
+    run and before its waiter returns, no helper on a younger run, no data race."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run(["g++", "-fsanitize=thread", "-x", "c++", "-", "-o", str(tmp_path / "probe")], input=b"int main(){return 0;}",
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ cannot link the ThreadSanitizer runtime here")
+    r = subprocess.run(["make", "-f", "tests/sanitize/Makefile", "tests/sanitize/queue_tsan"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "queue_tsan")], capture_output=True, text=True, timeout=250)
+    assert r.returncode == 0 and "queue harness ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
