@@ -4,6 +4,8 @@
 //   none   nothing else
 //   spin   persistent ALU workgroups (no memory traffic): W workgroups of 256 threads per CU, ~R VGPRs each
 //   stream persistent streaming reads of a large buffer (HBM-bound), W workgroups per CU
+//   write  persistent streaming WRITES of a large buffer (plain stores: the write-back L2 fills with dirty lines)
+//   burst  R threads launching big kernels back to back that cannot share a CU (W KB of LDS each)
 // Prints the mean time per tiny kernel and stream.  Build: hipcc --offload-arch=gfx950 -O2 -o tools/dispatch_probe tools/dispatch_probe.hip -lpthread
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -64,6 +66,19 @@ __global__ __launch_bounds__(256) void k_stream_bg(const uint4* __restrict__ src
   if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<float*>(sink)[8] = (float)iters; reinterpret_cast<float*>(sink)[9] = (float)((wall_clock64() - t0) / 100); }
 }
 
+__global__ __launch_bounds__(256) void k_write_bg(uint4* __restrict__ dst, size_t n16, const volatile int* stop, unsigned int* sink,
+                                                   unsigned long long max_cycles) {
+  unsigned int iters = 0;
+  const unsigned long long t0 = wall_clock64();
+  while (!*stop) {
+    ++iters;
+    const uint4 v = make_uint4(iters, iters + 1, iters + 2, iters + 3);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;   // plain stores: dirty lines in the write-back L2
+    if (wall_clock64() - t0 > max_cycles) break;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<float*>(sink)[8] = (float)iters; reinterpret_cast<float*>(sink)[9] = (float)((wall_clock64() - t0) / 100); }
+}
+
 // one of a series of big kernels: every workgroup holds `lds` bytes of LDS and 768 threads for `ticks` of the 100 MHz clock
 __global__ __launch_bounds__(768) void k_burst(unsigned long long ticks, float* sink) {
   extern __shared__ float s_buf[];
@@ -92,6 +107,9 @@ int main(int argc, char** argv) {
   if (!strcmp(kind, "spin")) {
     if (R <= 32) hipLaunchKernelGGL(k_spin<24>, dim3(256 * W), dim3(256), 0, bg[0], d_stop, d_sink, max_cycles);
     else hipLaunchKernelGGL(k_spin<96>, dim3(256 * W), dim3(256), 0, bg[0], d_stop, d_sink, max_cycles);
+  } else if (!strcmp(kind, "write")) {
+    CHK(hipMalloc(&d_big, big)); CHK(hipMemset(d_big, 1, big));
+    hipLaunchKernelGGL(k_write_bg, dim3(256 * W), dim3(256), 0, bg[0], d_big, big / 16, d_stop, reinterpret_cast<unsigned int*>(d_sink), max_cycles);
   } else if (!strcmp(kind, "stream")) {
     CHK(hipMalloc(&d_big, big)); CHK(hipMemset(d_big, 1, big));
     hipLaunchKernelGGL(k_stream_bg, dim3(256 * W), dim3(256), 0, bg[0], d_big, big / 16, d_stop, reinterpret_cast<unsigned int*>(d_sink), max_cycles);
@@ -151,6 +169,6 @@ int main(int argc, char** argv) {
   printf("background %-6s W=%d R=%d | %2d streams x %d %s: %.1f us per kernel and stream (slowest stream %.1f)\n", kind, W, R, S, N,
          fg_wgs > 0 ? "reductions" : "tiny kernels", mean, worst);
   if (strcmp(kind, "none") && strcmp(kind, "burst")) printf("    background workgroup 0: %.0f loop trips in %.0f us%s\n", bgstat[0], bgstat[1],
-                                   !strcmp(kind, "stream") ? " (one trip = the 4 GB buffer once)" : "");
+                                   (!strcmp(kind, "stream") || !strcmp(kind, "write")) ? " (one trip = the 4 GB buffer once)" : "");
   return 0;
 }
