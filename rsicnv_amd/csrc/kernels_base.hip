@@ -970,40 +970,51 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   const unsigned int* t_ecnt = tot + kJTotH + (kJOffEscCnt - kJPacked);
   const unsigned int* t_flags = tot + kJTotH + (kJOffFlags - kJPacked);
   const unsigned long long* t_esum = reinterpret_cast<const unsigned long long*>(tot + kJTotH + (kJOffEscSum - kJPacked));
-  // ---- row sums of H (count, sum of depths per level) and the largest depth byte present: every thread takes quads of four
-  // cells, eight loads in flight ----
+  // ---- H into registers, once: row g (256 cells) is one 16-byte quad per lane, every wave takes rows wave, wave + 12, ...
+  // (seventeen loads per lane, eight in flight).  Row sums (count, sum of depths per level) and the largest depth byte present
+  // are wave reductions -- 64-bit LDS atomics from every quad were 20 of the tail's 55 us -- and the rows stay in registers for
+  // the pass behind the table, which needs them again. ----
   __shared__ unsigned int s_vmax, s_gmin, s_gmax;
   if (threadIdx.x == 0) { s_vmax = 0u; s_gmin = 0xffffffffu; s_gmax = 0u; }
   __syncthreads();
   const unsigned long long tot_base = uniform_address(tot);
-  constexpr int kQuads = kJTotH / 4;                                   // 12928
-  constexpr int kBatches = (kQuads + 8 * kJThreads - 1) / (8 * kJThreads);   // 3
-  auto for_quads = [&](auto&& body) {
-    for (int b = 0; b < kBatches; ++b) {
-      unsigned int off[8];
-      u32x4 v[8];
+  constexpr int kRowsPerWave = (kGcLevels + kJWaves - 1) / kJWaves;   // 17
+  constexpr int kRowBatches = (kRowsPerWave + 7) / 8;                 // 3
+  u32x4 rowq[kRowBatches * 8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int q = (b * 8 + j) * kJThreads + (int)threadIdx.x; off[j] = (unsigned int)(q < kQuads ? q : 0) * 16u; }
-      ld_cg_x4_batch8(v, tot_base, off);
+  for (int b = 0; b < kRowBatches; ++b) {
+    unsigned int off[8];
+    u32x4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int q = (b * 8 + j) * kJThreads + (int)threadIdx.x;
-        if (q < kQuads) body(q, v[j]);
+    for (int j = 0; j < 8; ++j) { const int g = wave + (b * 8 + j) * kJWaves; off[j] = (unsigned int)((g < kGcLevels ? g : 0) * 256 + 4 * lane) * 4u; }
+    ld_cg_x4_batch8(v, tot_base, off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rowq[b * 8 + j] = v[j];
+  }
+  {
+    unsigned int wave_top = 0;
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; ++k) {
+      const int g = wave + k * kJWaves;
+      if (g >= kGcLevels) continue;                       // wave-uniform
+      const unsigned int c[4] = {rowq[k].x, rowq[k].y, rowq[k].z, rowq[k].w};
+      const int v0 = 4 * lane;
+      unsigned int cs = c[0] + c[1] + c[2] + c[3];          // a level holds fewer than 2^31 bases
+      unsigned long long vs = 0;
+      unsigned int top = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { vs += (unsigned long long)c[j] * (unsigned long long)(v0 + j); top = c[j] ? (unsigned int)(v0 + j) : top; }
+      for (int d = 32; d >= 1; d >>= 1) {
+        cs += (unsigned int)__shfl_xor((int)cs, d);
+        vs += (unsigned long long)__shfl_xor((long long)vs, d);
+        const unsigned int o = (unsigned int)__shfl_xor((int)top, d);
+        top = o > top ? o : top;
       }
+      if (lane == 0) { r_cnt[g] = cs; r_sum[g] = vs; }
+      wave_top = top > wave_top ? top : wave_top;
     }
-  };
-  for_quads([&](int q, u32x4 c4) {
-    const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
-    const unsigned int any = c[0] | c[1] | c[2] | c[3];
-    if (!any) return;
-    const int g = (4 * q) >> 8, v0 = (4 * q) & 255;
-    unsigned long long cs = 0, vs = 0;
-    int top = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { cs += c[k]; vs += (unsigned long long)c[k] * (unsigned long long)(v0 + k); top = c[k] ? v0 + k : top; }
-    atomicAdd(&r_cnt[g], cs); atomicAdd(&r_sum[g], vs);
-    atomicMax(&s_vmax, (unsigned int)top);
-  });
+    if (lane == 0 && wave_top) atomicMax(&s_vmax, wave_top);
+  }
   __syncthreads();
   for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
     const unsigned long long z = ld_cg(t_zero + g), ec = ld_cg(t_ecnt + g), es = ld_cg(t_esum + g);
@@ -1070,22 +1081,37 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   unsigned int* r_bad = reinterpret_cast<unsigned int*>(r_hist + kJRh);   // [202]
   for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) r_bad[g] = 0u;
   __syncthreads();
-  for (int q = threadIdx.x; q < kGcLevels * 64; q += kJThreads) {
-    const int g = q >> 6, v0 = (q & 63) * 4;
-    if (r_cnt[g] == 0) continue;
-    const double ratio = rdmean / r_tab[g];
+  // ---- one pass over the rows in registers: the reference's expression once per (level, depth byte) cell, compared with the
+  // fixed-point form (every depth byte of every level that occurs) and, where the cell is not empty, counted into the histogram
+  // of the rescaled depth ----
+  unsigned int lane_hi = 0;
+  auto count_value = [&](int r, unsigned int c) {
+    if (r >= 0 && r < kJRh) atomicAdd(&r_hist[r], c);
+    else if (r >= 0 && r < kHistValues) { atomicAdd(&ghist[r], c); lane_hi = (unsigned)r > lane_hi ? (unsigned)r : lane_hi; }
+    else if (r < 0) atomicOr(&aux->negatives, 1u);
+    else { atomicAdd(&aux->big, (unsigned long long)c); lane_hi = 0xffffffffu; }
+  };
+#pragma unroll
+  for (int k = 0; k < kRowsPerWave; ++k) {
+    const int g = wave + k * kJWaves;
+    if (g >= kGcLevels || r_cnt[g] == 0) continue;        // wave-uniform
+    const unsigned int c[4] = {rowq[k].x, rowq[k].y, rowq[k].z, rowq[k].w};
+    const double tg = r_tab[g];
+    const double ratio = rdmean / tg;
     bool bad = !(ratio < kFixMaxRatio);
     const unsigned int R = bad ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (v0 + k >= kByteEscape) continue;
-      int r = (int)((double)(v0 + k) * rdmean / r_tab[g] + 0.5);   // gccontent.cpp:89, truncation
-      r = r > kByteSat ? kByteSat : r;
-      unsigned int f = ((unsigned int)(v0 + k) * R + (1u << (kFixShift - 1))) >> kFixShift;
+    for (int j = 0; j < 4; ++j) {
+      const int v = 4 * lane + j;
+      if (v >= kByteEscape) continue;
+      const int r = (int)((double)v * rdmean / tg + 0.5);   // gccontent.cpp:89, truncation
+      const int rs = r > kByteSat ? kByteSat : r;
+      unsigned int f = ((unsigned int)v * R + (1u << (kFixShift - 1))) >> kFixShift;
       f = f > (unsigned int)kByteSat ? (unsigned int)kByteSat : f;
-      bad = bad || f != (unsigned int)r;
+      bad = bad || f != (unsigned int)rs;
+      if (c[j]) count_value(r, c[j]);
     }
-    if (bad) atomicOr(&r_bad[g], 1u);
+    if (__ballot(bad) != 0ull && lane == 0) r_bad[g] = 1u;   // the row's only writer
   }
   __syncthreads();
   for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
@@ -1093,22 +1119,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     const bool wide = !(ratio < kFixMaxRatio);
     rtab[g] = (wide ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5)) | ((r_bad[g] || wide || r_cnt[g] == 0) ? 0x80000000u : 0u);
   }
-  // ---- histogram of the rescaled depth from H: every (level, value) cell once ----
   {
-    unsigned int lane_hi = 0;
-    auto count_value = [&](int r, unsigned int c) {
-      if (r >= 0 && r < kJRh) atomicAdd(&r_hist[r], c);
-      else if (r >= 0 && r < kHistValues) { atomicAdd(&ghist[r], c); lane_hi = (unsigned)r > lane_hi ? (unsigned)r : lane_hi; }
-      else if (r < 0) atomicOr(&aux->negatives, 1u);
-      else { atomicAdd(&aux->big, (unsigned long long)c); lane_hi = 0xffffffffu; }
-    };
-    for_quads([&](int q, u32x4 c4) {
-      const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
-      if (!(c[0] | c[1] | c[2] | c[3])) return;
-      const int g = (4 * q) >> 8, v0 = (4 * q) & 255;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if (c[k]) count_value((int)((double)(v0 + k) * rdmean / r_tab[g] + 0.5), c[k]);   // gccontent.cpp:89, truncation
-    });
     for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) { const unsigned int z = ld_cg(t_zero + g); if (z) atomicAdd(&r_hist[0], z); }   // (int)(0 * ratio + 0.5) = 0
     // the escapes the workgroups listed by position: the reference's expression on the int32 depth, window by the clamped rule
     if (s_esc_total != 0u && !esc_pending) {
