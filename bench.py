@@ -201,6 +201,7 @@ def main():
     slots = threading.Semaphore(max(1, args.inflight))
 
     def post_worker():
+        torch.cuda.set_device(dev)   # a new thread starts on device 0: the gather's tensors and RCCL's streams belong to this rank's GPU
         while True:
             item = post_q.get()
             try:
