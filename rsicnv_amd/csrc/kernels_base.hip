@@ -30,6 +30,21 @@ __device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
   return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
 }
 
+
+// Sum over the 2, 4, 8 or 16 consecutive lanes that share a bin (the median phases of K4' / K4j): neighbours at distance 1 and 2
+// through DPP quad permutes -- one VALU instruction each -- instead of ds_bpermute, which goes through the LDS pipeline and whose
+// latency sat seven times two deep in every bin's bisection.
+__device__ inline int dpp_xor1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }   // quad_perm [1, 0, 3, 2]
+__device__ inline int dpp_xor2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); }   // quad_perm [2, 3, 0, 1]
+__device__ inline int parts_sum(int x, int parts) {
+  x += dpp_xor1(x);
+  if (parts > 2) x += dpp_xor2(x);
+  for (int d = 4; d < parts; d <<= 1) x += __shfl_xor(x, d);
+  return x;
+}
+__device__ inline uint64_t dpp_xor1_u64(uint64_t x) { return (uint64_t)(uint32_t)dpp_xor1((int)(uint32_t)x) | ((uint64_t)(uint32_t)dpp_xor1((int)(uint32_t)(x >> 32)) << 32); }
+__device__ inline uint64_t dpp_xor2_u64(uint64_t x) { return (uint64_t)(uint32_t)dpp_xor2((int)(uint32_t)x) | ((uint64_t)(uint32_t)dpp_xor2((int)(uint32_t)(x >> 32)) << 32); }
+
 // ------------------------------------------------------------------------------------------
 // K1  fasta_classify: one thread per 16 bytes; 4 neighbouring lanes assemble one 64-bit word.
 __global__ __launch_bounds__(kThreads) void k_fasta_classify(const uint8_t* __restrict__ fasta, int64_t n,
@@ -57,8 +72,8 @@ __global__ __launch_bounds__(kThreads) void k_fasta_classify(const uint8_t* __re
     const int sub = (int)(g & 3);
     uint64_t vg = (uint64_t)mg << (16 * sub), vn = (uint64_t)mn << (16 * sub);
     // the 4 lanes of a word are adjacent lanes of one wave (g is contiguous in threadIdx.x)
-    vg |= __shfl_xor(vg, 1); vg |= __shfl_xor(vg, 2);
-    vn |= __shfl_xor(vn, 1); vn |= __shfl_xor(vn, 2);
+    vg |= dpp_xor1_u64(vg); vg |= dpp_xor2_u64(vg);   // (quad permutes: one VALU instruction per half instead of a trip through the LDS pipeline)
+    vn |= dpp_xor1_u64(vn); vn |= dpp_xor2_u64(vn);
     if (sub == 0) { gcbits[g >> 2] = vg; nbits[g >> 2] = vn; }
   }
 }
@@ -1635,7 +1650,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
         int c = 0;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) c += r[i] <= mid;
-        for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
+        c = parts_sum(c, parts);
         if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
       }
     } else {
@@ -1649,7 +1664,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
         const int mid = (int)(((long long)lo + (long long)hi) >> 1);
         int c = 0;
         if (active && lo < hi) for (int j = part; j < m; j += parts) c += x[j] <= mid;
-        for (int d = 1; d < parts; d <<= 1) c += __shfl_xor(c, d);
+        c = parts_sum(c, parts);
         if (active && lo < hi) { if (c >= kth) hi = mid; else lo = mid + 1; }
       }
     }
@@ -1861,7 +1876,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
         ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
         xo[i] = (v | ~keep) | 0x80808080u;
       }
-      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      ssum = (uint32_t)parts_sum((int)ssum, parts);
       int lo = 0, hi = capval;
 #pragma unroll 1
       for (int it = 0; it < 7; ++it) {
@@ -1870,7 +1885,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xo[i] - sub) & 0x80808080u);
-        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        gt = parts_sum(gt, parts);
         // masked bytes (0xff) always count as "> mid" (mid <= 126): 28 dword slots x 4 bytes - m of them per bin
         const int le = 4 * 7 * parts - gt;
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
@@ -1899,7 +1914,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
         xa[i] = (xb & 0x00ff00ffu) | 0x80008000u;
         xc[i] = ((xb >> 8) & 0x00ff00ffu) | 0x80008000u;
       }
-      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      ssum = (uint32_t)parts_sum((int)ssum, parts);
       int lo = 0, hi = capval;
 #pragma unroll 1
       for (int it = 0; it < 8; ++it) {
@@ -1908,7 +1923,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xa[i] - sub) & 0x80008000u) + __popc((xc[i] - sub) & 0x80008000u);
-        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        gt = parts_sum(gt, parts);
         const int le = 4 * 7 * parts - gt;   // masked bytes (0xff) always count as "> mid" (mid <= 252)
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
       }
@@ -2142,7 +2157,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         ssum = __builtin_amdgcn_sad_u8(v & keep, 0u, ssum);
         xo[i] = (v | ~keep) | 0x80808080u;
       }
-      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      ssum = (uint32_t)parts_sum((int)ssum, parts);
       int lo = 0, hi = capval;
 #pragma unroll 1
       for (int it = 0; it < 7; ++it) {
@@ -2151,7 +2166,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xo[i] - sub) & 0x80808080u);
-        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        gt = parts_sum(gt, parts);
         // masked bytes (0xff) always count as "> mid" (mid <= 126): 28 dword slots x 4 bytes - m of them per bin
         const int le = 4 * 7 * parts - gt;
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
@@ -2180,7 +2195,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         xa[i] = (xb & 0x00ff00ffu) | 0x80008000u;
         xc[i] = ((xb >> 8) & 0x00ff00ffu) | 0x80008000u;
       }
-      for (int d = 1; d < parts; d <<= 1) ssum += __shfl_xor(ssum, d);
+      ssum = (uint32_t)parts_sum((int)ssum, parts);
       int lo = 0, hi = capval;
 #pragma unroll 1
       for (int it = 0; it < 8; ++it) {
@@ -2189,7 +2204,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xa[i] - sub) & 0x80008000u) + __popc((xc[i] - sub) & 0x80008000u);
-        for (int d = 1; d < parts; d <<= 1) gt += __shfl_xor(gt, d);
+        gt = parts_sum(gt, parts);
         const int le = 4 * 7 * parts - gt;   // masked bytes (0xff) always count as "> mid" (mid <= 252)
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
       }
