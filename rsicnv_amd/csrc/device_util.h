@@ -71,6 +71,35 @@ __device__ inline unsigned int ld_cg(const unsigned int* p) { return __hip_atomi
 __device__ inline unsigned long long ld_cg(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline int ld_cg(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Inclusive prefix sum over the 64 lanes of a wave without the LDS pipeline (`__shfl_up` compiles to ds_bpermute: a round trip
+// through the LDS crossbar per step): four row shifts inside the rows of 16 lanes, then lane 15 of each row into the next row and
+// lane 31 into the upper half -- six DPP moves.  Integer sums only (the association differs from the shuffle form).  All 64
+// lanes must be active.
+__device__ inline int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1, zeros shifted in
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+template <int CTRL, int ROWS, bool BOUND>
+__device__ inline long long dpp_move_i64(long long x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)x, CTRL, ROWS, 0xF, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)((unsigned long long)x >> 32), CTRL, ROWS, 0xF, BOUND);
+  return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ inline long long wave_incl_scan(long long x) {
+  x += dpp_move_i64<0x111, 0xF, true>(x);
+  x += dpp_move_i64<0x112, 0xF, true>(x);
+  x += dpp_move_i64<0x114, 0xF, true>(x);
+  x += dpp_move_i64<0x118, 0xF, true>(x);
+  x += dpp_move_i64<0x142, 0xA, false>(x);
+  x += dpp_move_i64<0x143, 0xC, false>(x);
+  return x;
+}
+
 // True in exactly one workgroup of a 1-D launch: the one that arrives last, after every other workgroup's global writes
 // and atomics are visible.  *counter must be zero before the launch and is zero again afterwards.  All threads of every
 // workgroup must call it (it synchronises the workgroup).

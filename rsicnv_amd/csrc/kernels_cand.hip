@@ -33,8 +33,7 @@ __device__ inline T block_reduce(T v, Op op, T* s_tmp /* kMaxWaves */) {
 }
 // exclusive prefix of one int per thread; returns the thread's offset, *total = sum over the block
 __device__ inline int block_exscan(int v, int* s_tmp /* kMaxWaves */, int* total) {
-  int incl = v;
-  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane_id() >= d) incl += up; }
+  const int incl = wave_incl_scan(v);
   __syncthreads();
   if (lane_id() == 63) s_tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
@@ -51,8 +50,7 @@ __device__ inline void block_prefix_i64(long long* __restrict__ P, int len, F f,
 
 // exclusive prefix of one int64 per thread over the block; *total = block sum
 __device__ inline long long block_exscan_i64(long long v, long long* s_tmp /* kMaxWaves */, long long* total) {
-  long long incl = v;
-  for (int d = 1; d < 64; d <<= 1) { const long long up = __shfl_up(incl, d); if (lane_id() >= d) incl += up; }
+  const long long incl = wave_incl_scan(v);
   __syncthreads();
   if (lane_id() == 63) s_tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
@@ -303,8 +301,7 @@ __device__ inline int gather_side(const TD* __restrict__ A, int64_t N, int dir, 
         if (!ext && !inside) { accm |= 1u << j; ++nacc; }
       }
     }
-    int incl = nacc, wtrig = trig;
-    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    int incl = wave_incl_scan(nacc), wtrig = trig;
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(wtrig, d); wtrig = o < wtrig ? o : wtrig; }
     if (lane == 63) W.cnt[par][wave] = incl;
     if (lane == 0) W.trg[par][wave] = wtrig;
@@ -526,10 +523,7 @@ __global__ __launch_bounds__(kTestThreads) void k_candidate_test(const TD* __res
       // named variables only: a runtime-indexed array would live in scratch memory
       auto quad = [](const int4& v) { return (long long)v.x + v.y + v.z + v.w; };
       long long i0 = quad(v0), i1 = quad(v1), i2 = quad(v2), i3 = quad(v3);   // inclusive wave scans of the quad sums
-      for (int d = 1; d < 64; d <<= 1) {
-        const long long u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d), u3 = __shfl_up(i3, d);
-        if (lane >= d) { i0 += u0; i1 += u1; i2 += u2; i3 += u3; }
-      }
+      i0 = wave_incl_scan(i0); i1 = wave_incl_scan(i1); i2 = wave_incl_scan(i2); i3 = wave_incl_scan(i3);   // DPP: no LDS round trips
       long long* X = s_x[par];   // [4][kMaxWaves] wave totals
       if (lane == 63) { X[wave] = i0; X[kMaxWaves + wave] = i1; X[2 * kMaxWaves + wave] = i2; X[3 * kMaxWaves + wave] = i3; }
       __syncthreads();
