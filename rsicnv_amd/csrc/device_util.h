@@ -100,6 +100,25 @@ __device__ inline long long wave_incl_scan(long long x) {
   return x;
 }
 
+// The same for doubles (the scan kernels' tile prefixes: sums that are exact in double, so the association does not matter), and
+// the value of lane 63 through v_readlane instead of a shuffle.
+__device__ inline double wave_incl_scan(double x) {
+  x += __longlong_as_double(dpp_move_i64<0x111, 0xF, true>(__double_as_longlong(x)));
+  x += __longlong_as_double(dpp_move_i64<0x112, 0xF, true>(__double_as_longlong(x)));
+  x += __longlong_as_double(dpp_move_i64<0x114, 0xF, true>(__double_as_longlong(x)));
+  x += __longlong_as_double(dpp_move_i64<0x118, 0xF, true>(__double_as_longlong(x)));
+  x += __longlong_as_double(dpp_move_i64<0x142, 0xA, false>(__double_as_longlong(x)));
+  x += __longlong_as_double(dpp_move_i64<0x143, 0xC, false>(__double_as_longlong(x)));
+  return x;
+}
+__device__ inline int wave_lane63(int x) { return __builtin_amdgcn_readlane(x, 63); }
+__device__ inline double wave_lane63(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)b, 63);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)b >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // True in exactly one workgroup of a 1-D launch: the one that arrives last, after every other workgroup's global writes
 // and atomics are visible.  *counter must be zero before the launch and is zero again afterwards.  All threads of every
 // workgroup must call it (it synchronises the workgroup).

@@ -609,10 +609,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_detect(const float* __restric
     for (int k = 0; k < kThreads / 64; ++k) {
       const int idx = k * 64 + threadIdx.x;
       const double mine = s_tot[idx];
-      double incl = mine;
-      for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
+      const double incl = wave_incl_scan(mine);   // DPP: the sums are exact in double, the association does not matter
       s_tot[idx] = carry + incl - mine;
-      carry += __shfl(incl, 63);
+      carry += wave_lane63(incl);
     }
   }
   __syncthreads();
@@ -776,25 +775,14 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
       for (int k = 0; k < kThreads / 64; ++k) {
         const int idx = k * 64 + threadIdx.x;
         const double mine = S.tot[idx];
-        double incl = mine;
+        const double incl = wave_incl_scan(mine);   // DPP row shifts and broadcasts: no trips through the LDS crossbar
         int m4[4], i4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { m4[q] = s_c[q][idx]; i4[q] = m4[q]; }
-        for (int d = 1; d < 64; d <<= 1) {
-          const double up = __shfl_up(incl, d);
-          int u4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) u4[q] = __shfl_up(i4[q], d);
-          if ((int)threadIdx.x >= d) {
-            incl += up;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) i4[q] += u4[q];
-          }
-        }
+        for (int q = 0; q < 4; ++q) { m4[q] = s_c[q][idx]; i4[q] = wave_incl_scan(m4[q]); }
         S.tot[idx] = carry + incl - mine;
-        carry += __shfl(incl, 63);
+        carry += wave_lane63(incl);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += __shfl(i4[q], 63); }
+        for (int q = 0; q < 4; ++q) { s_c[q][idx] = car[q] + i4[q] - m4[q]; car[q] += wave_lane63(i4[q]); }
       }
     }
     tile_sync();
@@ -1034,10 +1022,9 @@ __global__ __launch_bounds__(kThreads) void k_run_prefix(const float* __restrict
     double carry = 0.0;
     for (int k = 0; k < kThreads / 64; ++k) {
       const double mine = s_tot[k * 64 + threadIdx.x];
-      double incl = mine;
-      for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
+      const double incl = wave_incl_scan(mine);
       s_tot[k * 64 + threadIdx.x] = carry + incl - mine;
-      carry += __shfl(incl, 63);
+      carry += wave_lane63(incl);
     }
   }
   __syncthreads();
