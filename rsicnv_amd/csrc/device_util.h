@@ -111,6 +111,22 @@ __device__ inline double wave_incl_scan(double x) {
   x += __longlong_as_double(dpp_move_i64<0x143, 0xC, false>(__double_as_longlong(x)));
   return x;
 }
+// Wave-wide maximum of unsigned values the same way (zeros shifted in are the identity); the result is in lane 63.
+__device__ inline unsigned int wave_incl_max(unsigned int x) {
+  auto mx = [](unsigned int a, int b) { return (unsigned int)b > a ? (unsigned int)b : a; };
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+  return x;
+}
+__device__ inline long long wave_lane63(long long x) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)x, 63);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)x >> 32), 63);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ inline int wave_lane63(int x) { return __builtin_amdgcn_readlane(x, 63); }
 __device__ inline double wave_lane63(double x) {
   const long long b = __double_as_longlong(x);

@@ -1019,12 +1019,10 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
       unsigned int top = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { vs += (unsigned long long)c[j] * (unsigned long long)(v0 + j); top = c[j] ? (unsigned int)(v0 + j) : top; }
-      for (int d = 32; d >= 1; d >>= 1) {
-        cs += (unsigned int)__shfl_xor((int)cs, d);
-        vs += (unsigned long long)__shfl_xor((long long)vs, d);
-        const unsigned int o = (unsigned int)__shfl_xor((int)top, d);
-        top = o > top ? o : top;
-      }
+      // wave totals in lane 63 (DPP scans: no trips through the LDS crossbar in this one-workgroup tail)
+      cs = (unsigned int)wave_lane63(wave_incl_scan((int)cs));
+      vs = (unsigned long long)wave_lane63(wave_incl_scan((long long)vs));
+      top = (unsigned int)wave_lane63((int)wave_incl_max(top));
       if (lane == 0) { r_cnt[g] = cs; r_sum[g] = vs; }
       wave_top = top > wave_top ? top : wave_top;
     }
