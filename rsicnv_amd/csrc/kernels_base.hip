@@ -2058,16 +2058,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         bool redo = esc;
         int v[16];
         if (FIX) {
-          // The GC count of base j is cnt + #(entering bits below j) - #(leaving bits below j): sixteen independent expressions
-          // (two masked popcounts each) instead of a chain of sixteen updates -- the sixteen ratio lookups can all be issued at once
           unsigned int flags = 0;
-          unsigned int R[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) R[j] = s_rt[cnt + __popc(enter & ((1u << j) - 1u)) - __popc(leave & ((1u << j) - 1u))];
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            flags |= R[j];
-            v[j] = (int)((__umul24((w4[j >> 2] >> (8 * (j & 3))) & 0xffu, R[j]) + (1u << (kFixShift - 1))) >> kFixShift);   // the multiply looks at R's low 24 bits only
+            const unsigned int R = s_rt[cnt];
+            flags |= R;
+            v[j] = (int)((__umul24((w4[j >> 2] >> (8 * (j & 3))) & 0xffu, R) + (1u << (kFixShift - 1))) >> kFixShift);   // the multiply looks at R's low 24 bits only
+            cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
           }
           redo = redo || (int)flags < 0;
         } else if (!esc) {
