@@ -13,7 +13,7 @@ import numpy as np
 # GPU_MAX_HW_QUEUES hardware queues (default 4); with a dozen streams that puts unrelated chromosomes
 # in line behind each other's kernels (measured: ~10 % of the genome rate).  The variable is read when
 # the HIP runtime initialises, so it has to be in the environment before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RSI_HOT_LIB: another build of the same ABI (A/B measurements of library versions, tools/ab_bench.py)

@@ -276,6 +276,9 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
 }  // namespace
 
 int main(int argc, char** argv) {
+  // one hardware queue per stream of a pool (the runtime's default of 4 puts unrelated chromosomes in line behind each other);
+  // read when the HIP runtime initialises, so it has to be set before the first HIP call; the caller's own setting wins
+  setenv("GPU_MAX_HW_QUEUES", "32", 0);
   Options o;
   parse(argc, argv, o);
   if (o.function != "rsi") {
