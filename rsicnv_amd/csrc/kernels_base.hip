@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
 // Per value: cap, LDS store, one LDS atomic into the [value][MAD residue class] histogram.
 // Sum / sum of squares / median of the chromosome are all derived from that histogram on the host.
 struct __attribute__((packed, aligned(4))) Quad4 { int x, y, z, w; };   // 16 bytes, dword-aligned
-constexpr int kRegLds = 256;   // removed regions mirrored in LDS (the list is short; more stay in HBM)
+constexpr int kRegLds = 128;   // removed regions mirrored in LDS (the list is short; more stay in HBM; 128: K4j keeps four workgroups per CU with its 24 KB histogram)
 
 struct RegionTable {
   const int64_t* cbreak; const int64_t* cum; int nreg;
@@ -1941,6 +1941,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
 // FIX: the rescale is (byte * R[level] + 2^15) >> 16 with K2j's per-level 16.16 ratios, each verified there against the
 // reference's expression for every depth byte; a level that failed the check carries bit 31 and its lane takes the exact
 // expression.  Without (a chromosome that went through K2 + K3'): the float form with its exactness margin (rescale_f32).
+constexpr int kK4jCols = 48;   // columns of K4j's LDS histogram (see there)
 template <int MAXC, int EPT, bool SW7, bool FIX>
 __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
     const uint8_t* __restrict__ d8 /* K2j's byte copy of the raw depth (kByteEscape = look at the int32 array) */, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
@@ -1954,7 +1955,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
                                    K2j without the host in between; the launch configuration (vr, SW7) was a guess to be checked here */) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
-  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
+  // [vr][kK4jCols]: columns 0 .. 30 the MAD residue classes, 31 .. 46 classes 0 .. 15 AGAIN (a lane's sixteen consecutive classes
+  // then never wrap: no per-base select between two row pointers), 47 the class of the bases behind the last full stride of 31;
+  // folded back to [vr][32] when the slab is written
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);
+  const int cols = vr <= 128 ? kK4jCols : kResClasses;   // a 256-value range keeps the plain 32 columns (48 KB otherwise: a workgroup per CU less)
   __shared__ unsigned int s_rt[kGcLevels];   // FIX: the levels' fixed-point ratios
   if (pp) {
     nreg = pp->nreg; ncompact = pp->ncompact; capval = pp->capval;
@@ -1968,7 +1973,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
   __shared__ float s_ratio[kGcLevels];    // rdmean / table[g] as float (rescale_f32)
   __shared__ uint64_t s_gw[kK4GcWords];   // GC mask words under the tile's source range (+ margins), staged per tile
   __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < vr * cols; e += kThreads) s_hist[e] = 0;
   for (int e = threadIdx.x; e < kGcLevels; e += kThreads) { const double t = table[e]; s_table[e] = t; s_ratio[e] = (float)(table[kGcLevels] / t); }
   if (FIX) for (int e = threadIdx.x; e < kGcLevels; e += kThreads) s_rt[e] = rtab[e];
   if (nreg <= kRegInline && !pp) {
@@ -2081,11 +2086,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
           for (int j = 0; j < 16; ++j) {
             const int x = esc ? depth[p + j] : (int)((w4[j >> 2] >> (8 * (j & 3))) & 0xffu);
             v[j] = rescale(x, cnt);
+            v[j] = v[j] < 0 ? 0 : v[j];   // an escaped depth is any int32 (negative ones are refused by the caller, K2j's flag)
             cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
           }
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const int x = v[j] < 0 ? 0 : v[j]; v[j] = x > capval ? capval : x; }
+        for (int j = 0; j < 16; ++j) v[j] = v[j] > capval ? capval : v[j];   // (never negative: depth bytes and ratios are not)
         uint32_t pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
@@ -2095,10 +2101,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         // wrap point on; the element index rides in the instruction's offset field
         const uint32_t cls0 = (p0mod + 16u * (uint32_t)kc) % 31u;
         unsigned int* ha = s_hist + cls0;
-        unsigned int* hb = ha - 31;
-        const int jw = 31 - (int)cls0;
+        if (cols == kK4jCols) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) atomicAdd((j >= jw ? hb : ha) + v[j] * kResClasses + j, 1u);
+          for (int j = 0; j < 16; ++j) atomicAdd(ha + v[j] * kK4jCols + j, 1u);   // column cls0 + j <= 45
+        } else {   // 32 columns: minus 31 from the lane's wrap point on
+          unsigned int* hb = ha - 31;
+          const int jw = 31 - (int)cls0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) atomicAdd((j >= jw ? hb : ha) + v[j] * kResClasses + j, 1u);
+        }
       }
     } else {
       // ---- per-element path: contiguous source segments between removed regions, values from the int32 array ----
@@ -2117,7 +2128,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
             s_val[dst + e] = (unsigned char)x;
             rdc8[seg + e] = (unsigned char)x;
             const int64_t p = seg + e;
-            atomicAdd(&s_hist[x * kResClasses + (p < lim31 ? (int)((uint32_t)p % 31u) : 31)], 1u);
+            atomicAdd(&s_hist[x * cols + (p < lim31 ? (int)((uint32_t)p % 31u) : cols - 1)], 1u);
           }
         }
         seg = nxt;
@@ -2213,7 +2224,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
   // ---- per-workgroup histogram slab; the last workgroup folds them into res_hist (every value is below vr: overwrite)
   // and hands [BinAccum | histogram] to the host ----
   unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
+  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) {
+    const unsigned int* row = s_hist + (e >> 5) * cols;
+    const int c = e & 31;
+    st_cg(&slab[e], cols == kResClasses ? row[c] : (c == 31 ? row[kK4jCols - 1] : row[c] + (c < 16 ? row[31 + c] : 0u)));
+  }
   // res_hist is zero when the launch begins (K1's FillList): the groups' sums go straight into it
   if (!fold_slabs_add(hist_slabs, res_hist, vr * kResClasses, per_group, counters)) return;
   export_words(exp_dst, exp_src, exp_bytes);
@@ -2409,7 +2424,7 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
   int vr, grid, maxc;
   k48_geometry(m, capval, ncompact, vr, grid, maxc);   // pp != NULL: capval is the caller's guess (it fixes vr and SW7), ncompact an upper bound
   const int TB = k48_bins_per_tile(m);
-  const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
+  const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * (vr <= 128 ? kK4jCols : kResClasses) * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
   const int pg = fold_per_group(grid);
