@@ -220,7 +220,7 @@ void rsi_hot_set_timing_kernel(rsi_ctx* ctx, const char* name);
  * The reference's per-chromosome loop (rsi.cpp:2189-2217) has independent iterations.  A pool owns
  * `nworkers` host threads (created with the pool, asleep while no run is queued; worker 0 is a thread waiting for a run),
  * each with its own context (stream + workspace); the chromosomes of a run are handed out longest first.  Runs may be queued
- * (rsi_pool_submit / rsi_pool_wait below) and are worked on in submission order; several pools (one per GPU) are independent.  At most two HBM-bound
+ * (rsi_pool_submit / rsi_pool_wait below) and are worked on in submission order; several pools (one per GPU) are independent.  At most three HBM-bound
  * per-base phases are in flight per GPU (rsi_pool_set_schedule); bin-level and candidate kernels,
  * copies and the host stages of different chromosomes overlap. */
 typedef struct rsi_pool rsi_pool;

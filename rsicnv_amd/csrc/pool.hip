@@ -1,6 +1,6 @@
 // pool.hip -- several chromosomes at once on one GPU (the reference's loop over chromosomes, rsi.cpp:2189-2217, whose
 // iterations are independent): `nworkers` host threads, each with its own context (stream + workspace), the gate that
-// lets at most two per-base phases stream at a time, and a queue of runs (samples) whose chromosomes the workers take in
+// lets at most three per-base phases stream at a time, and a queue of runs (samples) whose chromosomes the workers take in
 // submission order.
 #include "pipeline_internal.h"
 #include "run_queue.h"
