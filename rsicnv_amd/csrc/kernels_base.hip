@@ -1491,8 +1491,8 @@ struct RegionTable {
 };
 
 // rare path (values outside the LDS range, partial quads): kept out of line
-__device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int vb, int x, int cls) {
-  if (x >= vb && x - vb < vr) atomicAdd(&s_hist[(x - vb) * kResClasses + cls], 1u);
+__device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int vb, int x, int cls, int pack16) {
+  if (x >= vb && x - vb < vr) { const int idx = (x - vb) * kResClasses + cls; if (pack16) atomicAdd(&s_hist[idx >> 1], 1u << ((idx & 1) << 4)); else atomicAdd(&s_hist[idx], 1u); }
   else if (x >= 0 && x < kHistValues) atomicAdd(&res_hist[(size_t)x * kResClasses + cls], 1u);
   else { atomicAdd(&acc->big, 1ull); atomicMax(&acc->vmax, (unsigned int)x); }
 }
@@ -1506,14 +1506,17 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     int vb /* first value of the LDS histogram's window: 0 unless the coverage is deep (k4_window_base) */, int32_t* __restrict__ rdc, int32_t* __restrict__ binmed, int64_t* __restrict__ binsum,
     uint32_t* __restrict__ res_hist, BinAccum* __restrict__ acc, unsigned int* __restrict__ hist_slabs,
     unsigned int* __restrict__ gsum, int per_group, unsigned int* __restrict__ counters, int overwrite,
-    const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
+    const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl,
+    int pack16 /* the LDS histogram as 16-bit counters, two to a word (deep coverage: a 512-value window in 32 KB instead of 64 -- two
+                  workgroups per CU instead of one; the caller guarantees fewer than 65536 x 31 values per workgroup); the
+                  workgroups' slabs are unpacked, their sums go straight into res_hist (cleared by the caller) */) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t* s_val = reinterpret_cast<int32_t*>(smem);                       // TB*m values (padded to 4)
   const int tile_elems = TB * m;
   const int tile_pad = (tile_elems + 3) & ~3;
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)tile_pad * 4);   // [vr][32]
   __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
-  for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) s_hist[e] = 0;
+  for (int e = threadIdx.x; e < (pack16 ? vr * kResClasses / 2 : vr * kResClasses); e += kThreads) s_hist[e] = 0;
   if (nreg <= kRegInline) {   // the short list travels with the kernel arguments: no upload in front of the launch
     for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
     for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
@@ -1581,11 +1584,17 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
         const int wx = d.x - vb, wy = d.y - vb, wz = d.z - vb, ww = d.w - vb;   // positions in the histogram's window
         if (whole && P0 + e0 + 3 < lim31 && ((unsigned)wx | (unsigned)wy | (unsigned)wz | (unsigned)ww) < (unsigned)vr) {
           // the common case, branch-free: four LDS atomics into [value][residue class]
-          atomicAdd(&s_hist[wx * kResClasses + c0], 1u); atomicAdd(&s_hist[wy * kResClasses + c1], 1u);
-          atomicAdd(&s_hist[wz * kResClasses + c2], 1u); atomicAdd(&s_hist[ww * kResClasses + c3], 1u);
+          if (pack16) {
+            const int i0 = wx * kResClasses + (int)c0, i1 = wy * kResClasses + (int)c1, i2 = wz * kResClasses + (int)c2, i3 = ww * kResClasses + (int)c3;
+            atomicAdd(&s_hist[i0 >> 1], 1u << ((i0 & 1) << 4)); atomicAdd(&s_hist[i1 >> 1], 1u << ((i1 & 1) << 4));
+            atomicAdd(&s_hist[i2 >> 1], 1u << ((i2 & 1) << 4)); atomicAdd(&s_hist[i3 >> 1], 1u << ((i3 & 1) << 4));
+          } else {
+            atomicAdd(&s_hist[wx * kResClasses + c0], 1u); atomicAdd(&s_hist[wy * kResClasses + c1], 1u);
+            atomicAdd(&s_hist[wz * kResClasses + c2], 1u); atomicAdd(&s_hist[ww * kResClasses + c3], 1u);
+          }
         } else {
           auto count = [&](int x, int e, uint32_t cls) {
-            if (e < cnt) hist_value(s_hist, res_hist, acc, vr, vb, x, (P0 + e) < lim31 ? (int)cls : 31);
+            if (e < cnt) hist_value(s_hist, res_hist, acc, vr, vb, x, (P0 + e) < lim31 ? (int)cls : 31, pack16);
           };
           count(d.x, e0, c0); count(d.y, e0 + 1, c1); count(d.z, e0 + 2, c2); count(d.w, e0 + 3, c3);
         }
@@ -1606,7 +1615,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
             s_val[dst + e] = x;
             rdc[seg + e] = x;
             const int64_t p = seg + e;
-            hist_value(s_hist, res_hist, acc, vr, vb, x, p < lim31 ? (int)((uint32_t)p % 31u) : 31);
+            hist_value(s_hist, res_hist, acc, vr, vb, x, p < lim31 ? (int)((uint32_t)p % 31u) : 31, pack16);
           }
         }
         seg = nxt;
@@ -1673,6 +1682,13 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   // folds the slabs into res_hist.  Atomics from every workgroup into the same few thousand words
   // would serialise on them. ----
   unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
+  if (pack16) {
+    for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], (s_hist[e >> 1] >> ((e & 1) << 4)) & 0xffffu);
+    // the groups' sums go straight into res_hist's window (the caller cleared res_hist): no 64 KB total in the last workgroup's LDS
+    if (!fold_slabs_add(hist_slabs, res_hist + (size_t)vb * kResClasses, vr * kResClasses, per_group, counters)) return;
+    export_words(exp_dst, exp_src, exp_bytes);
+    return;
+  }
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
   // ---- the last workgroup to finish folds the slabs into res_hist (device_util.h) and hands the histogram, with the
   // BinAccum record in front of it, to the host through mapped memory: no fold launch, no device -> host copy.
@@ -2461,7 +2477,9 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
   int TB, vr, grid;
   k4_geometry(m, capval, ncompact, vbase, TB, vr, grid);
   const size_t tile_pad = ((size_t)TB * m + 3) & ~(size_t)3;
-  const size_t lds = tile_pad * 4 + (size_t)vr * kResClasses * 4;
+  // deep coverage (a window that follows the depth): 16-bit LDS counters while a workgroup's share cannot make one wrap
+  const int pack16 = vbase > 0 && (ncompact + grid - 1) / grid < (int64_t)60000 * 31 ? 1 : 0;   // (margin: a class gets at most one value more per tile)
+  const size_t lds = tile_pad * 4 + (size_t)vr * kResClasses * (pack16 ? 2 : 4);
   const int quads = (int)(tile_pad / 4);
   const int maxv = (quads + kThreads - 1) / kThreads;          // 16-byte loads per thread and tile
   const int parts = kThreads / TB, ept = (m + parts - 1) / parts;   // values per thread in the median phase
@@ -2472,7 +2490,7 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
 #define RSI_K4(MV, EP) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin<MV, EP>));                                                            \
     RSI_LAUNCH((k_cap_compact_bin<MV, EP>), dim3(grid), dim3(kThreads), lds, stream, src, n, cbreak, cum, nreg,                \
                        ncompact, capval, m, TB, vr, vbase, rdc, binmed, binsum, res_hist, acc, sl, gs, pg, counters, overwrite,              \
-                       exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
+                       exp_src, exp_dst, (unsigned int)exp_bytes, inl, pack16); } while (0)
   if (maxv <= 4 && ept <= 13) RSI_K4(4, 13);          // m <= 52 (e.g. -m 51)
   else if (maxv <= 8 && ept <= 26) RSI_K4(8, 26);     // m <= 104 (e.g. the default -m 101)
   else if (ept <= 52) RSI_K4(13, 52);                 // m <= 191 with 4 threads per bin, or fewer bins per tile
