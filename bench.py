@@ -20,6 +20,12 @@ a cohort, weak scaling), reported with that label.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+Steps are SUBMITTED to the pool (rsi_pool_submit) and waited for, gathered and turned into rows on a second host thread:
+`config.steps_in_flight` genomes are queued at once (2 for a whole genome on one GPU, as many as fill the pool's 16 workers for
+a rank's few chromosomes; `--inflight 1` = one genome at a time), the way samples arrive in production -- the first
+chromosomes of genome k + 1 run beside the last ones of genome k.  Every step's rows are produced and hashed inside the timed
+region; the timer is read after the last step's rows exist (barrier + synchronize on both sides, max over ranks).
+
 Rank 0 prints ONE JSON line.  In it:
   roofline      the dominant per-base kernel -- the one an untimed pass with HIP events around every
                 per-base launch MEASURES as the longest -- then timed inside the timed steps (events
