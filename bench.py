@@ -109,7 +109,25 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="steps (genomes) queued in the pool at once (rsi_pool_submit): the next genome's first "
                     "chromosomes run beside the last ones of the current genome.  0 = as many as keep the pool's workers busy with this rank's "
                     "share (2 for a whole genome, more for the few chromosomes of one rank among eight, at most 6); 1 = one genome at a time")
+    ap.add_argument("--check-rows", choices=("auto", "off"), default="auto",
+                    help="auto: a full-size configs[3] / configs[4] genome's rows must hash to what the reference wrote (tests/golden/genome_rows.json)")
     args = ap.parse_args()
+
+    # ---- `--gpus N` without a launcher: this process -- before torch is imported or a GPU touched -- starts the N ranks itself
+    # (one process per GPU, torch.distributed.run on 127.0.0.1), relays rank 0's line and exits with the launcher's code.  A
+    # line with n_gpus != --gpus cannot come out of this file: a WORLD_SIZE that disagrees with --gpus is an error. ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] no launcher in the environment: starting", " ".join(cmd))
+        raise SystemExit(subprocess.run(cmd).returncode)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to print a line for the wrong number of GPUs")
 
     import numpy as np
     import torch
@@ -118,10 +136,7 @@ def main():
     from rsicnv_amd import dist as rd
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # RSI_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the
@@ -272,9 +287,9 @@ def main():
         step()
     # ---- which per-base kernel is the dominant one?  Measured, not assumed: one untimed pass with HIP events around every
     # per-base launch (timing mode 2); the timed steps then bracket that kernel only (event records are not free). ----
+    fence()                # the warm-up genomes are done before the timing mode changes under the workers
     pool.reset_times()
     pool.set_timing(2)
-    fence()
     step(timed=True)
     fence()
     insitu_all = pool.kernel_table()
@@ -288,6 +303,8 @@ def main():
     pool.set_timing(3)
     step_hashes.clear()
     pool.reset_times()
+    for _ in range(2):     # two untimed steps in the timed steps' own mode
+        step()
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -301,6 +318,27 @@ def main():
         elapsed = float(t.item())
     total_bases = genome_bases if sharded else world * genome_bases
     ms_per_step = elapsed / args.steps * 1e3
+    headline_hashes = list(step_hashes[:args.steps])
+
+    # ---- beside the headline: the same genome ONE AT A TIME (a step is submitted when the previous step's rows exist) ----
+    one_at_a_time = None
+    if args.inflight > 1:
+        saved_slots = slots
+        slots = threading.Semaphore(1)
+        k1 = max(3, min(args.steps, 10))
+        step(); fence()
+        t1 = time.perf_counter()
+        for _ in range(k1):
+            step()
+        fence()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        one_at_a_time = {"ms_per_step": round(e1 / k1 * 1e3, 3), "steps": k1, "bases_per_s": round(total_bases * k1 / e1, 1),
+                         "note": "--inflight 1: no genome is submitted before the previous genome's rows exist"}
+        slots = saved_slots
 
     # ---- roofline of the dominant kernel (HIP events on the library's streams, timed region) ----
     per_kernel = pool.kernel_table()      # name -> (sum ms, launches, sum of chromosome lengths)
@@ -345,14 +383,15 @@ def main():
                                    "note": "SURVEY 8d's whole-path algorithmic bytes x the bases one GPU processed per step / step time"}}
         # The same kernel with the per-base phases run alone on the chip (rsi_pool_set_schedule isolate=1):
         # one extra, untimed genome pass; `value` above does not include it.
+        fence()
         pool.set_schedule(isolate=True)
         pool.set_timing(2)
         timed_tables = (pool.times, )
         pool.reset_times()
-        fence()
         step(timed=True)
         fence()
         iso = pool.kernel_table()
+        del step_hashes[args.steps:]
         pool.set_schedule(isolate=False)
         pool.set_timing(3)
         if dom in iso:
@@ -370,12 +409,13 @@ def main():
             for k in sorted(streaming_names, key=lambda k: -insitu_all[k][0])}
         pool.times = timed_tables[0]
     # every launch of one more untimed pass (normal schedule), for the per-kernel picture of the whole path
+    fence()
     timed_table = pool.times
     pool.reset_times()
     pool.set_timing(1)
-    fence()
     step(timed=True)
     fence()
+    del step_hashes[args.steps:]
     all_table = pool.kernel_table()
     kernel_ms_all = {k: round(v[0], 3) for k, v in sorted(all_table.items(), key=lambda kv: -kv[1][0])}
     if roofline is not None and "rsi_scan" in all_table and all_table["rsi_scan"][0] > 0:
@@ -397,6 +437,31 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(lib, args, flags)
 
+    # ---- who ran where (every rank's device), the collective's backend and library version ----
+    dev_name = torch.cuda.get_device_name(local_rank)
+    me = {"rank": rank, "device_index": local_rank, "device": dev_name, "chromosomes": len(mine), "bases": my_bases}
+    ranks_info = [me]
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
+
+    # ---- the timed steps' rows against the REFERENCE's rows (tests/golden/genome_rows.json, written by
+    # tools/make_golden_full.py from the compiled reference's output for the very same generated chromosomes) ----
+    rows_ref = None
+    rows_match = None
+    if args.check_rows == "auto" and sharded and args.scale == 1.0 and args.config in (4, 5):
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "genome_rows.json")) as f:
+                rows_ref = json.load(f).get(f"config{args.config}")
+        except OSError:
+            rows_ref = None
+        if rows_ref is not None and rank == 0:
+            rows_match = bool(headline_hashes) and all(h == rows_ref["rows_sha256"] for h in headline_hashes)
+
     if rank == 0:
         value = total_bases * args.steps / elapsed
         if sharded:
@@ -412,9 +477,13 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload_name(args), "chromosomes": len(plans), "genome_bases": genome_bases,
                        "bases_on_rank0": my_bases, "flags": flag_string(flags), "calls_per_genome": ncalls, "shard": args.shard,
-                       "parallelism": par, "steps_in_flight": max(1, args.inflight)},
+                       "parallelism": par, "steps_in_flight": max(1, args.inflight), "world_size": world,
+                       "backend": (backend if world > 1 else "none (one rank)"), "rccl_version": rccl, "ranks": ranks_info},
+            "one_genome_at_a_time": one_at_a_time,
             "roofline": roofline, "cpu_baseline": cpu,
-            "steps_identical": steps_identical, "rows_sha256": step_hashes[0] if step_hashes else None,
+            "steps_identical": steps_identical, "rows_sha256": headline_hashes[0] if headline_hashes else None,
+            "rows_match_reference": rows_match,
+            "rows_reference_sha256": None if rows_ref is None else rows_ref["rows_sha256"],
             "kernel_ms_all_launches_extra_pass": kernel_ms_all,
             "worker_phase_ms_per_step": {k: round(v / args.steps, 2) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
         }
@@ -427,6 +496,11 @@ def main():
     pool.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        bad = [w for w, ok in (("headline", rows_match), ("configs[4] side pass", (side or {}).get("configs[4]_side_pass", {}).get("rows_match_reference")))
+               if ok is False]
+        if bad:
+            raise SystemExit(f"bench.py: rows differ from the reference's for: {', '.join(bad)}")
 
 
 def side_measurements(lib, pool, dev, args):
@@ -644,15 +718,37 @@ def config5_side_pass(lib, pool, dev, args, steps=10, warmup=5):
         pool.run(params, chrom_args)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pending = []
+    pending, all_res = [], []
     for _ in range(steps):   # as the main line: at most --inflight genomes queued in the pool
         pending.append(pool.submit(params, chrom_args))
         if len(pending) >= max(1, args.inflight):
-            res = pool.wait(pending.pop(0))
+            all_res.append(pool.wait(pending.pop(0)))
     while pending:
-        res = pool.wait(pending.pop(0))
+        all_res.append(pool.wait(pending.pop(0)))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    res = all_res[-1]
+    # every timed step's results, hashed as the main line hashes a step (rows in chromosome order, then chromosome median / SD)
+    # and compared with the hash of the reference's rows (tests/golden/genome_rows.json); the results are on the host when the
+    # timer stops, the text is made afterwards
+    import hashlib
+    hashes = []
+    for rs in all_res:
+        h = hashlib.sha256()
+        for c, r in enumerate(rs):
+            for row in r.format_rows(f"chr{c + 1}"):
+                h.update(row.encode()); h.update(b"\n")
+        for c, r in enumerate(rs):
+            h.update(repr((c, float(r.stats["RDmedian"]), float(r.stats["RDsd"]))).encode())
+        hashes.append(h.hexdigest())
+    rows_ref = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "genome_rows.json")) as f:
+            rows_ref = json.load(f).get("config5")
+    except OSError:
+        pass
+    rows_match = None if rows_ref is None else all(h == rows_ref["rows_sha256"] for h in hashes)
+    del all_res
     ncalls = sum(len(r.calls("calls")) for r in res)
     evals = sum(4 * int(r.stats["Lmax"]) * int(r.stats["nbins"]) for r in res)
     whole = WHOLE_PATH_BYTES_PER_BASE[51] * total / dt / 1e9
@@ -666,6 +762,7 @@ def config5_side_pass(lib, pool, dev, args, steps=10, warmup=5):
     pool.set_timing(0)
     out = {"workload": "24 synthetic chromosomes totalling 3 Gb, 60x, -m 51 -MED -cap 4 (configs[4])", "flags": flag_string(flags),
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "bases_per_s": round(total / dt, 1), "calls_per_genome": ncalls,
+           "steps_identical": len(set(hashes)) == 1, "rows_sha256": hashes[0], "rows_match_reference": rows_match,
            "whole_path": {"algorithmic_bytes_per_base": WHOLE_PATH_BYTES_PER_BASE[51], "achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4)},
            "kernel_ms_all_launches_extra_pass": {k: round(v[0], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][0])[:10]}}
     if "rsi_scan" in table and table["rsi_scan"][0] > 0:

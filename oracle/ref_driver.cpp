@@ -32,6 +32,7 @@ using namespace std;
 #include "wufunctions.h"
 #include "gccontent.h"
 #include "loaddata.h"
+#include "plotcnv.h"
 
 // reference functions with external linkage but no header (rsi.cpp, loaddata.cpp)
 void get_noseq_regions(string& FASTA);                                             // loaddata.cpp:243
@@ -52,6 +53,7 @@ void areblockscnv(Array<int>& RDmedint, Array<int>& RDtrans_status,
                   vector<cnv_st>& rsiseglist);                                     // rsi.cpp:415
 string cnv_format1(cnv_st& icnv);                                                  // rsi.cpp:581
 int expand_coordinate(int p1);                                                     // rsi.cpp:1524
+void plot_icnv(cnv_st icnv, string title, string datfile, string gpfile, string imgfile);   // plotcnv.cpp:246
 
 extern "C" {
 
@@ -367,6 +369,44 @@ int ref_run_timed(const ref_params* p, const int32_t* depth, const char* fasta, 
   double t5 = now_s();
   stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2; stage_s[3] = t4 - t3; stage_s[4] = t5 - t4;
   return nc;
+}
+
+// plot_icnv (plotcnv.cpp:246-610) on an explicit per-base array, set up as plot_cnv does (plotcnv.cpp:613-628: plot::RD,
+// plot::RDmed = _median of the array).  plot_icnv deletes its data and script file when it is done (plotcnv.cpp:606-607):
+// the driver gives each a second name (a hard link) beforehand, so the bytes the reference wrote stay readable as keep_dat /
+// keep_gp once the reference has removed its own names.  Nothing is re-implemented; the `gnuplot < script` the reference
+// starts fails harmlessly where gnuplot is absent.  out[0] = plot::RDmed, out[1] = the reference's gnuplot_version().
+int ref_plot_icnv(const ref_params* p, const int32_t* rd, int32_t n, const ref_call* c, const char* chrname, const char* title,
+                  const char* format, const char* datfile, const char* gpfile, const char* imgfile, const char* keep_dat,
+                  const char* keep_gp, double* out) {
+  rsi::m = p->m; rsi::minmlen = p->minmlen; rsi::chklen = p->chklen;
+  rsi::chr = chrname;
+  rsi::target_name.clear();
+  rsi::target_name.push_back(rsi::chr);
+  rsi::tid = 0;
+  static Array<int> RD(1);
+  RD.resize(0);
+  RD.resize(n);
+  for (int k = 0; k < n; ++k) RD[k] = rd[k];
+  plot::RD = &RD;
+  plot::RDmed = _median(&RD[0], RD.size());
+  plot::format = format;
+  cnv_st icnv;
+  icnv.tid = 0; icnv.start = c->start; icnv.end = c->end; icnv.type = c->type; icnv.length = c->length; icnv.p1 = c->p1;
+  const char* names[2][2] = {{datfile, keep_dat}, {gpfile, keep_gp}};
+  for (int f = 0; f < 2; ++f) {
+    unlink(names[f][0]); unlink(names[f][1]);
+    int fd = open(names[f][0], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return -1;
+    close(fd);
+    if (link(names[f][0], names[f][1]) != 0) return -2;
+  }
+  quiet_begin();
+  out[1] = gnuplot_version();
+  plot_icnv(icnv, title, datfile, gpfile, imgfile);
+  quiet_end();
+  out[0] = plot::RDmed;
+  return 0;
 }
 
 // Direct probes of the numeric utilities (used to pin the oracle's restatements).

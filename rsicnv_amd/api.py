@@ -441,8 +441,9 @@ class RsiPool:
         h = {"k": k, "params": params,
              "dp": (C.c_void_p * k)(*[C.c_void_p(c[0]) for c in chroms]), "fp": (C.c_void_p * k)(*[C.c_void_p(c[1]) for c in chroms]),
              "nn": (C.c_int64 * k)(*[c[2] for c in chroms]), "out": (C.c_void_p * k)(), "st": (C.c_int * k)()}
+        h["times"] = self.times if collect_times else None   # the run writes into it when it finishes: alive as long as the handle
         h["ticket"] = self.lib.rsi_pool_submit(self.pool, C.byref(params), k, h["dp"], h["fp"], h["nn"], h["out"], h["st"],
-                                               C.byref(self.times) if collect_times else None)
+                                               C.byref(h["times"]) if collect_times else None)
         if not h["ticket"]:
             raise RsiError(-2, "rsi_pool_submit: bad arguments")
         return h

@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "../../include/rsi_hot.h"
+#include "hostmath.h"
 
 namespace {
 
@@ -235,11 +236,13 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
   // ---- plots (rsi.cpp:2213-2216: expand_data, plot_cnv): the data / script files of every written call, piped through gnuplot
   // and deleted, as the reference does -- and like the reference only when there is a gnuplot.  -plotfiles (not a reference
   // flag) writes and keeps the files without one. ----
-  double gv = 0;
-  if (o.plot && rsi_result_ncalls(res, 0) > 0) {
-    if (FILE* pp = popen("gnuplot -V 2>/dev/null | cut -d' ' -f2", "r")) { char b[64] = {0}; if (fgets(b, sizeof(b), pp)) gv = atof(b); pclose(pp); }
-    if (gv <= 0 && !o.plotfiles) info << "gnuplot not found\n";
-  }
+  // gnuplot_version() (plotcnv.cpp:51-65) once per process, not once per chromosome
+  static const double gv = [] {
+    double v = -1.0;
+    if (FILE* pp = popen("gnuplot -V 2>/dev/null | cut -d' ' -f2", "r")) { char b[64] = {0}; if (fgets(b, sizeof(b), pp) && atof(b) > 0) v = atof(b); pclose(pp); }
+    return v;
+  }();
+  if (o.plot && rsi_result_ncalls(res, 0) > 0 && gv <= 0 && !o.plotfiles) info << "gnuplot not found\n";
   if (o.plot && rsi_result_ncalls(res, 0) > 0 && (gv > 0 || o.plotfiles)) {
     const int64_t nc = S->n_compact, nfull = S->n;
     std::vector<int32_t> rdc((size_t)nc), full((size_t)nfull), pairs((size_t)S->n_noncode * 2 + 2);
@@ -247,13 +250,11 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
     if (rsi_hot_fetch_i32(ctx, "rd_concat", rdc.data(), nc) == nc && rsi_plot_expand(rdc.data(), nc, pairs.data(), np, full.data(), nfull) == RSI_OK) {
       (void)!system(("mkdir -p " + o.plotfolder).c_str());
       // plot::RDmed = _median over the expanded array (plotcnv.cpp:625): zeros of the N regions included
-      std::vector<uint64_t> hist(65536, 0);
-      for (int32_t v : full) if (v >= 0 && v < 65536) ++hist[(size_t)v];
-      double med = 0;
-      { uint64_t seen = 0; const uint64_t r2 = (uint64_t)nfull / 2; for (size_t v = 0; v < hist.size(); ++v) { if (seen < r2 && seen + hist[v] >= r2) { med = (double)v; break; } seen += hist[v]; } }
+      const double med = rsih::grid_quantiles<int>(full.data(), (size_t)nfull).med;   // partition_stat_tp's walk, its degenerate case included
       if (gv <= 0) info << "plot data and scripts are left in " << o.plotfolder << "\n";
       const rsi_call* calls = rsi_result_calls(res, 0);
       static const char* kT[3] = {"DEL", "DUP", "UNKNOWN"};
+      std::vector<std::string> psfiles;
       for (int i = 0; i < rsi_result_ncalls(res, 0); ++i) {
         const rsi_call& c = calls[i];
         std::ostringstream base, title;
@@ -261,11 +262,22 @@ void process_chromosome(rsi_ctx* ctx, const Options& o, const std::string& chr, 
         title << chr << ":" << c.start << "-" << c.end << " " << c.end - c.start + 1 << " " << kT[c.type < 0 || c.type > 2 ? 2 : c.type];
         const std::string dat = base.str() + ".dat", gp = base.str() + ".gp", img = base.str() + ".ps";
         info << "plotting: " << title.str() << "\n";
-        if (rsi_plot_write_files(&c, title.str().c_str(), full.data(), nfull, med, o.P.m, o.P.minmlen, o.P.chklen, "ps", gv, dat.c_str(), gp.c_str(), img.c_str()) != RSI_OK) {
+        if (rsi_plot_write_files(&c, title.str().c_str(), full.data(), nfull, med, o.P.m, o.P.minmlen, o.P.chklen, "ps", gv > 0 ? gv : 5.0, dat.c_str(), gp.c_str(), img.c_str()) != RSI_OK) {
           info << "CNV exceeds reference length\n";
           continue;
         }
-        if (gv > 0) { (void)!system(("gnuplot < " + gp).c_str()); remove(dat.c_str()); remove(gp.c_str()); }
+        if (gv > 0) { (void)!system(("gnuplot < " + gp).c_str()); remove(dat.c_str()); remove(gp.c_str()); psfiles.push_back(img); }
+      }
+      // plot_cnv's last step (plotcnv.cpp:665-677): with ImageMagick at hand every figure also becomes a .png
+      static const bool have_convert = [] {
+        bool yes = false;
+        if (FILE* pp = popen("convert -version 2>/dev/null | grep Image", "r")) { char b[256]; while (fgets(b, sizeof(b), pp)) if (strstr(b, "ImageMagick")) yes = true; pclose(pp); }
+        return yes;
+      }();
+      if (have_convert) for (const std::string& ps : psfiles) {
+        info << "converting: " << ps << "\n";
+        (void)!system(("convert -limit thread 1 -limit area 256MB -limit disk 512MB -density 72 -rotate 90 -background white -render -antialias -flatten " +
+                       ps + " " + ps.substr(0, ps.size() - 3) + ".png").c_str());
       }
     } else info << "plots skipped: the per-base depth could not be fetched\n";
   }

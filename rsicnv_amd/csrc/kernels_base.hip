@@ -2449,7 +2449,7 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
                cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
                exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab, pp); } while (0)
   const bool sw7 = capval <= 127;   // four values to a register in the median phase (SW7)
-  const bool fix = rtab != nullptr && !(getenv("RSI_HOT_K4J_FIX") && atoi(getenv("RSI_HOT_K4J_FIX")) == 0);
+  const bool fix = rtab != nullptr;   // the caller hands the ratios over only when K2j verified them (pipeline.hip)
   if (fix) {
     if (sw7) { if (maxc == 1) RSI_K48J(1, 1, true, true); else RSI_K48J(2, 1, true, true); }
     else { if (maxc == 1) RSI_K48J(1, 0, false, true); else RSI_K48J(2, 0, false, true); }

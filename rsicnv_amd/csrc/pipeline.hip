@@ -352,7 +352,7 @@ class DeviceTester : public rsih::NeighbourTester {
         if (!ok(copy_h2d(ctx, ctx->cand_chains.p, chains.data(), chains.size() * 4))) return false;
       }
       {
-        Timer t(ctx, "candidate_test");
+        Timer t(ctx, split ? "candidate_test" : "candidate_test_one_wg");
         if (split)
           launch_candidate_test_split(d_rdc, N, d_jobs, (int)jobs.size(), d_chains, ctx->cand_i32.as<int32_t>(),
                                       ctx->cand_i64.as<long long>(), median, ctx->cand_mid.as<CandMid>(), ctx->cand_hist.as<uint32_t>(),
@@ -898,7 +898,8 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // The kernel declines when the real cap does not fit that configuration; the host checks everything again below and
   // launches the ordinary way whenever anything differs.  RSI_HOT_SPEC=0 switches it off.
   const char* spec_env = getenv("RSI_HOT_SPEC");
-  const bool spec = joint && !(spec_env && atoi(spec_env) == 0) && ctx->spec_capval >= 1 && ctx->spec_m == P.m && ctx->spec_cap == (double)P.cap &&
+  const bool k4j_fix_off = getenv("RSI_HOT_K4J_FIX") && atoi(getenv("RSI_HOT_K4J_FIX")) == 0;   // the queued K4j always takes K2j's ratios
+  const bool spec = joint && !(spec_env && atoi(spec_env) == 0) && !k4j_fix_off && ctx->spec_capval >= 1 && ctx->spec_m == P.m && ctx->spec_cap == (double)P.cap &&
                     cap_compact8_applies(P.m, ctx->spec_capval);
   constexpr uint32_t kSpecMagic = 0x5bec5bec;
   uint32_t* spec_slot = nullptr;
@@ -1123,12 +1124,17 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
     HIPCHK(ctx->rdc8.ensure((size_t)ncompact + 64));
     ctx->rdc_is_bytes = true;
+    // K2j's verified fixed-point ratios when it ran to the end; the float form with its exactness margin for a chromosome that
+    // went through K2 + K3' (wrapped pair counters) -- RSI_HOT_K4J_FIX=0 selects that form for any chromosome
+    const bool k4j_fix = joint_ok && !k4j_fix_off;
+    const bool k4j = joint_ok || !(joint_env && atoi(joint_env) == 0);
+    if (k4j && !k4j_fix) ctx->phases.push_back({"k4j.float rescale", 1.0});
     Timer t(ctx, "cap_compact_bin", true);
-    if (joint_ok || !(joint_env && atoi(joint_env) == 0))   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
+    if (k4j)   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
       launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                                   ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                                   ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0,
-                                  joint_ok ? reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off) : nullptr, nullptr, st);
+                                  k4j_fix ? reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off) : nullptr, nullptr, st);
     else   // RSI_HOT_JOINT=0: round 2's chain to the end (K4' from K3''s rescaled bytes), kept for A/B runs
     launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                             ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,

@@ -52,7 +52,8 @@ extern "C" {
 // Writes <base>.dat and <base>.gp for call `c` (coordinates in the expanded array, as printed in the output table).
 // rd: the expanded per-base depth (n values); chrom_median: _median of that array (plot::RDmed, plotcnv.cpp:625);
 // m / minmlen / chklen: the run's parameters (rsi.cpp:34-98); format: "ps", "eps" or "png" (plot::format);
-// gnuplot_version: what `gnuplot -V` reports (the script has two dialects, plotcnv.cpp:512), 0 = none found: the newer one.
+// gnuplot_version: what `gnuplot -V` reports, -1 = none found (gnuplot_version(), plotcnv.cpp:51-65).  The script has two
+// dialects and the reference picks the newer one only above 4.19 (plotcnv.cpp:512) -- "none found" gets the older one.
 // Returns RSI_OK, or RSI_ERR_BAD_ARG when the call lies outside the array (the reference draws an empty frame there).
 int rsi_plot_write_files(const rsi_call* c, const char* title_in, const int32_t* rd, int64_t n, double chrom_median, int m,
                          double minmlen, double chklen, const char* format, double gnuplot_version, const char* datfile,
@@ -165,7 +166,7 @@ int rsi_plot_write_files(const rsi_call* c, const char* title_in, const int32_t*
   i2 = i2 - d / 2;
   std::ofstream G(gpfile);
   if (!G) return RSI_ERR_BAD_ARG;
-  if (gnuplot_version <= 0 || gnuplot_version > 4.19) {
+  if (gnuplot_version > 4.19) {
     G << "f=\"" << datfile << "\"" << std::endl
       << "set datafile missing 'NaN'" << std::endl
       << "info=\"" << title << " \"" << std::endl

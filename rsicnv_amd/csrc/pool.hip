@@ -35,6 +35,7 @@ struct PoolRun : rsip::RunBase {   // nitems = chromosomes
   std::vector<std::vector<std::pair<const char*, float>>> ktimes;
   std::vector<std::vector<std::pair<const char*, double>>> ptimes;
   std::vector<std::vector<int64_t>> kbases;
+  std::vector<std::string> errs;   // per chromosome: the failing call's own message (written by the worker that ran it)
 };
 
 struct rsi_pool {
@@ -47,8 +48,19 @@ struct rsi_pool {
   // the last chromosome of the first wave was under way.
   std::vector<std::thread> threads;
   rsip::RunQueue<PoolRun> queue;                               // run_queue.h: runs in submission order, items claimed oldest run first
-  std::mutex w0m;                                              // worker 0's context: one waiting caller at a time
   std::mutex trace_mu;
+  mutable std::mutex err_mu;                                   // `err`
+  std::atomic<int> healthy{0};                                 // workers whose context still takes runs
+  std::vector<char> parked;                                    // per worker: left the healthy count (its own thread / the helper's seat only)
+
+  // A worker whose context has been poisoned (a wait gave up with kernels still queued) fails every run at once: left in the
+  // rotation it would claim and fail chromosome after chromosome faster than the healthy workers can take them.  It stops
+  // claiming instead -- unless it is the last one, which keeps claiming so that queued runs fail instead of waiting for ever.
+  bool retire_if_poisoned(size_t w) {
+    if (!workers[w]->poisoned) return false;
+    if (!parked[w]) { parked[w] = 1; healthy.fetch_sub(1); }
+    return healthy.load() > 0;
+  }
 
   void process(size_t w, PoolRun& R, int k) {
     static const bool trace = getenv("RSI_HOT_TRACE") && atoi(getenv("RSI_HOT_TRACE")) != 0;   // per-chromosome timeline on stderr
@@ -60,6 +72,7 @@ struct rsi_pool {
     // some chromosomes run beside the kernels of others -- H2D double-buffered against compute across the pool's workers
     R.rcs[(size_t)i] = R.host_inputs ? rsi_hot_run(ctx, &R.params, static_cast<const int32_t*>(R.depth[(size_t)i]), static_cast<const uint8_t*>(R.fasta[(size_t)i]), R.n[(size_t)i], &R.out[i])
                                      : rsi_hot_run_device(ctx, &R.params, R.depth[(size_t)i], R.fasta[(size_t)i], R.n[(size_t)i], &R.out[i]);
+    if (R.rcs[(size_t)i] != RSI_OK) R.errs[(size_t)i] = ctx->err;   // this call's message, not whatever the process saw last
     if (trace) {
       std::lock_guard<std::mutex> lk(trace_mu);
       fprintf(stderr, "[trace] run %llu worker %zu chrom %d n %lld start %.2f end %.2f :", (unsigned long long)R.id, w, i, (long long)R.n[(size_t)i], t_a - R.t0, now_ms() - R.t0);
@@ -76,7 +89,7 @@ struct rsi_pool {
     if (trace) fprintf(stderr, "[trace] run %llu: all chromosomes done at %.2f ms\n", (unsigned long long)R.id, now_ms() - R.t0);
     for (int i = 0; i < R.nitems; ++i) {
       if (R.status) R.status[i] = R.rcs[(size_t)i];
-      if (R.rcs[(size_t)i] != RSI_OK && R.worst == RSI_OK) { R.worst = R.rcs[(size_t)i]; std::lock_guard<std::mutex> lk(g_err_mu); err = g_last_error; }
+      if (R.rcs[(size_t)i] != RSI_OK && R.worst == RSI_OK) { R.worst = R.rcs[(size_t)i]; std::lock_guard<std::mutex> lk(err_mu); err = R.errs[(size_t)i]; }
     }
     if (rsi_batch_times* times = R.times) {   // accumulate into the caller's table (names are static strings)
       for (size_t w = 0; w < workers.size(); ++w) {
@@ -102,6 +115,7 @@ struct rsi_pool {
       if (!queue.next(r, k)) return;
       process(w, *r, k);
       queue.item_done(r, [this](PoolRun& R) { finish(R); });
+      if (retire_if_poisoned(w)) return;
     }
   }
 };
@@ -126,6 +140,8 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
     c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
     pool->workers.push_back(c);
   }
+  pool->healthy = (int)pool->workers.size();
+  pool->parked.assign(pool->workers.size(), 0);
   for (size_t w = 1; w < pool->workers.size(); ++w) pool->threads.emplace_back([pool, w] { pool->worker_loop(w); });
   if (status) *status = RSI_OK;
   return pool;
@@ -150,9 +166,9 @@ void rsi_pool_set_schedule(rsi_pool* pool, int isolate, int streamers) {
   if (streamers >= 1) pool->gate.max_streamers = streamers;
 }
 const char* rsi_pool_last_error(const rsi_pool* pool) {
-  if (pool) return pool->err.c_str();
-  static thread_local std::string copy;   // the global record changes under other threads' feet: hand out a snapshot
-  { std::lock_guard<std::mutex> lk(g_err_mu); copy = g_last_error; }
+  static thread_local std::string copy;   // the records change under other threads' feet: hand out a snapshot
+  if (pool) { std::lock_guard<std::mutex> lk(pool->err_mu); copy = pool->err; }
+  else { std::lock_guard<std::mutex> lk(g_err_mu); copy = g_last_error; }
   return copy.c_str();
 }
 
@@ -170,6 +186,7 @@ static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom
   for (int i = 0; i < nchrom; ++i) R->order[(size_t)i] = i;
   std::stable_sort(R->order.begin(), R->order.end(), [&](int a, int b) { return n[a] > n[b]; });   // longest first
   R->rcs.assign((size_t)nchrom, RSI_OK);
+  R->errs.resize((size_t)nchrom);
   R->ktimes.resize(pool->workers.size()); R->ptimes.resize(pool->workers.size()); R->kbases.resize(pool->workers.size());
   R->t0 = now_ms();
   int64_t largest = 0;
@@ -185,17 +202,10 @@ static int pool_wait_impl(rsi_pool* pool, uint64_t ticket) {
   if (!pool || !ticket) return RSI_ERR_BAD_ARG;
   std::shared_ptr<PoolRun> mine = pool->queue.find(ticket);
   if (!mine) return RSI_ERR_BAD_ARG;
-  // the caller is worker 0 while it waits (when nobody else is): chromosomes of its own run and of the runs ahead of it
-  if (pool->w0m.try_lock()) {
-    std::shared_ptr<PoolRun> r;
-    int k = 0;
-    while (pool->queue.try_next(mine, r, k)) {
-      pool->process(0, *r, k);
-      pool->queue.item_done(r, [pool](PoolRun& R) { pool->finish(R); });
-    }
-    pool->w0m.unlock();
-  }
-  pool->queue.wait_done(mine);
+  // the caller is worker 0 while it waits (one such caller at a time; run_queue.h: wait_helping): chromosomes of its own
+  // run and of the runs ahead of it, until its run is finished
+  pool->queue.wait_helping(mine, [pool](PoolRun& R, int k) { pool->process(0, R, k); }, [pool](PoolRun& R) { pool->finish(R); },
+                           [pool] { return !(pool->workers[0]->poisoned && pool->retire_if_poisoned(0)); });
   return mine->worst;
 }
 

@@ -31,6 +31,7 @@ struct RunQueue {
   std::vector<std::shared_ptr<Run>> unwaited;   // submitted, wait() not yet returned
   uint64_t next_id = 1;
   bool quit = false;
+  bool helper_busy = false;                     // a waiting caller is processing an item with the helpers' shared resource
 
   // under m: the next item to work on, from the oldest run that has one (no younger than `upto`; 0 = any)
   bool claim_locked(std::shared_ptr<Run>& r, int& k, uint64_t upto) {
@@ -66,15 +67,19 @@ struct RunQueue {
     std::lock_guard<std::mutex> lk(m);
     return !mine->done && claim_locked(r, k, mine->id);
   }
-  // One item of the run has been processed; the last one closes the run.
+  // under m: one item of the run has been processed; the last one closes the run.
   template <class Finish>
-  void item_done(const std::shared_ptr<Run>& r, Finish&& finish) {
-    std::lock_guard<std::mutex> lk(m);
+  void complete_locked(const std::shared_ptr<Run>& r, Finish&& finish) {
     if (++r->completed < r->nitems) return;
     finish(*r);
     r->done = true;
     for (auto it = active.begin(); it != active.end(); ++it) if (it->get() == r.get()) { active.erase(it); break; }
     done_cv.notify_all();
+  }
+  template <class Finish>
+  void item_done(const std::shared_ptr<Run>& r, Finish&& finish) {
+    std::lock_guard<std::mutex> lk(m);
+    complete_locked(r, finish);
   }
   std::shared_ptr<Run> find(uint64_t ticket) {
     std::lock_guard<std::mutex> lk(m);
@@ -85,6 +90,33 @@ struct RunQueue {
   void wait_done(const std::shared_ptr<Run>& mine) {
     std::unique_lock<std::mutex> lk(m);
     done_cv.wait(lk, [&] { return mine->done; });
+    for (auto it = unwaited.begin(); it != unwaited.end(); ++it) if (it->get() == mine.get()) { unwaited.erase(it); break; }
+  }
+  // Blocks until the run is finished, and works while it waits: the caller takes items of its own run and of the runs ahead
+  // of it (never of a younger run) and hands them to `process(run, k)`.  The helpers share ONE resource (the pool's worker-0
+  // context), so one helper processes at a time; the others sleep and are woken when the helper's item is done -- whoever
+  // wakes first is the next helper.  A waiter therefore never sleeps while an item it may take is unclaimed and no helper
+  // is at work: with no background workers at all, any number of waiting threads still drain the queue (round 3's form
+  // tried the helper role once and then slept for good, which left the second of two waiters asleep next to its unclaimed
+  // run).  `may_help()` = false (evaluated under the mutex) turns the caller into a plain waiter.
+  template <class Process, class Finish, class MayHelp>
+  void wait_helping(const std::shared_ptr<Run>& mine, Process&& process, Finish&& finish, MayHelp&& may_help) {
+    std::unique_lock<std::mutex> lk(m);
+    while (!mine->done) {
+      std::shared_ptr<Run> r;
+      int k = 0;
+      if (!helper_busy && may_help() && claim_locked(r, k, mine->id)) {
+        helper_busy = true;
+        lk.unlock();
+        process(*r, k);
+        lk.lock();
+        helper_busy = false;
+        complete_locked(r, finish);
+        done_cv.notify_all();     // the helper's seat is free: another waiter may have claimable items
+        continue;
+      }
+      done_cv.wait(lk);
+    }
     for (auto it = unwaited.begin(); it != unwaited.end(); ++it) if (it->get() == mine.get()) { unwaited.erase(it); break; }
   }
   void shutdown() {

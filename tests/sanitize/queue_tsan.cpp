@@ -1,6 +1,7 @@
 // ThreadSanitizer harness for RunQueue (rsicnv_amd/csrc/run_queue.h), the pool's queue of runs: eleven worker threads take items
 // of queued runs, three client threads submit runs of different sizes and wait for them -- helping as a twelfth worker while
-// they wait, as rsi_pool_wait does -- out of order and concurrently.  Checked: every item of every run is processed exactly
+// they wait, as rsi_pool_wait does (RunQueue::wait_helping) -- out of order and concurrently; then the same with NO worker
+// threads at all (a pool of one context: the waiting callers are the only workers, one at a time).  Checked: every item of every run is processed exactly
 // once, `finish` runs once per run before its waiter returns and sees all of the run's results, items are claimed oldest run
 // first, a helper never touches a run younger than its own, and ThreadSanitizer sees no race.  CPU only.
 #include <atomic>
@@ -17,9 +18,10 @@ struct TestRun : rsip::RunBase {
   int finished = 0;
 };
 
-int main() {
+static int drive(int nworkers, int nclients, int rounds) {
   rsip::RunQueue<TestRun> q;
-  std::atomic<long> processed(0), order_violations(0), young_help(0);
+  std::atomic<long> processed(0), young_help(0);
+  std::atomic<int> helpers_inside(0), helper_overlap(0);
   std::atomic<uint64_t> oldest_unfinished(1);
   auto process = [&](TestRun& r, int k) {
     r.result[(size_t)k] = (int)r.id * 1000 + k;
@@ -34,15 +36,14 @@ int main() {
     ++r.finished;
   };
   std::vector<std::thread> workers;
-  for (int w = 0; w < 11; ++w) workers.emplace_back([&] {
+  for (int w = 0; w < nworkers; ++w) workers.emplace_back([&] {
     std::shared_ptr<TestRun> r; int k = 0;
     while (q.next(r, k)) { process(*r, k); q.item_done(r, finish); }
   });
-  std::mutex helper;   // worker 0's context: one helping waiter at a time
   int failures = 0;
   std::mutex fail_mu;
   auto client = [&](int c) {
-    for (int round = 0; round < 60; ++round) {
+    for (int round = 0; round < rounds; ++round) {
       std::vector<std::shared_ptr<TestRun>> mine;
       const int nruns = 1 + (round + c) % 3;
       for (int j = 0; j < nruns; ++j) {
@@ -57,16 +58,13 @@ int main() {
       for (auto& r : mine) {
         auto found = q.find(r->id);
         if (found.get() != r.get()) { std::lock_guard<std::mutex> lk(fail_mu); ++failures; }
-        if (helper.try_lock()) {
-          std::shared_ptr<TestRun> h; int k = 0;
-          while (q.try_next(r, h, k)) {
-            if (h->id > r->id) young_help.fetch_add(1);
-            process(*h, k);
-            q.item_done(h, finish);
-          }
-          helper.unlock();
-        }
-        q.wait_done(r);
+        const uint64_t my_id = r->id;
+        q.wait_helping(r, [&](TestRun& h, int k) {
+          if (helpers_inside.fetch_add(1) != 0) helper_overlap.fetch_add(1);   // worker 0's context: one helper at a time
+          if (h.id > my_id) young_help.fetch_add(1);
+          process(h, k);
+          helpers_inside.fetch_sub(1);
+        }, finish, [] { return true; });
         long want = 0;
         bool once = true;
         for (int k = 0; k < r->nitems; ++k) { want += (long)r->id * 1000 + k; once = once && r->touched[(size_t)k] == 1; }
@@ -79,14 +77,23 @@ int main() {
     }
   };
   std::vector<std::thread> clients;
-  for (int c = 0; c < 3; ++c) clients.emplace_back(client, c);
+  for (int c = 0; c < nclients; ++c) clients.emplace_back(client, c);
   for (auto& t : clients) t.join();
   q.shutdown();
   for (auto& t : workers) t.join();
-  const bool ok = failures == 0 && young_help.load() == 0 && q.active.empty() && q.unwaited.empty();
-  printf("runs checked by 3 clients, %ld items processed, %d failures, helper on younger runs %ld, queue empty at the end %d\n",
-         processed.load(), failures, young_help.load(), (int)(q.active.empty() && q.unwaited.empty()));
-  if (!ok) return 1;
+  const bool ok = failures == 0 && young_help.load() == 0 && helper_overlap.load() == 0 && q.active.empty() && q.unwaited.empty();
+  printf("%d workers, %d clients: %ld items processed, %d failures, helper on younger runs %ld, two helpers at once %d, queue empty at the end %d\n",
+         nworkers, nclients, processed.load(), failures, young_help.load(), helper_overlap.load(), (int)(q.active.empty() && q.unwaited.empty()));
+  return ok ? 0 : 1;
+}
+
+int main() {
+  if (drive(11, 3, 60)) return 1;
+  // no background workers (rsi_pool_create(nworkers = 1)): two and four waiting callers are all the workers there are --
+  // round 3's wait slept for good next to its own unclaimed run here
+  if (drive(0, 2, 60)) return 1;
+  if (drive(0, 4, 40)) return 1;
+  if (drive(1, 3, 40)) return 1;
   printf("queue harness ok\n");
   return 0;
 }

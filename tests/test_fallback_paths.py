@@ -1,0 +1,152 @@
+"""GPU: every road a chromosome can take through the pipeline in production, not only the main one (VERDICT r3 "weak" 3).
+
+* K2j's 16-bit pair counters wrap -> the three-pass chain K2 + K3' + K4j(float rescale), with and without a speculative K4j
+  queued behind the failed K2j (pipeline.hip: "a2-3.joint wrapped");
+* 1 - 10 % of the bases at 255x and more -> k_escape_hist ("a2-3.escapes");
+* the RSI_HOT_* switches, each of which selects a whole alternative path: four golden cases under each, with an assertion that
+  the alternative really ran (kernel / phase names of the run, rsi_hot_kernel_times / rsi_hot_phase_times).
+
+Bars as everywhere: integer arrays bit for bit against the oracle / the reference's golden files, calls equal."""
+import os
+
+import numpy as np
+import pytest
+
+import fallback_cases as fc
+import golden_util as gu
+from conftest import calls_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def hot():
+    from rsicnv_amd import api
+    h = api.RsiHot(0)
+    yield h
+    h.close()
+
+
+def _against_oracle(hot, res, O):
+    assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc")), "rd_gc"
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat")), "rd_concat"
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint")), "binmedint"
+    rdc, medint = O.i32("rd_concat"), O.i32("binmedint")
+    m = len(rdc) // len(medint)
+    assert np.array_equal(hot.fetch("binsum"), rdc[:len(medint) * m].reshape(len(medint), m).sum(axis=1, dtype=np.int64)), "binsum"
+    ch = O.f64("chrom")
+    assert res.stats["RDmedian"] == ch[0] and res.stats["RDsd"] == pytest.approx(ch[1], rel=1e-12)
+    assert res.stats["cap_median"] == ch[2]
+    for w in ("status1", "status1f", "status2"):
+        assert np.array_equal(hot.fetch(w), O.i32(f"nb_{w}")), w
+    for which in ("calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
+    assert len(res.calls("calls")) > 0
+
+
+@pytest.mark.timeout(600)
+def test_wrapped_pair_counters_take_the_three_pass_chain(hot, oracle_cls):
+    import oracle
+    from rsicnv_amd import api
+    fasta, depth, _ = fc.wrap_case()
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    hot.set_timing(1)
+    # a fresh context has no cap to guess from: no K4j is queued behind K2j
+    res = hot.run(api.make_params(), depth, fasta)
+    phases, kernels = dict(hot.phase_times()), [k for k, _ in hot.kernel_times()]
+    assert "a2-3.joint wrapped: three-pass chain" in phases, phases
+    assert "spec.k4j accepted" not in phases and "spec.k4j rejected" not in phases
+    assert "gc_joint_hist" in kernels and "gc_hist" in kernels and "value_hist8" in kernels, kernels
+    assert "k4j.float rescale" in phases          # no verified ratios from a K2j that gave up: the float form
+    _against_oracle(hot, res, O)
+    # the same chromosome again: now a K4j IS queued behind K2j (the cap of the previous run), finds the wrap flag, declines
+    res2 = hot.run(api.make_params(), depth, fasta)
+    phases2 = dict(hot.phase_times())
+    assert "a2-3.joint wrapped: three-pass chain" in phases2 and "spec.k4j rejected" in phases2, phases2
+    _against_oracle(hot, res2, O)
+    # and an ordinary chromosome behind it on the same context is not disturbed by what the wrapped run left
+    gu.check_hip_against_golden(hot, api.load_library(), "gampois_nb_m101")
+
+
+def test_escapes_beyond_the_workgroup_lists_take_the_escape_pass(hot, hotlib, oracle_cls):
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, depth = fc.escape_case(hotlib)
+    frac = float((depth >= 255).mean())
+    assert 0.01 < frac < 0.10, frac
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    hot.set_timing(1)
+    res = hot.run(api.make_params(), depth, fasta)
+    phases, kernels = dict(hot.phase_times()), [k for k, _ in hot.kernel_times()]
+    assert "a2-3.escapes" in phases and "escape_hist" in kernels, (phases, kernels)
+    assert "a2-3.deep coverage" not in phases
+    assert res.stats["byte_escapes"] == int((depth >= 255).sum())
+    _against_oracle(hot, res, O)
+
+
+SWITCH_CASES = ["poisson_nb_m101", "gampois_nb_m101", "gampois_med_m51_cap4", "poisson_tail7"]
+
+
+def _ran(hot):
+    return dict(hot.phase_times()), [k for k, _ in hot.kernel_times()]
+
+
+def _check_joint_off(hot, res, second):
+    phases, kernels = _ran(hot)
+    assert "gc_joint_hist" not in kernels and "gc_hist" in kernels and "value_hist8" in kernels, kernels
+
+
+def _check_spec_off(hot, res, second):
+    phases, kernels = _ran(hot)
+    assert "spec.k4j accepted" not in phases and "spec.k4j rejected" not in phases, phases
+    assert "gc_joint_hist" in kernels
+
+
+def _check_fix_off(hot, res, second):
+    phases, kernels = _ran(hot)
+    assert "k4j.float rescale" in phases and "gc_joint_hist" in kernels, (phases, kernels)
+    assert "spec.k4j accepted" not in phases
+
+
+def _check_detect_off(hot, res, second):
+    assert res.stats["scan_tiles_listed"] == 0 and res.stats["scan_tiles"] > 0
+
+
+def _check_split_off(hot, res, second):
+    phases, kernels = _ran(hot)
+    assert "candidate_test_one_wg" in kernels and "candidate_test" not in kernels, kernels
+
+
+SWITCHES = {"RSI_HOT_JOINT": _check_joint_off, "RSI_HOT_SPEC": _check_spec_off, "RSI_HOT_K4J_FIX": _check_fix_off,
+            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off}
+
+
+@pytest.mark.parametrize("switch", sorted(SWITCHES))
+def test_alternative_paths_behind_the_switches(hot, hotlib, switch):
+    """<switch>=0 for four golden cases, each run twice on the same context (the second run is the one a queued K4j would
+    accompany); every run is the full golden comparison.  Then the same cases with the switch unset, and the assertion the
+    other way round where the main road leaves a trace: the default really is the other path."""
+    hot.set_timing(1)
+    old = os.environ.get(switch)
+    os.environ[switch] = "0"
+    try:
+        for name in SWITCH_CASES:
+            for second in (False, True):
+                res = gu.check_hip_against_golden(hot, hotlib, name)
+                SWITCHES[switch](hot, res, second)
+    finally:
+        if old is None:
+            del os.environ[switch]
+        else:
+            os.environ[switch] = old
+    res = gu.check_hip_against_golden(hot, hotlib, SWITCH_CASES[1])
+    res = gu.check_hip_against_golden(hot, hotlib, SWITCH_CASES[1])     # second run under the same flags: a K4j is queued
+    phases, kernels = _ran(hot)
+    assert "gc_joint_hist" in kernels and "gc_hist" not in kernels
+    assert "spec.k4j accepted" in phases, phases
+    assert "k4j.float rescale" not in phases
+    assert res.stats["scan_tiles_listed"] > 0
+    assert "candidate_test" in kernels and "candidate_test_one_wg" not in kernels

@@ -48,13 +48,34 @@ def _plan(plan):
     return plan
 
 
-def _check_against_golden(res, g, what):
+def _check_against_golden(res, g, what, chrom=None):
     assert np.array_equal(res.noncode, g["noncode"]), what
     assert (res.stats["RDmedian"], res.stats["RDsd"]) == tuple(g["chrom_scalars"]), what
     assert res.stats["n_compact"] == int(g["n_compact"])
     for which in ("calls_raw", "calls"):
         ok, why = calls_equal(res.calls(which), gu.calls_from_array(g[which]))
         assert ok, f"{what} {which}: {why}"
+    if chrom is not None and "rows" in g:   # the output rows as the reference's cnv_format1 printed them (rsi.cpp:581-631)
+        assert "\n".join(res.format_rows(chrom)) + ("\n" if res.rows else "") == str(g["rows"]), what
+
+
+def _genome_hash(results):
+    """bench.py's step hash: every row + newline in chromosome order, then (chromosome index, RDmedian, RDsd) per chromosome."""
+    import hashlib
+    h = hashlib.sha256()
+    for c, r in enumerate(results):
+        for row in r.format_rows(f"chr{c + 1}"):
+            h.update(row.encode()); h.update(b"\n")
+    for c, r in enumerate(results):
+        h.update(repr((c, float(r.stats["RDmedian"]), float(r.stats["RDsd"]))).encode())
+    return h.hexdigest()
+
+
+def _genome_rows(config):
+    path = os.path.join(gu.GOLDEN_DIR, "genome_rows.json")
+    if not os.path.exists(path):
+        pytest.skip("genome_rows.json not generated (tools/make_golden_full.py genome4 genome5)")
+    return json.load(open(path))[f"config{config}"]
 
 
 def _properties(hot, res, m, cap, plan):
@@ -125,10 +146,12 @@ def test_config4_one_60x_med_chromosome_against_reference_golden(hot, hotlib):
     assert gu.sha(rdc) == str(g["rd_concat_sha"])
 
 
+@pytest.mark.timeout(900)
 def test_config3_genome_in_flight_equals_one_at_a_time_and_golden(hot, hotlib):
     """configs[3]: the 24 chromosomes of the 3 Gb genome, twelve in flight on one GPU: every chromosome's calls and statistics
-    equal the same chromosome alone on one context, and four of them (chr8 at 142 Mb, three of <= 60 Mb) equal the
-    reference's golden tables."""
+    equal the same chromosome alone on one context, and ALL 24 equal the golden tables the compiled reference produced from the
+    same generated arrays (tests/golden/cfg4_chr1..24.npz: N regions, n', median, SD, raw and final call tables, output rows);
+    the genome's rows hash to what bench.py must report (tests/golden/genome_rows.json)."""
     from rsicnv_amd import api, synth
     flags = synth.config_flags(4)
     params = api.make_params(**flags)
@@ -149,12 +172,40 @@ def test_config3_genome_in_flight_equals_one_at_a_time_and_golden(hot, hotlib):
             for k in ("RDmedian", "RDsd", "cap_median", "nb_mad", "tmedian1", "tlamda1", "tmedian2", "tlamda2", "Lmax", "n_compact", "nbins"):
                 assert one.stats[k] == other.stats[k], (c + 1, k)
         ncalls += len(one.calls("calls"))
-        if c in (7, 18, 20, 21):          # chr8 (142 Mb) is one of the twelve that start together; the other three are <= 60 Mb
-            g, gplan, gflags = _golden(f"cfg4_chr{c + 1}")
-            assert _plan(gplan)["seed"] == plans[c]["seed"] and gflags == flags
-            _check_against_golden(a, g, f"chr{c + 1} in flight")
+        g, gplan, gflags = _golden(f"cfg4_chr{c + 1}")
+        assert _plan(gplan)["seed"] == plans[c]["seed"] and _plan(gplan)["n"] == plans[c]["n"] and gflags == flags
+        _check_against_golden(a, g, f"chr{c + 1} in flight", chrom=f"chr{c + 1}")
     pool.close()
-    assert ncalls >= 300
+    ref = _genome_rows(4)
+    assert ncalls == ref["calls"] and ncalls >= 300
+    assert _genome_hash(batch) == ref["rows_sha256"] == _genome_hash(batch2)
+
+
+@pytest.mark.timeout(900)
+def test_config4_genome_through_the_pool_against_reference_golden(hotlib):
+    """configs[4]: the 3 Gb genome at 60x with -m 51 -MED -cap 4, sixteen chromosomes in flight (bench.py's pool): all 24
+    chromosomes against the reference's golden tables (tests/golden/cfg5_chr1..24.npz) -- N regions, n', chromosome median and
+    SD exactly, raw and final calls, output rows byte for byte -- and the genome's rows hash against genome_rows.json.  Queued
+    twice (two genomes in the pool at once, as the bench runs them): both passes must agree."""
+    from rsicnv_amd import api, synth
+    flags = synth.config_flags(5)
+    params = api.make_params(**flags)
+    plans = [synth.config_plan(5, chrom=c) for c in range(24)]
+    assert abs(sum(p["n"] for p in plans) - 3_000_000_000) < 1000
+    bufs = [_device_case(hotlib, p) for p in plans]
+    args = [(b[0].data_ptr(), b[1].data_ptr(), p["n"]) for b, p in zip(bufs, plans)]
+    pool = api.RsiPool(0, 16)
+    h1 = pool.submit(params, args)
+    h2 = pool.submit(params, args)
+    batch, batch2 = pool.wait(h1), pool.wait(h2)
+    for c, r in enumerate(batch):
+        g, gplan, gflags = _golden(f"cfg5_chr{c + 1}")
+        assert _plan(gplan)["seed"] == plans[c]["seed"] and _plan(gplan)["n"] == plans[c]["n"] and gflags == flags
+        _check_against_golden(r, g, f"60x chr{c + 1}", chrom=f"chr{c + 1}")
+    ref = _genome_rows(5)
+    assert sum(len(r.calls("calls")) for r in batch) == ref["calls"]
+    assert _genome_hash(batch) == ref["rows_sha256"] == _genome_hash(batch2)
+    pool.close()
 
 
 def _digest(results):

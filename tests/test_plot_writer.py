@@ -98,3 +98,33 @@ def test_plot_files_of_a_deletion(hotlib, tmp_path):
     # a call beyond the array is refused (the reference draws an empty frame)
     assert hotlib.rsi_plot_write_files(C.byref(_call(hotlib, n + 5, n + 90)), b"t", rd.ctypes.data, n, 30.0, m, minmlen, chklen, b"ps", 5.0,
                                        dat.encode(), gp.encode(), img.encode()) != 0
+
+
+GOLDEN_PLOTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plot_cases.npz")
+
+
+@pytest.mark.parametrize("name", ["del_mid", "dup_wide", "del_short", "dup_left_edge", "del_right_edge"])
+def test_plot_files_equal_the_references_own(hotlib, tmp_path, name, monkeypatch):
+    """The writer against plot_icnv ITSELF (plotcnv.cpp:246-610): tests/golden/plot_cases.npz holds, per case, the per-base array,
+    the call and the bytes the compiled reference wrote into its .dat and .gp file (tools/make_golden_plot.py).  Byte for byte:
+    a deletion, a duplication wider than plot::pts positions (subsampled walk), a call shorter than m * minmlen, neighbourhoods
+    clamped at either chromosome end.  The script is in the dialect the reference chose where the files were made
+    (gnuplot_version() = -1: none installed)."""
+    from rsicnv_amd import api
+    g = np.load(GOLDEN_PLOTS, allow_pickle=False)
+    rd = np.ascontiguousarray(g[name + "_rd"], dtype=np.int32)
+    start, end, typ, length = (int(v) for v in g[name + "_call"])
+    m, minmlen, chklen = (float(v) for v in g["params"])
+    c = api.RsiCall()
+    c.start, c.end, c.type, c.length, c.p1 = start, end, typ, length, float(g[name + "_p1"][0])
+    base = str(g[name + "_base"])
+    monkeypatch.chdir(tmp_path)                      # the data file's name is written into the script: same relative names
+    os.makedirs("plots")
+    hotlib.rsi_plot_write_files.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double,
+                                             C.c_char_p, C.c_double, C.c_char_p, C.c_char_p, C.c_char_p]
+    rc = hotlib.rsi_plot_write_files(C.byref(c), str(g[name + "_title"]).encode(), rd.ctypes.data, rd.size, float(g[name + "_rdmed"][0]), int(m),
+                                     minmlen, chklen, b"ps", float(g[name + "_version"][0]), (base + ".dat").encode(), (base + ".gp").encode(),
+                                     (base + ".ps").encode())
+    assert rc == 0
+    assert open(base + ".dat").read() == str(g[name + "_dat"])
+    assert open(base + ".gp").read() == str(g[name + "_gp"])
