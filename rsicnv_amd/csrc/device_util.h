@@ -26,11 +26,16 @@ struct FillList {
   unsigned int value[kFillMax];
   int n;
 };
+// First failure of this thread's launches since the last wait (kernels.h: RSI_LAUNCH records, the pipeline's next ctx_sync
+// collects and fails the run).  Defined here because a FillList that cannot take another range fails the same way.
+inline thread_local hipError_t tl_launch_error = hipSuccess;
 inline void fill_add(FillList& f, void* p, size_t bytes, unsigned int value) {   // host side; bytes rounded up to 16
   if (!p || bytes == 0) return;
-  if (f.n >= kFillMax) {   // a dropped range = stale counters behind it (wrong medians, a hand-over that never completes): never silent
+  if (f.n >= kFillMax) {   // a dropped range = stale counters behind it (wrong medians, a hand-over that never completes): never
+                           // silent, and never the host application's death either -- the run that carries the list fails
     fprintf(stderr, "librsi_hot: FillList overflow (more than %d ranges): raise kFillMax\n", kFillMax);
-    abort();
+    if (tl_launch_error == hipSuccess) tl_launch_error = hipErrorInvalidValue;
+    return;
   }
   f.p[f.n] = p; f.units[f.n] = (bytes + 15) / 16; f.value[f.n] = value; ++f.n;
 }

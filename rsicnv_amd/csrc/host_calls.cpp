@@ -85,7 +85,7 @@ void DepthPager::fetch(int64_t p0, int64_t p1) {
   const double t0 = tick_ms();
   if (!mirror_) {
     mirror_ = mirror_source_ ? mirror_source_() : nullptr;
-    if (!mirror_) { fprintf(stderr, "rsi_hot: no host memory for the depth mirror\n"); abort(); }
+    if (!mirror_) { failed_ = true; return; }   // the caller checks failed() and fails the run (RSI_ERR_INTERNAL)
   }
   const int64_t lo = p0 << kBits;
   int64_t hi = ((p1 + 1) << kBits);
@@ -450,6 +450,7 @@ void sharpen_edges(const View& A, Candidate& c) {
   if (to > A.size() - 2 * len) return;
   A.prefetch((int64_t)from - len - 1, (int64_t)to + len + 1);
   const int* p = A.raw();
+  if (!p) return;   // the pager has no host memory for its mirror (DepthPager::failed(): the caller fails the run)
   int64_t diff = 0;
   for (int k = from - len; k < from; ++k) diff += p[k];
   for (int k = from; k < from + len; ++k) diff -= p[k];

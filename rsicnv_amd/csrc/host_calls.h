@@ -42,8 +42,9 @@ class DepthPager {
   int64_t size() const { return n_; }
   int operator[](int64_t i) {
     if (!have_[(size_t)(i >> kBits)]) fetch(i >> kBits, i >> kBits);
-    return mirror_[i];
+    return failed_ ? 0 : mirror_[i];
   }
+  bool failed() const { return failed_; }   // no host memory for the mirror: every value read since was 0, the results are void
   void prefetch(int64_t lo, int64_t hi);   // [lo, hi] clipped to the array, one copy per missing stretch
   const int32_t* raw() const { return mirror_; }   // valid only inside prefetched ranges
   int64_t bytes_fetched() const { return fetched_; }
@@ -63,6 +64,7 @@ class DepthPager {
   void wait();
   int64_t fetched_ = 0;
   double fetch_ms_ = 0;
+  bool failed_ = false;
 };
 
 // wall-clock split of the candidate stages (ms), filled when CallerInput::prof is set

@@ -15,8 +15,7 @@ namespace rsik {
 // and keeps the first failure in a thread-local slot; the pipeline's next wait (ctx_sync) collects it.  A context's launches all
 // come from the thread that runs it, and the entry points drain whatever the host application's own calls left in the runtime's
 // slot before the first launch (drain_stale_errors), so only this library's launches are attributed to a run.
-inline thread_local hipError_t tl_launch_error = hipSuccess;
-inline void note_launch() {
+inline void note_launch() {   // tl_launch_error: device_util.h
   const hipError_t e = hipGetLastError();   // cleared by the read
   if (e != hipSuccess && tl_launch_error == hipSuccess) tl_launch_error = e;
 }

@@ -526,24 +526,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_gc_hist(const int32_t* __restri
 // Tail of the 20-slice write-back (gccontent.cpp:156-175; App. A Q2/Q3) and the ragged last quad
 // that the streaming kernel leaves out.  One wave (the last workgroup of K3).  adjust = 0: only the ragged quad's values are
 // added to the histogram (the -NOGC path has no slices).
-__device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
-                                     const double* __restrict__ table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
-                                     uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
+// The cells' old and new values go through `hist_add(value)` / `hist_sub(value)`: the global histogram (gc_tail_fixup below) or
+// a workgroup's LDS copy of it (K2j's tail).
+template <class Add, class Sub>
+__device__ inline void gc_tail_fixup_with(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                                          const double* table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
+                                          Add hist_add, Sub hist_sub) {
   // called by wave 0 of one workgroup; lane k handles tail cell k (r <= 19)
   const double rdmean = adjust ? table[kGcLevels] : 0.0;
   const int lane = threadIdx.x;
   const int64_t ragged = n & ~(int64_t)3;   // first base not consumed by the streaming kernel
-  auto hist_add = [&](int to) {
-    if (!ghist) return;
-    if (to >= 0 && to < kHistValues) { atomicAdd(&ghist[to], 1u); if (to >= kValLds) atomicMax(&aux->vmax, (unsigned int)to); }
-    else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
-    else atomicOr(&aux->negatives, 1u);
-  };
-  auto hist_sub = [&](int from) {
-    if (!ghist) return;
-    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
-    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
-  };
   // what the streaming loop wrote to out[i]: recomputed here, because a plain load of another workgroup's plain store
   // of the same launch may be stale (device_util.h); window rule of App. A Q1
   auto streamed = [&](int64_t i) {
@@ -580,6 +572,22 @@ __device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const ui
     hist_add(depth[idx]);
     if (out) out[idx] = depth[idx];
   }
+}
+__device__ inline void gc_tail_fixup(const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n,
+                                     const double* __restrict__ table /* [kGcLevels] + rdmean */, int adjust, int32_t* __restrict__ out,
+                                     uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux) {
+  auto hist_add = [&](int to) {
+    if (!ghist) return;
+    if (to >= 0 && to < kHistValues) { atomicAdd(&ghist[to], 1u); if (to >= kValLds) atomicMax(&aux->vmax, (unsigned int)to); }
+    else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&aux->vmax, (unsigned int)to); }
+    else atomicOr(&aux->negatives, 1u);
+  };
+  auto hist_sub = [&](int from) {
+    if (!ghist) return;
+    if (from >= 0 && from < kHistValues) atomicSub(&ghist[from], 1u);
+    else if (from >= kHistValues) atomicAdd(&aux->big, (unsigned long long)-1ll);
+  };
+  gc_tail_fixup_with(depth, gcbits, n, table, adjust, out, hist_add, hist_sub);
 }
 
 // Median walk of partition_stat_tp (wufunctions.cpp:398-420, dy = 1) over hist[kHistValues] for `total` values by one
@@ -728,6 +736,15 @@ constexpr int kJOffFlags = kJOffEscCnt + kGcLevels;              // [8]: workgro
 constexpr int kJOffEscSum = kJOffFlags + 8;                      // [202] 64-bit sums of the escapes' depths (8-byte aligned)
 constexpr int kJSlabWords = kJOffEscSum + 2 * kGcLevels;         // 26672, a multiple of 4
 static_assert(kJSlabWords % 4 == 0 && (kJOffEscSum % 2) == 0 && kJPacked % 4 == 0, "slab layout");
+// A workgroup's pair counters are mostly zero (a chromosome's window GC counts cover 50 - 80 of the 202 levels, its depths a
+// quarter of the 256 values): the slab is written, and folded, in BLOCKS of 32 words (a level's row = 4 blocks of 64 values),
+// only the blocks that hold a count.  Behind the slab image: the workgroup's block bitmap (26 words), then words that stay zero
+// (the quad at +28 is what a folding lane reads in place of a block its member did not write).
+constexpr int kJBlocks = kJPacked / 32;                          // 808
+constexpr int kJBitWords = (kJBlocks + 31) / 32;                 // 26
+constexpr int kJSlabStride = kJSlabWords + 32;                   // words between two workgroups' slabs
+constexpr int kJZeroQuad = kJSlabWords + 28;
+static_assert(kJPacked % 32 == 0 && kJBitWords <= 28 && kJSlabStride % 4 == 0, "block bitmap layout");
 // the folded totals (global, zero before the launch): H as 32-bit counters, then the slab's tail as it is
 constexpr int kJTotH = kGcLevels * 256;
 constexpr int kJTotWords = kJTotH + (kJSlabWords - kJPacked);
@@ -777,7 +794,9 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   __shared__ unsigned int s_nesc;
   __shared__ WaveGc s_gc[kJWaves];
   __shared__ unsigned int s_flag, s_hi;
+  __shared__ unsigned int s_bits[32];   // blocks of the pair counters that hold a count (kJBitWords words; the rest stay zero)
   for (int e = threadIdx.x; e < kJSlabWords; e += kJThreads) s_j[e] = 0;
+  if (threadIdx.x < 32) s_bits[threadIdx.x] = 0u;
   if (threadIdx.x == 0) s_nesc = 0u;
   __syncthreads();
   unsigned int* const my_list = esc_list + (size_t)blockIdx.x * (1 + kJEscPerWg);
@@ -877,7 +896,16 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   // ---- did a 16-bit field wrap?  The fields must add up to what the lanes counted into them ----
   {
     unsigned int have = 0;
-    for (int e = threadIdx.x; e < kJPacked; e += kJThreads) { const unsigned int w = s_j[e]; have += (w & 0xffffu) + (w >> 16); }
+    for (int e = threadIdx.x; e < kJPacked; e += kJThreads) {   // whole waves (kJPacked is a multiple of 64): a wave's 64 words are two blocks
+      const unsigned int w = s_j[e];
+      have += (w & 0xffffu) + (w >> 16);
+      const unsigned long long nz = __ballot(w != 0u);
+      if (lane == 0 && nz != 0ull) {
+        const int b = e >> 5;
+        if (nz & 0xffffffffull) atomicOr(&s_bits[b >> 5], 1u << (b & 31));
+        if (nz >> 32) atomicOr(&s_bits[(b + 1) >> 5], 1u << ((b + 1) & 31));
+      }
+    }
     unsigned int diff = nfast - have;   // modulo 2^32: zero over the workgroup iff nothing wrapped (a workgroup sees < 2^31 bases)
     for (int d = 32; d >= 1; d >>= 1) { diff += __shfl_xor(diff, d); escapes += __shfl_xor(escapes, d); negs |= __shfl_xor(negs, d); }
     if (threadIdx.x == 0) s_flag = 0u;
@@ -895,10 +923,15 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   // ---- slab out (16-byte write-through stores), then the two-level hand-over of device_util.h with a fold of its own: the
   // last workgroup of a group unpacks the group's slabs into 32-bit sums and adds them to the totals ----
   {
-    unsigned int* slab = slabs + (size_t)blockIdx.x * kJSlabWords;
+    unsigned int* slab = slabs + (size_t)blockIdx.x * kJSlabStride;
     for (int q = threadIdx.x; q < kJSlabWords / 4; q += kJThreads) {
+      if (4 * q < kJPacked && !((s_bits[q >> 8] >> ((q >> 3) & 31)) & 1u)) continue;   // block q / 8 holds no count: not written
       u32x4 v; v.x = s_j[4 * q]; v.y = s_j[4 * q + 1]; v.z = s_j[4 * q + 2]; v.w = s_j[4 * q + 3];
       st_cg_x4(slab + 4 * q, v);
+    }
+    if (threadIdx.x < 8) {   // the bitmap and the zero words behind it
+      u32x4 v; v.x = s_bits[4 * threadIdx.x]; v.y = s_bits[4 * threadIdx.x + 1]; v.z = s_bits[4 * threadIdx.x + 2]; v.w = s_bits[4 * threadIdx.x + 3];
+      st_cg_x4(slab + kJSlabWords + 4 * threadIdx.x, v);
     }
   }
   const int nblocks = (int)gridDim.x;
@@ -916,41 +949,73 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   __syncthreads();
   if (!s_flag) return;
   {
-    const unsigned int* src = slabs + (size_t)grp * per_group * kJSlabWords;
+    const unsigned int* src = slabs + (size_t)grp * per_group * kJSlabStride;
     const int last = __builtin_amdgcn_readfirstlane(members - 1);
-    for (int q = threadIdx.x; q < kJSlabWords / 4; q += kJThreads) {
+    // the members' block bitmaps (the slab image in LDS is not needed any more), their union as a list of blocks
+    unsigned int* m_bits = s_j;                 // [members][32]
+    unsigned int* b_list = s_j + 32 * 32;       // up to kJBlocks entries
+    for (int e = threadIdx.x; e < members * 32; e += kJThreads) m_bits[e] = ld_cg(src + (size_t)(e >> 5) * kJSlabStride + kJSlabWords + (e & 31));
+    if (threadIdx.x == 0) s_hi = 0u;
+    __syncthreads();
+    for (int b = threadIdx.x; b < kJBlocks; b += kJThreads) {
+      unsigned int any = 0;
+      for (int k = 0; k <= last; ++k) any |= m_bits[k * 32 + (b >> 5)];
+      if ((any >> (b & 31)) & 1u) b_list[atomicAdd(&s_hi, 1u)] = (unsigned int)b;
+    }
+    __syncthreads();
+    const int nlist = (int)s_hi;
+    const unsigned long long src_base = uniform_address(src);
+    // ---- the pair counters: the quads of the listed blocks; a member that did not write a block is read at its zero quad ----
+    for (int idx = threadIdx.x; idx < nlist * 8; idx += kJThreads) {
+      const int b = (int)b_list[idx >> 3];
+      const int q = b * 8 + (idx & 7);
       unsigned int lo4[4] = {0, 0, 0, 0}, hi4[4] = {0, 0, 0, 0};
-      const bool packed = 4 * q < kJPacked;
+      for (int k0 = 0; k0 <= last; k0 += 8) {
+        unsigned int off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j < last ? k0 + j : last;
+          const bool has = (m_bits[k * 32 + (b >> 5)] >> (b & 31)) & 1u;
+          off[j] = ((unsigned int)k * (unsigned int)kJSlabStride + (has ? (unsigned int)q * 4u : (unsigned int)kJZeroQuad)) * 4u;
+        }
+        u32x4 v[8];
+        ld_cg_x4_batch8(v, src_base, off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j <= last) {
+          const unsigned int w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { lo4[c] += w[c] & 0xffffu; hi4[c] += w[c] >> 16; }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ws = 4 * q + c;                                            // word g * 128 + (pair ^ (g & 31)) of the slab
+        const int wi = (ws & ~127) | ((ws & 127) ^ (int)((ws >> 7) & swz));     // <-> counters 2 * wi, 2 * wi + 1 of the 32-bit table
+        if (lo4[c]) atomicAdd(&tot[2 * wi], lo4[c]);
+        if (hi4[c]) atomicAdd(&tot[2 * wi + 1], hi4[c]);
+      }
+    }
+    // ---- behind them: the zero / escape counters per level, the flags, the escapes' 64-bit sums (always written) ----
+    for (int q = kJPacked / 4 + threadIdx.x; q < kJSlabWords / 4; q += kJThreads) {
+      unsigned int lo4[4] = {0, 0, 0, 0}, hi4[4] = {0, 0, 0, 0};
       for (int k0 = 0; k0 <= last; k0 += 8) {
         unsigned long long b[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = uniform_address(src + (size_t)(k0 + j < last ? k0 + j : last) * kJSlabWords);
+        for (int j = 0; j < 8; ++j) b[j] = uniform_address(src + (size_t)(k0 + j < last ? k0 + j : last) * kJSlabStride);
         u32x4 v[8];
         ld_cg_x8(v, (unsigned int)q * 16u, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (k0 + j <= last) {
           const unsigned int w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (packed) { lo4[c] += w[c] & 0xffffu; hi4[c] += w[c] >> 16; }
-            else { const unsigned int o = lo4[c]; lo4[c] += w[c]; hi4[c] += lo4[c] < o; }   // plain words; hi4 = carries (the 64-bit sums' low halves)
-          }
+          for (int c = 0; c < 4; ++c) { const unsigned int o = lo4[c]; lo4[c] += w[c]; hi4[c] += lo4[c] < o; }   // plain words; hi4 = carries (the 64-bit sums' low halves)
         }
       }
-      if (packed) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int ws = 4 * q + c;                                            // word g * 128 + (pair ^ (g & 31)) of the slab
-          const int wi = (ws & ~127) | ((ws & 127) ^ (int)((ws >> 7) & swz));     // <-> counters 2 * wi, 2 * wi + 1 of the 32-bit table
-          if (lo4[c]) atomicAdd(&tot[2 * wi], lo4[c]);
-          if (hi4[c]) atomicAdd(&tot[2 * wi + 1], hi4[c]);
-        }
-      } else if (4 * q < kJOffEscSum) {
+      if (4 * q < kJOffEscSum) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (lo4[c]) atomicAdd(&tot[kJTotH + (4 * q + c - kJPacked)], lo4[c]);
       } else {   // the escapes' 64-bit sums: two per vector; each slab's value is below 2^63, eight of them are added as (low, high) halves
         unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tot + kJTotH + (4 * q - kJPacked));
-        // recombine per slab pair is not needed: sum of lows with carries + sum of highs
         const unsigned long long a = (unsigned long long)lo4[0] + ((unsigned long long)hi4[0] << 32) + ((unsigned long long)lo4[1] << 32);
         const unsigned long long c2 = (unsigned long long)lo4[2] + ((unsigned long long)hi4[2] << 32) + ((unsigned long long)lo4[3] << 32);
         if (a) atomicAdd(&t64[0], a);
@@ -1041,10 +1106,11 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   __syncthreads();
   // ---- the ragged last n % 4 bases: the stale-window zone i >= n-101, count of [n-202, n-2] (App. A Q1); table only (the value
   // histogram gets them from gc_tail_fixup, as raw depths) ----
-  __shared__ unsigned int s_esc_total, s_list_over;
+  __shared__ unsigned int s_esc_total, s_list_over, s_bad_flags;
   if (threadIdx.x == 0) {
-    unsigned int fl_neg = ld_cg(t_flags + 0);
-    unsigned long long esc = ld_cg(t_flags + 1);
+    const u32x4 f4 = ld_cg_x4(t_flags);   // negative depth seen | escapes | a workgroup's counters wrapped | a list ran over: ONE round trip
+    unsigned int fl_neg = f4.x;
+    unsigned long long esc = f4.y;
     if ((n & 3) != 0) {
       const int g = gc_window_count(gcbits, n - 202);
       for (int64_t i = n & ~(int64_t)3; i < n; ++i) {
@@ -1058,10 +1124,12 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
       }
     }
     acc->possum = r_misc[0]; acc->poscnt = r_misc[1];
-    acc->negatives = (fl_neg ? 1u : 0u) | (ld_cg(t_flags + 2) ? 4u : 0u);   // bit 2: a workgroup's 16-bit counters wrapped, nothing below is valid
-    acc->escapes = esc > 0xffffffffull ? 0xffffffffu : (unsigned int)esc;
-    s_esc_total = acc->escapes;
-    s_list_over = ld_cg(t_flags + 3);
+    s_bad_flags = (fl_neg ? 1u : 0u) | (f4.z ? 4u : 0u);
+    acc->negatives = s_bad_flags;   // bit 2: a workgroup's 16-bit counters wrapped, nothing below is valid
+    const unsigned int esc32 = esc > 0xffffffffull ? 0xffffffffu : (unsigned int)esc;
+    acc->escapes = esc32;
+    s_esc_total = esc32;
+    s_list_over = f4.w;
   }
   __syncthreads();
   const unsigned long long ps = r_misc[0], pc = r_misc[1];
@@ -1152,11 +1220,87 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     if (lane == 0 && lane_hi) atomicMax(&s_hi, lane_hi);
   }
   __syncthreads();
+  // ---- histogram side of the tail quirks of the 20-slice write-back (App. A Q2/Q3) and the ragged bases, as K3' does it: on the
+  // LDS counters where the values lie inside them, else on the global histogram (marking s_hi, which sends the rest of the
+  // tail down the global road) ----
+  if (threadIdx.x < 64) {
+    auto t_add = [&](int to) {
+      if (to >= 0 && to < kJRh) atomicAdd(&r_hist[to], 1u);
+      else if (to >= 0 && to < kHistValues) { atomicAdd(&ghist[to], 1u); atomicMax(&s_hi, (unsigned int)to); }
+      else if (to >= kHistValues) { atomicAdd(&aux->big, 1ull); atomicMax(&s_hi, 0xffffffffu); }
+      else { atomicOr(&aux->negatives, 1u); atomicMax(&s_hi, 0xffffffffu); }
+    };
+    auto t_sub = [&](int from) {
+      if (from >= 0 && from < kJRh) atomicSub(&r_hist[from], 1u);
+      else if (from >= 0 && from < kHistValues) { atomicSub(&ghist[from], 1u); atomicMax(&s_hi, (unsigned int)from); }
+      else if (from >= kHistValues) { atomicAdd(&aux->big, (unsigned long long)-1ll); atomicMax(&s_hi, 0xffffffffu); }
+    };
+    gc_tail_fixup_with(depth, gcbits, n, r_tab, 1, nullptr, t_add, t_sub);
+  }
+  __syncthreads();
+  // ---- the walk to the median apply_cap needs (loaddata.cpp:233; partition_stat_tp's walk, wufunctions.cpp:398-420, dy = 1).
+  // Every rescaled value below kJRh (all of them, on any ordinary chromosome): the histogram never leaves LDS -- counts, the
+  // bucket where the running count reaches n / 2, smallest and largest value, the cap for a queued K4j, all from registers
+  // and LDS; what used to be eight global round trips (flush, drain, fix-up, drain, reload, walk, reload, reload).  Nobody reads
+  // the global histogram of a chromosome without pending escapes, so it is not written either. ----
+  const bool lds_walk = !esc_pending && s_hi == 0u;
+  __shared__ unsigned long long s_wsum[kJWaves];
+  __shared__ int s_wlo[kJWaves], s_whi[kJWaves], s_wmed;
+  if (lds_walk) {
+    constexpr int kPer = (kJRh + kJThreads - 1) / kJThreads;   // 11 consecutive counters per thread
+    const int v0 = threadIdx.x * kPer;
+    unsigned int c[kPer];
+    unsigned long long local = 0;
+    int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      c[i] = v0 + i < kJRh ? r_hist[v0 + i] : 0u;
+      local += c[i];
+      if (c[i]) { lo = v0 + i < lo ? v0 + i : lo; hi = v0 + i; }
+    }
+    const unsigned long long incl = (unsigned long long)wave_incl_scan((long long)local);
+    int wlo = lo, whi = hi;
+    for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(wlo, d), b2 = __shfl_xor(whi, d); wlo = a < wlo ? a : wlo; whi = b2 > whi ? b2 : whi; }
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) { s_wlo[wave] = wlo; s_whi[wave] = whi; }
+    if (threadIdx.x == 0) s_wmed = -1;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    int glo = 0x7fffffff, ghi = -1;
+    for (int w = 0; w < kJWaves; ++w) { if (w < wave) before += s_wsum[w]; all += s_wsum[w]; glo = s_wlo[w] < glo ? s_wlo[w] : glo; ghi = s_whi[w] > ghi ? s_whi[w] : ghi; }
+    const unsigned long long r2 = (unsigned long long)n / 2;
+    unsigned long long seen = before + incl - local;
+    if (local != 0 && seen < r2 && seen + local >= r2) {   // the walk's bucket lies in this thread's stretch
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const unsigned long long upto = seen + c[i];
+        if (seen < r2 && upto >= r2) s_wmed = v0 + i;
+        seen = upto;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int med = s_wmed;
+      st_cg(&vm->inrange, all);
+      st_cg(reinterpret_cast<unsigned int*>(&vm->lo), (unsigned int)glo); st_cg(reinterpret_cast<unsigned int*>(&vm->hi), (unsigned int)ghi);
+      st_cg(reinterpret_cast<unsigned int*>(&vm->med), (unsigned int)med); st_cg(reinterpret_cast<unsigned int*>(&vm->pad), 0u);
+      // the cap as apply_cap takes it (loaddata.cpp:233-238: median of the uncompacted array, RD = median * cap truncated), for a
+      // K4j queued right behind this launch; the host derives the same number from the header and checks everything else
+      if (cap_mult > 1.0) {
+        double qm = (double)glo;
+        if (glo <= ghi && (double)ghi - (double)glo >= 1.0 && med >= 0) qm = (double)med;
+        const bool ok = all == (unsigned long long)n && (unsigned long long)n / 2 <= all && s_bad_flags == 0u;   // (nothing went to aux->big on this road)
+        pp->capval = ok ? (int32_t)(qm * cap_mult) : -1;
+      }
+    }
+    sync_drained();
+    export_words(head_dst, head_src, head_bytes);
+    return;
+  }
+  // ---- the global road: values beyond the LDS counters, or escapes still to come (k_escape_hist adds them and walks again) ----
   for (int e = threadIdx.x; e < kJRh; e += kJThreads) { const unsigned int c = r_hist[e]; if (c) { atomicAdd(&ghist[e], c); atomicMax(&s_hi, (unsigned int)e); } }
   sync_drained();
   if (threadIdx.x == 0 && s_hi >= (unsigned int)kValLds) atomicMax(&aux->vmax, s_hi >= (unsigned int)kHistValues ? (unsigned int)kHistValues : s_hi);
-  // histogram side of the tail quirks of the 20-slice write-back (App. A Q2/Q3) and the ragged bases, as K3' does it
-  if (threadIdx.x < 64) gc_tail_fixup(depth, gcbits, n, table, 1, nullptr, ghist, aux);
   sync_drained();
   {
     const unsigned int hi = ld_cg(&aux->vmax);
@@ -1167,15 +1311,13 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     value_median_block<kJThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
   }
   sync_drained();
-  // the cap as apply_cap takes it (loaddata.cpp:233-238: median of the uncompacted array, RD = median * cap truncated), for a
-  // K4j queued right behind this launch; the host derives the same number from the header and checks everything else
   if (threadIdx.x == 0 && !esc_pending && cap_mult > 1.0) {
     const int lo = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->lo)), hi = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->hi));
     const int med = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->med));
     double qm = (double)lo;
     if (lo <= hi && (double)hi - (double)lo >= 1.0 && med >= 0) qm = (double)med;
     const unsigned long long inr = ld_cg(&vm->inrange);
-    const bool ok = inr + aux->big == (unsigned long long)n && (unsigned long long)n / 2 <= inr && !(ld_cg(t_flags + 2)) && !(ld_cg(t_flags + 0));
+    const bool ok = inr + aux->big == (unsigned long long)n && (unsigned long long)n / 2 <= inr && s_bad_flags == 0u;
     pp->capval = ok ? (int32_t)(qm * cap_mult) : -1;
   }
   sync_drained();
@@ -2304,7 +2446,7 @@ static int gc_joint_grid(int64_t n) {
   if (grid > 256) grid = 256;   // one workgroup per CU: its histogram takes 107 KB of LDS
   return (int)(grid < 1 ? 1 : grid);
 }
-size_t gc_joint_slab_bytes(int64_t n) { return (size_t)gc_joint_grid(n) * kJSlabWords * 4; }
+size_t gc_joint_slab_bytes(int64_t n) { return (size_t)gc_joint_grid(n) * kJSlabStride * 4; }
 size_t gc_joint_totals_bytes() { return (size_t)kJTotWords * 4; }
 size_t gc_joint_esc_list_bytes() { return (size_t)256 * (1 + kJEscPerWg) * 4; }
 void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,

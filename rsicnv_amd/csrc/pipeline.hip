@@ -669,7 +669,18 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   if (runs.empty()) return RSI_OK;
   std::vector<int64_t> poff(runs.size() + 1, 0);
   std::vector<SegItem> items;
-  const int64_t kPairsPerItem = 1 << 16;   // about 256 pairs per thread: enough workgroups to cover the chip
+  // About 256 (L, offset) pairs per thread of a workgroup in a pool that shares the chip (a long, thin kernel there costs the
+  // other chromosomes next to nothing).  A chromosome that has the chip to itself (a stand-alone context, a pool run over a
+  // few chromosomes) waits for exactly this kernel: as many items as still ride in the kernel arguments (kItemsInline), down
+  // to 32 pairs per thread -- a 60 Mb chromosome's 2 M pairs then spread over ~130 workgroups instead of ~35.
+  int64_t pairs_per_item = 1 << 16;
+  if (!ctx->gate || ctx->gate->few_chromosomes.load()) {
+    int64_t total = 0;
+    for (const Region& r : runs) { const int64_t len = r.end - r.start + 1; total += len * (len + 1) / 2; }
+    const int64_t room = std::max<int64_t>(8, (int64_t)kItemsInline - 2 * (int64_t)runs.size());   // every run's last item is a partial one
+    pairs_per_item = std::min<int64_t>(pairs_per_item, std::max<int64_t>(1 << 13, total / room + 1));
+  }
+  const int64_t kPairsPerItem = pairs_per_item;
   for (size_t r = 0; r < runs.size(); ++r) {
     const int len = runs[r].end - runs[r].start + 1;
     poff[r + 1] = poff[r] + len + 1;
@@ -1321,6 +1332,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     in.tester = host_tests ? nullptr : &tester;
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
     if (tester.failed) return RSI_ERR_HIP;
+    if (pager.failed()) return fail(ctx, RSI_ERR_INTERNAL, "no pinned host memory for the candidate stages' depth mirror");
     ctx->phases.push_back({"calls.device(wait)", tester.kernel_wait_ms});
     ctx->phases.push_back({"calls.device_ms", prof.device_ms});
     ctx->phases.push_back({"calls.final", prof.final_tests});
