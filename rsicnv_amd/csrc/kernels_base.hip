@@ -2152,6 +2152,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
   const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
   const int parts = kThreads / TB;          // threads cooperating on one bin
   const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
+  const float inv_m = 1.0f / (float)m;      // for the median phase's first guess only (any guess gives the same median)
   // the 20-slice write-back's tail (App. A Q2/Q3): cells n-201 .. n-201+r-1 carry the rescaled depth of the last r bases,
   // computed with the fresh edge window [n-201, n-1]; the last r bases keep their raw depth
   const int64_t S20 = n / 20, r20 = n - 20 * S20;
@@ -2325,17 +2326,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         xo[i] = (v | ~keep) | 0x80808080u;
       }
       ssum = (uint32_t)parts_sum((int)ssum, parts);
-      int lo = 0, hi = capval;
-#pragma unroll 1
-      for (int it = 0; it < 7; ++it) {
-        const int mid = (lo + hi) >> 1;
-        const uint32_t sub = (uint32_t)(mid + 1) * 0x01010101u;
+      // #{x <= t} of the bin, t = -1 .. 126 (masked bytes, 0xff, always count as "> t": 28 dword slots x 4 bytes - m of them per bin)
+      auto count_le = [&](int t) {
+        const uint32_t sub = (uint32_t)(t + 1) * 0x01010101u;
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xo[i] - sub) & 0x80808080u);
-        gt = parts_sum(gt, parts);
-        // masked bytes (0xff) always count as "> mid" (mid <= 126): 28 dword slots x 4 bytes - m of them per bin
-        const int le = 4 * 7 * parts - gt;
+        return 4 * 7 * parts - parts_sum(gt, parts);
+      };
+      // The median of a bin lies next to its mean: eight values around sum / m bracket it on all but a handful of bins (event
+      // edges), and three bisection steps inside the bracket plus the two counts that prove it replace seven steps from
+      // [0, cap].  A wave with a bin outside its bracket takes the seven steps (the result is the same either way).
+      int lo = 0, hi = capval, steps = 7;
+      {
+        const int est = (int)((float)ssum * inv_m);
+        int lo0 = est - 3;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        int hi0 = lo0 + 7;
+        hi0 = hi0 > capval ? capval : hi0;
+        lo0 = lo0 > hi0 ? hi0 : lo0;
+        const bool below = count_le(lo0 - 1) < kth;                                   // the median is not below the bracket
+        const bool above = hi0 >= capval || count_le(hi0 > 126 ? 126 : hi0) >= kth;   // ... nor above it (every value is <= cap)
+        if (__all((below && above) || !active)) { lo = lo0; hi = hi0; steps = 3; }
+      }
+#pragma unroll 1
+      for (int it = 0; it < steps; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const int le = count_le(mid);
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
       }
       if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
@@ -2363,16 +2380,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_rescale_compact_bin8(
         xc[i] = ((xb >> 8) & 0x00ff00ffu) | 0x80008000u;
       }
       ssum = (uint32_t)parts_sum((int)ssum, parts);
-      int lo = 0, hi = capval;
-#pragma unroll 1
-      for (int it = 0; it < 8; ++it) {
-        const int mid = (lo + hi) >> 1;
-        const uint32_t sub = (uint32_t)(mid + 1) * 0x00010001u;
+      auto count_le = [&](int t) {   // #{x <= t}, t = -1 .. 252; masked bytes (0xff) always count as "> t"
+        const uint32_t sub = (uint32_t)(t + 1) * 0x00010001u;
         int gt = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) gt += __popc((xa[i] - sub) & 0x80008000u) + __popc((xc[i] - sub) & 0x80008000u);
-        gt = parts_sum(gt, parts);
-        const int le = 4 * 7 * parts - gt;   // masked bytes (0xff) always count as "> mid" (mid <= 252)
+        return 4 * 7 * parts - parts_sum(gt, parts);
+      };
+      // bracket of sixteen values around the bin's mean (deeper coverage: wider bins of values), four steps inside it
+      int lo = 0, hi = capval, steps = 8;
+      {
+        const int est = (int)((float)ssum * inv_m);
+        int lo0 = est - 7;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        int hi0 = lo0 + 15;
+        hi0 = hi0 > capval ? capval : hi0;
+        lo0 = lo0 > hi0 ? hi0 : lo0;
+        const bool below = count_le(lo0 - 1) < kth;
+        const bool above = hi0 >= capval || count_le(hi0 > 252 ? 252 : hi0) >= kth;
+        if (__all((below && above) || !active)) { lo = lo0; hi = hi0; steps = 4; }
+      }
+#pragma unroll 1
+      for (int it = 0; it < steps; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const int le = count_le(mid);
         if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
       }
       if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
