@@ -119,7 +119,7 @@ size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup hist
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
-                       hipStream_t stream);
+                       hipStream_t stream, uint8_t* out8 = nullptr);
 // Only the rescaled array: out[] as the launch above leaves it, nothing else touched (rsi_hot_fetch of "rd_gc" when the run
 // itself streamed the byte copy and never wrote the int32 array).
 void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,
@@ -177,7 +177,7 @@ void launch_cap_compact_bin8(const uint8_t* rescaled8, const int32_t* depth, con
                              const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
                              int m, uint8_t* rdc8 /* ncompact + 64 bytes: the capped, compacted depth as bytes */, int32_t* binmed, int64_t* binsum,
                              uint32_t* res_hist, void* slabs, void* gsum,
-                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream);
+                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream, int raw = 0);
 
 // K4j: K4' fed from the byte copy of the RAW depth (K2 / K2j's depth8), rescaling on the way with the GC table -- same outputs.
 void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,

@@ -1378,7 +1378,8 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
                                                          int per_group, unsigned int* __restrict__ counters,
                                                          ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
-                                                         unsigned int head_bytes, int materialize /* 1: only out[] is produced */) {
+                                                         unsigned int head_bytes, int materialize /* 1: only out[] is produced */,
+                                                         uint8_t* __restrict__ out8 /* optional: the values as bytes, saturated at kByteSat (-NOGC: what K4' compacts) */) {
   __shared__ GcTile gt;
   __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
   __shared__ double s_table[kGcLevels];
@@ -1432,6 +1433,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
         lane_hi = h > lane_hi ? h : lane_hi;
       }
       if (out) *reinterpret_cast<int4*>(out + q) = make_int4(v0, v1, v2, v3);
+      if (out8) {
+        auto sat = [](int v) -> uint32_t { return v < 0 ? 0u : (v > kByteSat ? (uint32_t)kByteSat : (uint32_t)v); };
+        *reinterpret_cast<uint32_t*>(out8 + q) = sat(v0) | (sat(v1) << 8) | (sat(v2) << 16) | (sat(v3) << 24);
+      }
     }
   };
   TileRegs ra, rb;
@@ -1449,6 +1454,10 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
     tile += gridDim.x;
   }
   __syncthreads();
+  if (out8 && blockIdx.x == 0 && threadIdx.x < 4) {   // the ragged last n % 4 bases (the loop consumes whole quads)
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    if (i < n) { const int v = depth[i]; out8[i] = (uint8_t)(v < 0 ? 0 : (v > kByteSat ? kByteSat : v)); }
+  }
   if (materialize) return;   // the tail quirks are applied to out[] by a launch of their own (k_gc_tail_fixup_out)
   publish_hist_hi(lane_hi, aux);
   value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, vb, width, phsh);
@@ -1884,7 +1893,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
     const int64_t* __restrict__ cum, int nreg, int64_t ncompact, int32_t capval, int m, int TB, int vr, uint8_t* __restrict__ rdc8 /* capped + compacted depth, one byte per base */,
     int32_t* __restrict__ binmed,
     int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist, unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum,
-    int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
+    int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl,
+    int raw /* 1: r8 is the RAW depth (-NOGC): no rescale and no slice quirks on the per-element path either */) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* s_val = smem;                                                              // MAXC * 256 chunks of 16 bytes
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 16);   // [vr][32]
@@ -1917,6 +1927,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
 
   auto rescale = [&](int d, uint32_t g) { return (int)((double)d * rdmean / s_table[g] + 0.5); };   // gccontent.cpp:89, truncation
   auto slow_value = [&](int64_t i) -> int {   // the value K3 + its tail fixup would have left at source index i
+    if (raw) return depth[i];
     if (r20 >= 2 && i >= n - 201 && i < n - 201 + r20) return rescale(depth[20 * S20 + (i - (n - 201))], (uint32_t)gc_count201(gcbits, n - 201));
     if (i >= 20 * S20) return depth[i];
     int64_t lo = i - 100;
@@ -2504,7 +2515,7 @@ __global__ void k_gc_tail_fixup_out(const int32_t* __restrict__ depth, const uin
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, uint8_t* out8) {
   const int grid = grid_for(n, kTileBases);
   const dim3 g(grid), b(kThreads);
   unsigned int* sl = static_cast<unsigned int*>(slabs);
@@ -2513,9 +2524,9 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   // adjust = 1 (rescaled array + histogram in one pass) is the deep-coverage path; adjust = 0, out = NULL the -NOGC histogram.
   // The tail cells of out[] get their quirks from a launch of their own (see k_gc_tail_fixup_out).
   if (adjust) {
-    RSI_LAUNCH(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+    RSI_LAUNCH(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, static_cast<uint8_t*>(nullptr));
     if (out) RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
-  } else RSI_LAUNCH(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0);
+  } else RSI_LAUNCH(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, out8);
 }
 // The tail quirks in out[] as a launch of its own: the cells it rewrites were written by other workgroups of the streaming
 // launch, and two stores to one address from different XCDs within one launch have no defined order.
@@ -2527,7 +2538,7 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
                            unsigned int* counter, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   RSI_LAUNCH(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
-                     nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1);
+                     nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1, static_cast<uint8_t*>(nullptr));
   RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
 }
 static int value_hist8_grid(int64_t n) {
@@ -2585,7 +2596,7 @@ size_t cap_compact8_slab_bytes(int m, int32_t capval, int64_t ncompact) {
 void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                              const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
                              int m, uint8_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs, void* gsum,
-                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream) {
+                             unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, hipStream_t stream, int raw) {
   int vr, grid, maxc;
   k48_geometry(m, capval, ncompact, vr, grid, maxc);
   const int TB = k48_bins_per_tile(m);
@@ -2597,7 +2608,7 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
 #define RSI_K48(MC, EP, SW) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP, SW>));                                                  \
     RSI_LAUNCH((k_cap_compact_bin8<MC, EP, SW>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
                        cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \
-                       exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
+                       exp_src, exp_dst, (unsigned int)exp_bytes, inl, raw); } while (0)
   const bool sw7 = capval <= 127;   // four values to a register in the median phase (k_cap_compact_bin8, SW7)
   (void)ept;
   if (sw7) { if (maxc == 1) RSI_K48(1, 1, true); else RSI_K48(2, 1, true); }

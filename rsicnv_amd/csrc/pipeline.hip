@@ -944,8 +944,12 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       { Timer t(ctx, packed ? "gc_hist" : "gc_hist_wide", true); launch_gc_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, packed, ctx->slabs.p, ctx->gsum.p, d_done, ctx->depth8.as<uint8_t>(), st); }
       { Timer t(ctx, "value_hist8", true); launch_value_hist8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, ctx->rescaled8.as<uint8_t>(), &d_acc->escapes, st); }
     } else if (want_cap) {
+      // -NOGC: the histogram pass for the cap median also leaves the depth as bytes (saturated at 254: K4' only needs
+      // min(value, cap) and is taken when the cap is below that), so that the compaction moves 1 + 1 bytes per base
+      // instead of 4 + 4 (loaddata.cpp:229-240, 48-85 without gccontent.cpp in front)
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
-      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st); }
+      HIPCHK(ctx->rescaled8.ensure((size_t)n + 2048));
+      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st, ctx->rescaled8.as<uint8_t>()); }
     } else {
       HIPCHK(copy_d2h(ctx, head, small, head_bytes));   // no kernel behind K1b to hand the header over: a plain copy
     }
@@ -1150,6 +1154,16 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                             ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                             ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st);
+  } else if (!P.gcadjust && want_cap && cap_compact8_applies(P.m, capval) && !(getenv("RSI_HOT_NOGC_BYTES") && atoi(getenv("RSI_HOT_NOGC_BYTES")) == 0)) {
+    // -NOGC with a cap below 254: K4' from the byte copy the histogram pass left (raw depth: no rescale anywhere)
+    HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
+    HIPCHK(ctx->rdc8.ensure((size_t)ncompact + 64));
+    ctx->rdc_is_bytes = true;
+    ctx->phases.push_back({"a5.nogc byte path", 1.0});
+    Timer t(ctx, "cap_compact_bin", true);
+    launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+                            ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
+                            ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st, 1);
   } else {
     if (P.gcadjust) {   // no cap, a cap of 255 and more, or a wide bin: K4 from the rescaled int32 array, built first
       int rcm = materialize_rd_gc(ctx);

@@ -89,6 +89,23 @@ def test_escapes_beyond_the_workgroup_lists_take_the_escape_pass(hot, hotlib, or
     _against_oracle(hot, res, O)
 
 
+def test_nogc_takes_the_byte_kernels_and_the_int32_ones_behind_the_switch(hot, hotlib):
+    """-NOGC: the histogram pass for the cap median leaves a byte copy and K4' compacts from it (round 4); RSI_HOT_NOGC_BYTES=0 is the
+    int32 K4 it used before, which a cap of 254 and more still takes.  Both against the reference's golden file, twice each."""
+    hot.set_timing(1)
+    for _ in range(2):
+        gu.check_hip_against_golden(hot, hotlib, "poisson_nogc")
+        assert "a5.nogc byte path" in dict(hot.phase_times())
+    os.environ["RSI_HOT_NOGC_BYTES"] = "0"
+    try:
+        for _ in range(2):
+            gu.check_hip_against_golden(hot, hotlib, "poisson_nogc")
+            assert "a5.nogc byte path" not in dict(hot.phase_times())
+    finally:
+        del os.environ["RSI_HOT_NOGC_BYTES"]
+    gu.check_hip_against_golden(hot, hotlib, "poisson_nb_m101")     # and a GC-adjusted chromosome behind it on the same context
+
+
 SWITCH_CASES = ["poisson_nb_m101", "gampois_nb_m101", "gampois_med_m51_cap4", "poisson_tail7"]
 
 
