@@ -652,14 +652,19 @@ struct Oracle {
       diff = diff - RD[i - 1 - len] + RD[i - 1] + RD[i - 1] - RD[i - 1 + len];
       dd.push_back(diff);
     }
+    // A candidate whose first refinement left end < start (len <= 0) has fewer than 2 * disp entries: the reference's loops
+    // (rsi.cpp:917, 930) then index its vector out of range -- undefined behaviour, heap contents decide.  The restatement
+    // (and the library, host_calls.cpp:sharpen_edges / k_sharpen_edges) searches the entries that exist; parity on such a
+    // candidate cannot be defined (divergences).
+    const int nd = (int)dd.size();
     int imax = -1; double best = 0;
-    for (int i = 0; i < 2 * disp; ++i) {
+    for (int i = 0; i < 2 * disp && i < nd; ++i) {
       if (c.type == T_DEL && dd[i] > best) { best = dd[i]; imax = i; }
       if (c.type == T_DUP && dd[i] < best) { best = dd[i]; imax = i; }
     }
     if (imax > 0) c.start = nstart + imax;
     imax = -1; best = 0;
-    for (int i = (int)dd.size() - 2 * disp; i < (int)dd.size(); ++i) {
+    for (int i = std::max(0, nd - 2 * disp); i < nd; ++i) {
       if (c.type == T_DEL && dd[i] < best) { best = dd[i]; imax = i; }
       if (c.type == T_DUP && dd[i] > best) { best = dd[i]; imax = i; }
     }

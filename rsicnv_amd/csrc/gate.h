@@ -19,6 +19,9 @@ struct GpuGate {
   std::condition_variable cv;
   int sharers = 0, streamers_waiting = 0, streaming = 0;
   std::atomic<bool> few_chromosomes{false};   // set per submitted run: so few chromosomes that latency, not sharing, decides (pipeline.hip, candidate tests)
+  std::atomic<int> in_flight{0};              // chromosomes the pool's workers are processing right now
+  // Latency, not sharing, decides: a run of a few chromosomes, or the last few of a genome with nothing queued behind it.
+  bool lonely() const { return few_chromosomes.load() || in_flight.load() <= 4; }
   int max_streamers = 3;   // per-base phases in flight: the others fill the host gaps (syncs, small decisions) and one-workgroup tails of one
   void lock_shared() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return streaming == 0 && streamers_waiting == 0; }); ++sharers; }
   void unlock_shared() { { std::lock_guard<std::mutex> lk(m); --sharers; } cv.notify_all(); }

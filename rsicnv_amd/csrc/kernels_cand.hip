@@ -140,10 +140,17 @@ __global__ __launch_bounds__(kThreads) void k_sharpen_edges(const TD* __restrict
   const int nstep = to - from;
   const int win = blockIdx.x / kEdgeChunks, chunk = blockIdx.x % kEdgeChunks;   // win 0: start search, 1: end search
   const int wlen = 2 * reach;
-  const int wbase = win == 0 ? 0 : nstep - wlen;
-  const int cs = (wlen + kEdgeChunks - 1) / kEdgeChunks;
+  // The two search windows are the first and the last 2 * reach entries of dd[0 .. nstep).  A candidate whose first
+  // refinement left end < start (len <= 0) has FEWER than 2 * reach entries: the reference's loops then index its vector out
+  // of range (rsi.cpp:917, 930: undefined); here, as in the host path (host_calls.cpp:sharpen_edges) and the oracle, both
+  // searches cover the entries that exist.  (Until round 4 this kernel continued dd's recurrence beyond the vector instead --
+  // a third answer, found by tests/test_fallback_paths.py's bimodal chromosome as one call's neighbourhood statistics.)
+  const int wbase = win == 0 ? 0 : (nstep - wlen > 0 ? nstep - wlen : 0);
+  const int wend = win == 0 ? (wlen < nstep ? wlen : nstep) : nstep;
+  const int wspan = wend > wbase ? wend - wbase : 0;
+  const int cs = (wspan + kEdgeChunks - 1) / kEdgeChunks;
   const int i0 = wbase + chunk * cs;
-  int i1 = i0 + cs; if (i1 > wbase + wlen) i1 = wbase + wlen;
+  int i1 = i0 + cs; if (i1 > wend) i1 = wend;
   const bool del = job.type == 0;
   const bool want_max = win == 0 ? del : !del;
   {   // this workgroup's share of dd at the window's first index

@@ -366,8 +366,13 @@ class DeviceTester : public rsih::NeighbourTester {
       if (slot) memcpy(outs.data(), d_outs, ob);
       gs.release();
       ph.stop();
+      static const bool cand_dbg = getenv("RSI_HOT_CAND_DBG") && atoi(getenv("RSI_HOT_CAND_DBG")) != 0;   // every test's plan and what the device found, on stderr
       for (size_t k = 0; k < jobs.size(); ++k) {
         const CandOut& O = outs[k];
+        if (cand_dbg)
+          fprintf(stderr, "[cand] [%d,%d] kind %d margin %d cap %d top %d chains %d/%d cut %d -> flags %d nref %d nbody %d nwin %d reach %d/%d ref q %.6f %.6f %.6f s1 %.6f s2 %.6f\n",
+                  jobs[k].start, jobs[k].end, jobs[k].kind, jobs[k].margin, jobs[k].capacity, jobs[k].top, jobs[k].nleft, jobs[k].nright, jobs[k].cut,
+                  O.flags, O.nref, O.nbody, O.nwin, O.left_reach, O.right_reach, O.ref_q[0], O.ref_q[1], O.ref_q[2], O.ref_s1, O.ref_s2);
         if (O.flags != 0) continue;
         rsih::TestStats& S = stats[first + k];
         const double nb = (double)O.nbody, nw = (double)O.nwin;
@@ -674,7 +679,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   // few chromosomes) waits for exactly this kernel: as many items as still ride in the kernel arguments (kItemsInline), down
   // to 32 pairs per thread -- a 60 Mb chromosome's 2 M pairs then spread over ~130 workgroups instead of ~35.
   int64_t pairs_per_item = 1 << 16;
-  if (!ctx->gate || ctx->gate->few_chromosomes.load()) {
+  if (!ctx->gate || ctx->gate->lonely()) {
     int64_t total = 0;
     for (const Region& r : runs) { const int64_t len = r.end - r.start + 1; total += len * (len + 1) / 2; }
     const int64_t room = std::max<int64_t>(8, (int64_t)kItemsInline - 2 * (int64_t)runs.size());   // every run's last item is a partial one

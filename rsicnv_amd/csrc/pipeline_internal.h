@@ -264,7 +264,7 @@ inline hipError_t copy_h2d(rsi_ctx* ctx, void* d_dst, const void* src, size_t by
 // still succeed; without this check the run would return RSI_OK on stale data.
 inline hipError_t ctx_sync(rsi_ctx* ctx) {
   if (ctx->poisoned) return hipErrorLaunchTimeOut;
-  hipError_t e = stream_wait(ctx->stream, ctx->sync_ev, ctx->gate != nullptr && !ctx->gate->few_chromosomes.load());
+  hipError_t e = stream_wait(ctx->stream, ctx->sync_ev, ctx->gate != nullptr && !ctx->gate->lonely());
   // A queue that outlived the wait's deadline is still running: its kernels write the workspaces and the mapped mailbox of
   // this context, so the context takes no further run (a next run would reset the mailbox and reuse the buffers under
   // them) -- every entry point refuses a poisoned context; rsi_hot_destroy is what is left to do with it.

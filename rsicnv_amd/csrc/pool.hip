@@ -68,6 +68,7 @@ struct rsi_pool {
     const int i = R.order[(size_t)k];
     R.out[i] = nullptr;
     const double t_a = now_ms();
+    struct InFlight { GpuGate& g; InFlight(GpuGate& g_) : g(g_) { g.in_flight.fetch_add(1); } ~InFlight() { g.in_flight.fetch_sub(1); } } in_flight(gate);
     // host inputs: the worker's own stream carries its chromosome's transfer (pinned memory: a plain DMA), so the transfers of
     // some chromosomes run beside the kernels of others -- H2D double-buffered against compute across the pool's workers
     R.rcs[(size_t)i] = R.host_inputs ? rsi_hot_run(ctx, &R.params, static_cast<const int32_t*>(R.depth[(size_t)i]), static_cast<const uint8_t*>(R.fasta[(size_t)i]), R.n[(size_t)i], &R.out[i])

@@ -106,6 +106,48 @@ def test_nogc_takes_the_byte_kernels_and_the_int32_ones_behind_the_switch(hot, h
     gu.check_hip_against_golden(hot, hotlib, "poisson_nb_m101")     # and a GC-adjusted chromosome behind it on the same context
 
 
+def _deep_case(hotlib, seed, bimodal):
+    from conftest import make_case
+    _, fasta, depth = make_case(hotlib, dict(n=2_000_003, seed=seed, model=1, n_events=8, gaps=1, max_len=40000, end_n=4000, gap_len=9000))
+    fill = np.random.default_rng(seed).integers(0, 10, size=depth.size, dtype=np.int32)
+    depth = np.where(depth > 0, depth * 10 + fill, 0).astype(np.int32)
+    if bimodal:   # the second half of the chromosome at three times the depth: no 512-value window holds half of a subsample
+        h = depth.size * 9 // 20
+        depth[h:] = np.where(depth[h:] > 0, depth[h:] * 3 + 1, 0)
+    return fasta, depth
+
+
+def _deep_against_oracle(hot, res, O):
+    assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    ch = O.f64("chrom")
+    assert res.stats["RDmedian"] == ch[0] and res.stats["RDsd"] == pytest.approx(ch[1], rel=1e-13) and res.stats["cap_median"] == ch[2]
+    nbs = O.f64("nb")
+    assert res.stats["nb_mad"] == nbs[1] and res.stats["nb_r"] == nbs[2]
+    for which in ("calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
+
+
+@pytest.mark.parametrize("bimodal", [False, True])
+def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimodal):
+    """300x, overdispersed (2 % of the bases outside the int32 K4's 512-value LDS window: global atomics), and the same with the
+    second half of the chromosome three times as deep (no window holds half of the values; cap at 2000; 1800 segments, 345 raw
+    calls, candidate tests on int32 values in the thousands).  Median, SD, MAD, every array and the calls against the oracle.
+    The bimodal case is where the REFERENCE leaves defined behaviour: a candidate whose first edge refinement left end < start
+    makes optimize_with_derivative index its vector out of range (rsi.cpp:917, 930) -- the compiled reference returns 346 raw
+    calls on it, from heap contents.  The oracle (and the library) search the entries that exist: 345."""
+    import oracle
+    from rsicnv_amd import api
+    fasta, depth = _deep_case(hotlib, 0x3000 + bimodal, bimodal)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert "a2-3.deep coverage" in dict(hot.phase_times())
+    _deep_against_oracle(hot, res, O)
+
+
 SWITCH_CASES = ["poisson_nb_m101", "gampois_nb_m101", "gampois_med_m51_cap4", "poisson_tail7"]
 
 
