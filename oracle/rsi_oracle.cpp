@@ -138,6 +138,7 @@ double pnorm(double x) { return 0.5 * (erf_cephes(x / 1.41421356237309504880) + 
 
 // ---------------------------------------------------------------------------------------------
 struct Oracle {
+  mutable int short_neighbourhoods = 0;   // tests the reference would have aborted in (isitcnv)
   Params P;
   int n = 0;                       // chromosome length
   std::vector<Region> noncode;     // padded N regions
@@ -479,6 +480,10 @@ struct Oracle {
   // ---- isitcnv, rsi.cpp:101-172 ----
   void isitcnv(const std::vector<int>& ref, const std::vector<int>& cnv, Cnv& c) const {
     int d = (int)cnv.size(), nr = (int)ref.size() - d;
+    if (nr <= 0) {   // a neighbourhood no longer than the candidate: the reference sizes its running-mean array RDref.size() - d
+                     // (rsi.cpp:107) and indexes [0]: its Array throws, the program aborts.  Counted; orc_run reports it (-3).
+      ++short_neighbourhoods; c.geno = 0; c.status = -9; return;
+    }
     std::vector<float> rm(nr > 0 ? nr : 0);
     double sum = 0;
     for (int i = 0; i < d; ++i) sum += ref[i];
@@ -832,6 +837,7 @@ static orc::Params conv(const orc_params* p) {
 int orc_run(void* h, const orc_params* p, const int32_t* depth, const uint8_t* fasta, int32_t n, int32_t keep_snapshots) {
   orc::Oracle& O = *(orc::Oracle*)h;
   double t0 = orc::now_s();
+  O.short_neighbourhoods = 0;
   O.load(conv(p), depth, fasta, n);
   double t1 = orc::now_s();
   O.gc_correct();
@@ -845,6 +851,7 @@ int orc_run(void* h, const orc_params* p, const int32_t* depth, const uint8_t* f
   O.detect();
   double t5 = orc::now_s();
   O.stage_s[0] = t1 - t0; O.stage_s[1] = t2 - t1; O.stage_s[2] = t3 - t2; O.stage_s[3] = t4 - t3; O.stage_s[4] = t5 - t4;
+  if (O.short_neighbourhoods) return -3;   // the reference aborts on this input (a candidate longer than its neighbourhood)
   return (int)O.calls.size();
 }
 

@@ -174,7 +174,12 @@ void judge(const CallerInput& in, const std::vector<int>& ref, const std::vector
   const double t0 = tick_ms();
   const int width = (int)body.size();
   const int nwin = (int)ref.size() - width;
-  std::vector<float> winmean(nwin > 0 ? (size_t)nwin : 0);
+  if (nwin <= 0 || width <= 0) {   // the reference aborts here (CallerInput::short_neighbourhoods)
+    if (in.short_neighbourhoods) ++*in.short_neighbourhoods;
+    c.geno = 0; c.status = -9;
+    return;
+  }
+  std::vector<float> winmean((size_t)nwin);
   // running mean of width `width` (rsi.cpp:113-124); its minimum, maximum, mean and second moment are
   // accumulated in the same index order as the reference's separate passes would
   double acc = 0;

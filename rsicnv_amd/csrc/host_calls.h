@@ -130,6 +130,10 @@ struct CallerInput {
   int64_t ncompact;                 // rsi::end with rsi::start = 1
   const std::vector<Region>* noncode;
   IntSpan binmedint;
+  // Tests whose neighbourhood is no longer than the candidate itself (the walks ran out of sequence around a candidate that
+  // spans most of what is left): the reference sizes its running-mean array ref - body (rsi.cpp:107) and indexes it -- its
+  // Array throws and the program aborts.  Counted here; the caller fails the chromosome with RSI_ERR_UNSUPPORTED.
+  int* short_neighbourhoods = nullptr;
 };
 
 // areblockscnv on one scan's segments (rsi.cpp:415-546); segs are updated in place.

@@ -1278,6 +1278,8 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     ph_nb.stop();
     gs_nb.release();
     rsih::CallerInput in;
+    int short_neighbourhoods = 0;
+    in.short_neighbourhoods = &short_neighbourhoods;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     HIPCHK(ctx->h_medint.ensure((size_t)nb * 4));
     HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));   // complete at the scan's first wait
@@ -1351,6 +1353,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     in.tester = host_tests ? nullptr : &tester;
     { Phase ph(ctx, "a16-19.calls"); rsih::call_from_segments(in, tested, pager, blocks, raw, kept); }
     if (tester.failed) return RSI_ERR_HIP;
+    if (short_neighbourhoods) return fail(ctx, RSI_ERR_UNSUPPORTED, "a candidate longer than the neighbourhood left around it (the reference aborts in isitcnv, rsi.cpp:107)");
     if (pager.failed()) return fail(ctx, RSI_ERR_INTERNAL, "no pinned host memory for the candidate stages' depth mirror");
     ctx->phases.push_back({"calls.device(wait)", tester.kernel_wait_ms});
     ctx->phases.push_back({"calls.device_ms", prof.device_ms});

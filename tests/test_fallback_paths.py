@@ -106,6 +106,92 @@ def test_nogc_takes_the_byte_kernels_and_the_int32_ones_behind_the_switch(hot, h
     gu.check_hip_against_golden(hot, hotlib, "poisson_nb_m101")     # and a GC-adjusted chromosome behind it on the same context
 
 
+def test_a_chromosome_without_spread_is_an_error_not_a_hang(hot, oracle_cls):
+    """A constant depth (every subsample's MAD is 0, r = median / MAD is infinite): the reference's NB transform yields NaN thresholds
+    and the program dies in partition_stat_tp (bad_array_new_length).  The library reports RSI_ERR_UNSUPPORTED for -NB and -NOGC;
+    under -MED the NB values are never scanned and the reference, the oracle and the library all return no call."""
+    import oracle
+    from rsicnv_amd import api
+    n = 400_000
+    rng = np.random.default_rng(1)
+    fasta = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    depth = np.full(n, 30, dtype=np.int32)
+    depth[100_000:104_000] = 15
+    for flags in (dict(), dict(gcadjust=0)):
+        with pytest.raises(api.RsiError) as e:
+            hot.run(api.make_params(**flags), depth, fasta)
+        assert "non-finite" in str(e.value)
+    res = hot.run(api.make_params(trans=1), depth, fasta)
+    O = oracle_cls()
+    O.run(oracle.make_params(trans=1), depth, fasta)
+    assert res.calls("calls") == [] == O.calls("calls")
+    assert res.stats["RDmedian"] == O.f64("chrom")[0] and res.stats["RDsd"] == pytest.approx(O.f64("chrom")[1], rel=1e-13)
+    gu_case = "poisson_nb_m101"          # and the context is as good as new
+    gu.check_hip_against_golden(hot, api.load_library(), gu_case)
+
+
+def _full_against_oracle(hot, res, O, pre="nb"):
+    assert np.array_equal(res.noncode, O.i32("noncode")), "noncode"
+    for name in ("rd_gc", "rd_concat", "binmedint"):
+        assert np.array_equal(hot.fetch(name), O.i32(name)), name
+    ch = O.f64("chrom")
+    assert res.stats["RDmedian"] == ch[0] and res.stats["RDsd"] == pytest.approx(ch[1], rel=1e-13) and res.stats["cap_median"] == ch[2]
+    for w in ("status1", "status1f", "status2"):
+        assert np.array_equal(hot.fetch(w), O.i32(f"{pre}_{w}")), w
+    for which in ("blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
+
+
+def many_gaps_case(hotlib, ngaps, seed=0x6A95):
+    """A chromosome cut by `ngaps` short N runs (assembly gaps every few kilobases): more removed regions than ride in a kernel's
+    arguments (48) or in K4j's LDS mirror (128), events that straddle gaps, candidates whose neighbourhood walks cross them."""
+    from conftest import make_case
+    plan, fasta, depth = make_case(hotlib, dict(n=3_000_017, seed=seed, model=1, n_events=10, gaps=0, max_len=40000, end_n=3000))
+    rng = np.random.default_rng(seed)
+    fasta, depth = fasta.copy(), depth.copy()
+    starts = np.sort(rng.integers(20_000, depth.size - 20_000, size=ngaps))
+    for s0 in starts:
+        ln = int(rng.integers(1, 400))
+        fasta[s0:s0 + ln] = ord("N")
+        depth[s0:s0 + ln] = 0
+    return fasta, depth
+
+
+@pytest.mark.parametrize("ngaps", [60, 200, 700])
+def test_many_removed_regions(hot, hotlib, oracle_cls, ngaps):
+    import oracle
+    from rsicnv_amd import api
+    fasta, depth = many_gaps_case(hotlib, ngaps)
+    O = oracle_cls()
+    O.run(oracle.make_params(), depth, fasta)
+    res = hot.run(api.make_params(), depth, fasta)
+    assert len(res.noncode) // 2 > min(ngaps, 128) // 2          # padded runs merge; still far more than fit the kernel arguments
+    _full_against_oracle(hot, res, O)
+    res2 = hot.run(api.make_params(), depth, fasta)              # again on the same context: a K4j queued behind K2j with a region list from K1b
+    _full_against_oracle(hot, res2, O)
+    assert len(res.calls("calls")) > 0
+
+
+def test_events_at_the_chromosome_ends(hot, hotlib, oracle_cls):
+    """A deletion that begins 3 kb into the chromosome and a duplication that ends 2 kb before its end, no N runs at the ends: the
+    neighbourhood walks run out of sequence on one side (rsi.cpp:231-236: the gap is closed at the front), the edge refinement is
+    too close to the ends to move anything (rsi.cpp:898-899)."""
+    import oracle
+    from conftest import make_case
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=900_011, seed=0xED6E, model=0, n_events=3, gaps=0, max_len=20000, end_n=0))
+    depth = depth.copy()
+    depth[3_000:21_000] //= 2
+    depth[-30_000:-2_000] = (depth[-30_000:-2_000] * 3) // 2
+    for flags in (dict(), dict(m=51, trans=1)):
+        O = oracle_cls()
+        O.run(oracle.make_params(**flags), depth, fasta)
+        res = hot.run(api.make_params(**flags), depth, fasta)
+        _full_against_oracle(hot, res, O, pre="med" if flags.get("trans") == 1 else "nb")
+        assert len(res.calls("calls_raw")) > 0
+
+
 def _deep_case(hotlib, seed, bimodal):
     from conftest import make_case
     _, fasta, depth = make_case(hotlib, dict(n=2_000_003, seed=seed, model=1, n_events=8, gaps=1, max_len=40000, end_n=4000, gap_len=9000))
@@ -117,8 +203,9 @@ def _deep_case(hotlib, seed, bimodal):
     return fasta, depth
 
 
-def _deep_against_oracle(hot, res, O):
-    assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
+def _deep_against_oracle(hot, res, O, gc=True):
+    if gc:
+        assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
     assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
     assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
     ch = O.f64("chrom")
@@ -130,8 +217,12 @@ def _deep_against_oracle(hot, res, O):
         assert ok, f"{which}: {why}"
 
 
+DEEP_FLAGS = {"default": dict(), "med_m51": dict(m=51, trans=1), "nogc": dict(gcadjust=0), "nocap": dict(cap=-1.0)}
+
+
+@pytest.mark.parametrize("flags", sorted(DEEP_FLAGS))
 @pytest.mark.parametrize("bimodal", [False, True])
-def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimodal):
+def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimodal, flags):
     """300x, overdispersed (2 % of the bases outside the int32 K4's 512-value LDS window: global atomics), and the same with the
     second half of the chromosome three times as deep (no window holds half of the values; cap at 2000; 1800 segments, 345 raw
     calls, candidate tests on int32 values in the thousands).  Median, SD, MAD, every array and the calls against the oracle.
@@ -140,12 +231,23 @@ def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimoda
     calls on it, from heap contents.  The oracle (and the library) search the entries that exist: 345."""
     import oracle
     from rsicnv_amd import api
+    fl = DEEP_FLAGS[flags]
     fasta, depth = _deep_case(hotlib, 0x3000 + bimodal, bimodal)
     O = oracle_cls()
-    O.run(oracle.make_params(), depth, fasta)
-    res = hot.run(api.make_params(), depth, fasta)
-    assert "a2-3.deep coverage" in dict(hot.phase_times())
-    _deep_against_oracle(hot, res, O)
+    rc = O.run(oracle.make_params(**fl), depth, fasta)
+    if rc == -3:   # (bimodal, -NOGC): a candidate of a megabase whose walks run out of sequence -- its neighbourhood is shorter than
+                   # itself, the reference sizes an array with the negative difference and aborts (SIGABRT from the compiled
+                   # reference on this input); the library reports it
+        with pytest.raises(api.RsiError) as e:
+            hot.run(api.make_params(**fl), depth, fasta)
+        assert "UNSUPPORTED" in str(e.value) and "neighbourhood" in str(e.value)
+        gu.check_hip_against_golden(hot, hotlib, "poisson_nogc")     # the context is fine afterwards
+        return
+    assert (bimodal, flags) != (True, "nogc") or rc == -3
+    res = hot.run(api.make_params(**fl), depth, fasta)
+    if fl.get("gcadjust", 1):
+        assert "a2-3.deep coverage" in dict(hot.phase_times())
+    _deep_against_oracle(hot, res, O, gc=bool(fl.get("gcadjust", 1)))
 
 
 SWITCH_CASES = ["poisson_nb_m101", "gampois_nb_m101", "gampois_med_m51_cap4", "poisson_tail7"]
