@@ -542,9 +542,23 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   int Lmax = LmaxBase;
   if (Lmax < cal_max) Lmax = cal_max;
+  out.tmedian1 = tmedian; out.tsigma1 = tsigma; out.tlamda1 = tlamda; out.Lmax = Lmax;   // the reference's Lmax, as its log prints it
+  // More lengths than bins: the reference's sweeps run L = 1, 2, ... and the PROGRAM exits at L = nb + 1 (runmean refuses a
+  // span beyond the array, wufunctions.cpp:589-596) -- unless the 20 % rule (rsi.cpp:1226, 1256) has ended the sweep before,
+  // which on a chromosome with so few bins per length it usually has.  So the scan runs up to nb lengths, and a sweep that
+  // gets there without having stopped is what the reference exits on.
+  const bool clipped = Lmax > nb;
+  if (clipped) Lmax = (int)nb;
   if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond 10400 (the reference's own ceiling without a larger computed length is 10000, at -m 1)");
-  if (Lmax > nb) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length (the reference exits in runmean)");
-  out.tmedian1 = tmedian; out.tsigma1 = tsigma; out.tlamda1 = tlamda; out.Lmax = Lmax;
+  auto sweeps_stopped = [&](const uint32_t* w) -> bool {   // both sweeps of a pass ended by the 20 % rule (w: the pass's work block)
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t* cnt = w + 16 + (size_t)k * scan_level_stride(Lmax);
+      uint64_t cum = 0;
+      for (uint32_t L = 0; L <= w[2 + k] && L <= (uint32_t)Lmax; ++L) cum += cnt[L];
+      if (!((double)(int)cum / (double)(int)nb > 0.2)) return false;
+    }
+    return true;
+  };
 
   int32_t* d_st1 = ctx->status1.as<int32_t>();
   int32_t* d_st1f = ctx->status1f.as<int32_t>();
@@ -567,6 +581,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
                       reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4, fs_slot, ctx->stream);
   }
   { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
+  if (clipped && !sweeps_stopped(wslot)) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length, and a sweep reached them all (the reference exits in runmean)");
   out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[0].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[1].assign(wslot + 16 + scan_level_stride(Lmax), wslot + 16 + scan_level_stride(Lmax) + Lmax + 1);
@@ -665,6 +680,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   HIPCHK(CTX_SYNC());
   std::vector<Region> runs;
   if ((rc = runs_from_export(ctx, rslot, ctx->runs.as<uint64_t>(), runs)) != RSI_OK) return rc;
+  if (clipped && !sweeps_stopped(wslot)) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length, and a sweep reached them all (the reference exits in runmean)");
   out.escapes += wslot[0]; out.inexact = wslot[1]; out.tiles_listed += wslot[8];
   out.level_log[2].assign(wslot + 16, wslot + 16 + Lmax + 1);
   out.level_log[3].assign(wslot + 16 + scan_level_stride(Lmax), wslot + 16 + scan_level_stride(Lmax) + Lmax + 1);

@@ -192,6 +192,38 @@ def test_events_at_the_chromosome_ends(hot, hotlib, oracle_cls):
         assert len(res.calls("calls_raw")) > 0
 
 
+def test_more_scan_lengths_than_bins(hot, oracle_cls):
+    """A chromosome whose second half is 40 times as deep, no cap: the NB fit asks for Lmax = 6763 lengths, the chromosome has 3960
+    bins.  The reference's sweeps stop at L = 387 (DEL) and L = 1 (DUP) by the 20 % rule (rsi.cpp:1226, 1256) and the run ends
+    with one call; the program would only exit -- in runmean, at L = nb + 1 -- if a sweep got that far.  The library scans
+    up to nb lengths and refuses only then (until round 4 it refused whenever Lmax > nb)."""
+    import oracle
+    from rsicnv_amd import api
+    rng = np.random.default_rng(7)
+    n = 400_000
+    fasta = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    depth = rng.poisson(30, size=n).astype(np.int32)
+    depth[n // 3:n // 3 + 8000] //= 2
+    depth[2 * n // 3:2 * n // 3 + 8000] = (depth[2 * n // 3:2 * n // 3 + 8000] * 3) // 2
+    depth[200_000:] *= 40
+    p = dict(cap=-1.0)
+    O = oracle_cls()
+    assert O.run(oracle.make_params(**p), depth, fasta) >= 1
+    res = hot.run(api.make_params(**p), depth, fasta)
+    sc = O.f64("scan_nb")
+    assert res.stats["Lmax"] == int(sc[7]) > res.stats["nbins"]
+    _full_against_oracle(hot, res, O)
+    # ... and when no sweep stops: a flat chromosome (no event marks a fifth of it) with as few bins -- the reference exits
+    depth2 = rng.poisson(30, size=200_000).astype(np.int32)
+    fasta2 = fasta[:200_000].copy()
+    depth2[::2] *= 60                       # a MAD large enough for a computed length beyond the 1980 bins
+    try:
+        r2 = hot.run(api.make_params(**p), depth2, fasta2)
+        assert r2.stats["Lmax"] <= r2.stats["nbins"]          # (the fit did not ask for more lengths than bins after all)
+    except api.RsiError as e:
+        assert "TOO_SMALL" in str(e) or "UNSUPPORTED" in str(e)
+
+
 def _deep_case(hotlib, seed, bimodal):
     from conftest import make_case
     _, fasta, depth = make_case(hotlib, dict(n=2_000_003, seed=seed, model=1, n_events=8, gaps=1, max_len=40000, end_n=4000, gap_len=9000))
