@@ -84,7 +84,7 @@ static bool same_calls(const std::vector<rsih::Candidate>& a, const std::vector<
   return true;
 }
 
-static void candidate_stage_case(uint64_t seed, int n, int model, const orc_params& P) {
+static void candidate_stage_case(uint64_t seed, int n, int model, const orc_params& P, int deep_bimodal = 0) {
   // a chromosome with N runs at the ends, one gap and a few events (layout as tests/conftest.py's plans)
   std::vector<rsi_synth_interval_c> nruns = {{0, 4000, 0, 0}, {n / 2, n / 2 + 6000, 0, 0}, {n - 4000, n, 0, 0}};
   std::vector<rsi_synth_interval_c> events;
@@ -97,6 +97,13 @@ static void candidate_stage_case(uint64_t seed, int n, int model, const orc_para
   spec.events = events.data(); spec.n_events = (int)events.size(); spec.nruns = nruns.data(); spec.n_nruns = (int)nruns.size();
   std::vector<uint8_t> fasta((size_t)n); std::vector<int32_t> depth((size_t)n);
   CHECK(rsi_synth_generate_host(&spec, fasta.data(), depth.data()) == 0, "generator");
+  if (deep_bimodal) {   // 300x with the second half three times as deep: ~1800 segments, hundreds of candidates, neighbour chains
+                        // cut at 48, a candidate whose first edge refinement leaves end < start (the reference indexes its
+                        // vector out of range there; oracle and library search the entries that exist -- this case under
+                        // AddressSanitizer is what keeps both honest), thinned neighbourhoods of a 170 kb candidate
+    for (int i = 0; i < n; ++i) if (depth[(size_t)i] > 0) depth[(size_t)i] = depth[(size_t)i] * 10 + (int)((seed + (uint64_t)i * 2654435761u) % 10);
+    for (int i = n * 9 / 20; i < n; ++i) if (depth[(size_t)i] > 0) depth[(size_t)i] = depth[(size_t)i] * 3 + 1;
+  }
   void* O = orc_create();
   orc_run(O, &P, depth.data(), fasta.data(), n, 0);
   const std::vector<int32_t> rdc = geti(O, "rd_concat"), medint = geti(O, "binmedint"), noncode = geti(O, "noncode");
@@ -125,6 +132,7 @@ static void candidate_stage_case(uint64_t seed, int n, int model, const orc_para
   same_calls(raw, getc(O, "calls_raw"), "calls_raw");
   same_calls(kept, getc(O, "calls"), "calls");
   CHECK(!raw.empty(), "the case should call something (seed %llu)", (unsigned long long)seed);
+  if (deep_bimodal) CHECK(raw.size() > 100, "the bimodal case should be crowded (%zu raw calls)", raw.size());
   orc_destroy(O);
 }
 
@@ -193,6 +201,7 @@ int main(int argc, char** argv) {
   candidate_stage_case(0x5A12, 350013, 1, Q);
   orc_params R = P; R.merge = 0; R.chklen = 1.5; R.maxchkbp = 2000;
   candidate_stage_case(0x5A13, 300000, 1, R);
+  candidate_stage_case(0x5A14, 2000003, 1, P, 1);
   if (argc > 1) bam_checks(argv[1]);
   if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
   printf("host harness ok\n");

@@ -16,3 +16,49 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_chromosomes_and_flags_agree_with_the_oracle(seed):
     import fuzz_probe
     assert fuzz_probe.run(8, seed, max_bins=60_000) == 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flags", [dict(), dict(m=51, trans=1), dict(gcadjust=0, cap=2.0), dict(m=201, trans=2, cap=-1.0)])
+def test_a_pool_of_random_chromosomes_equals_one_context(flags):
+    """Ten random chromosomes of very different lengths (40 kb ... 3 Mb; one of them deep, one with a pile-up, one without spread enough to
+    call anything) through a pool of eight workers from host memory, twice, against the same chromosomes one at a time on a
+    single context: the same statistics and lists, bit for bit (the single-context results are what the oracle tests pin)."""
+    import numpy as np
+    from conftest import make_case
+    from rsicnv_amd import api
+    lib = api.load_library()
+    rng = np.random.default_rng(0xF0 + len(flags))
+    cases = []
+    for k in range(10):
+        n = int(rng.choice([40_000, 90_000, 300_000, 800_000, 1_500_000, 3_000_000])) + int(rng.integers(0, 64))
+        mean = 300.0 if k == 3 else float(rng.choice([15, 30, 60]))
+        _, fasta, depth = make_case(lib, dict(n=n, seed=int(rng.integers(1, 1 << 30)), model=int(rng.integers(0, 2)), mean=mean, n_events=int(rng.integers(1, 10)),
+                                              gaps=int(rng.integers(0, 3)), max_len=20000, end_n=int(rng.choice([0, 3000])), gap_len=3000))
+        depth = depth.copy()
+        if k == 5:
+            depth[n // 2:n // 2 + 300] *= 50
+        cases.append((np.ascontiguousarray(fasta), np.ascontiguousarray(depth)))
+    params = api.make_params(**flags)
+    hot = api.RsiHot(0)
+    single = []
+    for fasta, depth in cases:
+        try:
+            single.append(hot.run(params, depth, fasta))
+        except api.RsiError as e:
+            single.append(e)
+    usable = [i for i, r in enumerate(single) if not isinstance(r, api.RsiError)]
+    assert len(usable) >= 6
+    chroms = [(cases[i][1].ctypes.data, cases[i][0].ctypes.data, cases[i][1].size) for i in usable]
+    pool = api.RsiPool(0, 8)
+    keys = ("RDmedian", "RDsd", "cap_median", "nb_mad", "nb_r", "tmedian1", "tlamda1", "tmedian2", "tlamda2", "Lmax", "n_compact", "nbins", "trim_escapes")
+    for _ in range(2):
+        batch = pool.run(params, chroms, host=True)
+        for i, got in zip(usable, batch):
+            want = single[i]
+            assert [got.stats[k] for k in keys] == [want.stats[k] for k in keys], i
+            for which in ("blocks", "calls_raw", "calls"):
+                assert got.calls(which) == want.calls(which), (i, which)
+            assert np.array_equal(got.noncode, want.noncode)
+    pool.close()
+    hot.close()
