@@ -41,10 +41,18 @@ def run(ncases, seed, max_bins=250_000):
         n = int(rng.choice([60_000, 150_000, 400_000, 900_000, 2_000_000])) + int(rng.integers(0, 40))
         model = int(rng.integers(0, 2))
         mean = float(rng.choice([8, 15, 30, 30, 60, 120, 300]))
-        plan_kw = dict(n=n, seed=int(rng.integers(1, 1 << 30)), model=model, mean=mean, n_events=int(rng.integers(1, 12)), gaps=int(rng.integers(0, 4)),
-                       max_len=int(rng.choice([5000, 20000, 60000])), end_n=int(rng.choice([0, 3000, 10000])), gap_len=int(rng.choice([200, 3000, 9000])))
+        crowded = rng.random() < 0.3
+        plan_kw = dict(n=n, seed=int(rng.integers(1, 1 << 30)), model=model, mean=mean, n_events=int(rng.integers(20, 60)) if crowded else int(rng.integers(1, 12)),
+                       gaps=int(rng.integers(0, 4)), min_len=600 if crowded else 3000, max_len=int(rng.choice([3000, 8000])) if crowded else int(rng.choice([5000, 20000, 60000])),
+                       end_n=int(rng.choice([0, 3000, 10000])), gap_len=int(rng.choice([200, 3000, 9000])))
         fl = dict(m=int(rng.choice([11, 51, 101, 101, 201, 439])), trans=int(rng.choice([0, 0, 1, 2])), cap=float(rng.choice([-1.0, 2.0, 4.0, 4.0])),
                   gcadjust=int(rng.choice([0, 1, 1, 1])), merge=int(rng.choice([0, 1, 1])))
+        if rng.random() < 0.5:   # the rarely touched knobs (rsi.cpp:34-98): score factor, MED threshold, neighbourhood size, minimum length,
+                                 # margin, thinning budget, p-value bar
+            fl.update(epsilon=float(rng.choice([0.5, 1.5, 3.0])), chklen=float(rng.choice([1.5, 2.5, 4.0])), minmlen=float(rng.choice([2.01, 3.01, 6.0])),
+                      buffer=float(rng.choice([0.0, 0.05, 0.2])), maxchkbp=int(rng.choice([2000, 20000, 100000])), p=float(rng.choice([0.01, 0.05, 0.2])))
+            if fl["trans"] == 1 and rng.random() < 0.5:
+                fl["threshold"] = float(rng.choice([0.3, 0.6]))
         if n // fl["m"] < 1200:
             fl["m"] = 11 if n < 100_000 else 51
         if n // fl["m"] > max_bins:      # the oracle's scan at -m 11 takes half a minute per 200 000 bins
@@ -89,10 +97,20 @@ def run(ncases, seed, max_bins=250_000):
             pre = "med" if fl["trans"] == 1 else "nb"
             diffs = []
             if not np.array_equal(res.noncode, og["noncode"]): diffs.append("noncode")
+            st_low = res.stats["RDmedian"] < 5
             for name, key in (("rd_concat", "rd_concat"), ("binmedint", "binmedint"), ("status1", pre + "_status1"), ("status1f", pre + "_status1f"), ("status2", pre + "_status2")):
-                if not np.array_equal(hot.fetch(name), og[key]): diffs.append(name)
+                try:
+                    a = hot.fetch(name)
+                except (KeyError, api.RsiError):
+                    a = np.zeros(0, dtype=np.int32)
+                if name != "rd_concat" and og[key].size == 0 and st_low: continue   # "Read depths too low" (rsi.cpp:1809-1813): the reference returns before it bins anything
+                if a.shape != og[key].shape or not np.array_equal(a, og[key]): diffs.append(f"{name} {a.shape} vs {og[key].shape}")
             if fl["gcadjust"] and not np.array_equal(hot.fetch("rd_gc"), og["rd_gc"]): diffs.append("rd_gc")
-            if not np.allclose(hot.fetch("binnb"), og["binnb"], rtol=1e-6, atol=0): diffs.append("binnb")
+            try:
+                nbv = hot.fetch("binnb")
+            except KeyError:      # a median depth below 5: the reference returns before any transform (rsi.cpp:1809-1813)
+                nbv = np.zeros(0, dtype=np.float32)
+            if nbv.shape != og["binnb"].shape or not np.allclose(nbv, og["binnb"], rtol=1e-6, atol=0): diffs.append(f"binnb {nbv.shape} vs {og['binnb'].shape}")
             st = res.stats
             if st["RDmedian"] != orc["chrom"][0] or abs(st["RDsd"] - orc["chrom"][1]) > 1e-12 * max(1, abs(orc["chrom"][1])): diffs.append(f"chrom {st['RDmedian']},{st['RDsd']} vs {orc['chrom'][:2]}")
             if st["Lmax"] != int(orc["scan"][7]): diffs.append(f"Lmax {st['Lmax']} vs {orc['scan'][7]}")
