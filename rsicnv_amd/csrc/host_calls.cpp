@@ -339,6 +339,14 @@ TestPlan plan_test(const CallerInput& in, int64_t N, const std::vector<Candidate
     while (nb < count - 1 && list[nb].status == -9) ++nb;
   }
   if (nb < count) *cut |= 2;
+  // bit 2: the left walk certainly fills its top + 1 slots unless every other base is extreme -- more than twice as many
+  // positions between the chromosome's start and the candidate, the listed neighbours taken off, as slots.  The device's
+  // right walk then gathers only what the left one leaves (kernels_cand.hip: k_cand_gather) and the result is checked there.
+  if (!(*cut & 1) && T.top >= 0) {
+    long long avail = (long long)me.start - T.margin - 2;
+    for (const auto& iv : T.left_chain) avail -= (long long)iv.second - iv.first + 1;
+    if (avail >= 2LL * (T.top + 1) + 64) *cut |= 4;
+  }
   T.cut = *cut;
   return T;
 }

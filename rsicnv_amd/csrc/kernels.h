@@ -357,7 +357,7 @@ struct CandJob {            // one isitcnvwrap test, prepared on the host from t
   int64_t lscratch_off;     // int64 scratch: capacity + 1 rounded up to a multiple of 4; offset even
 };
 struct CandOut {
-  int32_t flags;            // 1: empty neighbourhood, 2: body value range beyond the LDS histogram, 4: same for the window means, 8: cut chain used up
+  int32_t flags;            // 1: empty neighbourhood, 2: body value range beyond the LDS histogram, 4: same for the window means, 8: cut chain used up, 16: the left walk ran short where the host had vouched it would not (split form)
   int32_t nref, nbody, nwin, left_reach, right_reach, body_min, body_max;
   double body_q[3], body_s1, body_s2;   // lower quartile / median / upper quartile (partition_stat_tp), sum, sum of squares
   double ref_q[3], ref_s1, ref_s2;      // the same for the window means

@@ -687,10 +687,15 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_gather(const TD* __restri
       lcnt = gather_side(A, N, -1, J.start - J.margin, J.top + 1, b.left, J.top, chains + J.left_off, J.nleft, J.kind, too_high, too_low, W, &lreach, &lused, s_stage);
     if (threadIdx.x == 0) { M.lcnt = lcnt; M.lreach = lreach; M.lused = lused; }
   } else {
-    // the right walk does not know yet how many slots the left one leaves: it fills as many as it could ever get
+    // The right walk does not know yet how many slots the left one leaves.  Where the host vouches that the left walk fills
+    // all of its top + 1 slots (J.cut bit 2: more than twice as many positions to the left, known neighbours taken off, as
+    // slots -- it would take every other base to be extreme for that to fail, and k_cand_hist checks: flag 16 sends the test
+    // to the host path) the right walk takes what is left, about half the capacity; else as many as it could ever get.  The
+    // right walk is the launch's critical path: a trip of 16 384 positions at a time, twice as many trips as needed before.
     int room = J.capacity;
     const int lim = (int)ceil(J.right_cap);
     if (lim < room) room = lim;
+    if ((J.cut & 4) && J.top >= 0) room -= J.top + 1;
     if (room < 0) room = 0;
     int rreach = J.end, rused = 0;
     const int rcnt = gather_side(A, N, +1, J.end + J.margin, room, b.right, 0, chains + J.right_off, J.nright, J.kind, too_high, too_low, W, &rreach, &rused, s_stage);
@@ -838,9 +843,10 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_hist(const CandJob* __res
   CandOut O;
   O.flags = M.body_flags;
   if (((J.cut & 1) && M.lused >= J.nleft) || ((J.cut & 2) && M.rused >= J.nright)) O.flags |= 8;
+  if ((J.cut & 4) && J.top >= 0 && M.lcnt < J.top + 1) O.flags |= 16;   // the left walk ran short after all: the right one gathered too little
   O.nref = g.nref; O.nbody = g.nbody_eff; O.nwin = g.nwin; O.left_reach = M.lreach; O.right_reach = M.rreach;
   if (g.nwin <= 0 || g.width <= 0) {
-    O.flags = (O.flags & 8) | 1;
+    O.flags = (O.flags & 24) | 1;
     O.body_min = O.body_max = 0; O.body_s1 = O.body_s2 = O.ref_s1 = O.ref_s2 = 0;
     for (int k = 0; k < 3; ++k) { O.body_q[k] = 0; O.ref_q[k] = 0; }
     if (blockIdx.x == 0 && threadIdx.x == 0) outs[blockIdx.y] = O;
