@@ -166,6 +166,9 @@ __device__ inline bool last_block_done(unsigned int* counter) {
 // obvious alternative, serialise on the memory side and cost more than a whole streaming pass.
 constexpr int kFoldGroups = 32;   // upper bound on the number of groups
 inline int fold_per_group(int nblocks) { return (nblocks + kFoldGroups - 1) / kFoldGroups; }
+// fold_slabs_add has no second reading level (the groups' sums are atomic adds): more, smaller groups make its one level shorter
+constexpr int kFoldGroupsAdd = 64;
+inline int fold_per_group_add(int nblocks) { return (nblocks + kFoldGroupsAdd - 1) / kFoldGroupsAdd; }
 
 // Sixteen bytes from each of eight slabs with agent-scope coherence (the sc1 bit an agent-scope atomic load carries), all
 // eight in flight at once.  The slab bases are wave-uniform (scalar registers), the thread's offset is one VGPR.  An atomic
@@ -196,23 +199,34 @@ __device__ inline void fold_add(unsigned long long (&s)[2], u32x4 v) {
   s[0] += (unsigned long long)v.x | ((unsigned long long)v.y << 32);
   s[1] += (unsigned long long)v.z | ((unsigned long long)v.w << 32);
 }
-// dst[e] = sum over k < members of src[k * stride + e], e < width; width a multiple of 16 / sizeof(T), src 16-byte aligned
-template <typename T, int MODE /* 0: plain stores, 1: st_cg stores, 2: atomic adds of the non-zero sums */>
+// Sixteen coherent bytes through a buffer descriptor (`buffer_load_dwordx4 ... sc1`: the agent-scope load as above), issued by
+// the COMPILER: it keeps count of the loads in flight itself, so a loop over members can have sixteen and more outstanding per
+// thread where the inline-asm forms above wait after every eighth.  The descriptor's base is wave-uniform; `soff` must be too.
+__device__ inline __amdgpu_buffer_rsrc_t coherent_buffer(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uniform_address(base)), 0, 0x7fffffff, 0x00020000);
+}
+__device__ inline u32x4 ld_cg_buf_x4(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, __builtin_amdgcn_readfirstlane((int)soff), 16 /* sc1 */);
+}
+// dst[e] = sum over k < members of src[k * stride + e], e < width; width a multiple of 16 / sizeof(T), src 16-byte aligned,
+// members * stride * sizeof(T) < 2^31.  kFlight members' quads in flight per thread (sixteen in fold_slabs_add): the fold is a chain of memory round trips
+// (2 - 3 us each, the slabs were written by other XCDs), and with eight in flight K4j's last group spent sixteen of them here.
+template <typename T, int MODE /* 0: plain stores, 1: st_cg stores, 2: atomic adds of the non-zero sums */, int kFlight = 8>
 __device__ inline void fold_columns(const T* src, size_t stride, int members, int width, T* dst) {
   constexpr int kPer = 16 / (int)sizeof(T);
   const int last = __builtin_amdgcn_readfirstlane(members - 1);
+  const __amdgpu_buffer_rsrc_t rs = coherent_buffer(src);
+  const unsigned int sbytes = (unsigned int)(stride * sizeof(T));
   for (int q = threadIdx.x; q < width / kPer; q += blockDim.x) {
     T s[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) s[j] = 0;
-    for (int k0 = 0; k0 <= last; k0 += 8) {
-      unsigned long long b[8];
+    for (int k0 = 0; k0 <= last; k0 += kFlight) {
+      u32x4 v[kFlight];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[j] = uniform_address(src + (size_t)(k0 + j < last ? k0 + j : last) * stride);
-      u32x4 v[8];
-      ld_cg_x8(v, (unsigned int)q * 16u, b);
+      for (int j = 0; j < kFlight; ++j) v[j] = ld_cg_buf_x4(rs, (unsigned int)q * 16u, (unsigned int)(k0 + j < last ? k0 + j : last) * sbytes);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (k0 + j <= last) fold_add(s, v[j]);
+      for (int j = 0; j < kFlight; ++j) if (k0 + j <= last) fold_add(s, v[j]);
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -277,7 +291,7 @@ __device__ inline bool fold_slabs_add(const T* slabs, T* total, int width, int p
   }
   __syncthreads();
   if (!s_flag2__) return false;
-  fold_columns<T, 2>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, total);
+  fold_columns<T, 2, 16>(slabs + (size_t)g * per_group * width, (size_t)width, members, width, total);
   drain();
   __syncthreads();   // this group's atomics have completed
   if (threadIdx.x == 0) {

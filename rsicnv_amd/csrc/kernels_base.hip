@@ -6,6 +6,7 @@
 // Built with -ffp-contract=off: the only floating-point here is the GC rescale, which must round
 // exactly like the reference's x86-64 SSE2 build.
 #include <stdio.h>
+#include <algorithm>
 #include "kernels.h"
 #include "device_util.h"
 
@@ -1046,10 +1047,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   for (int e = threadIdx.x; e < 2 * kGcLevels; e += kJThreads) r_sum[e] = 0;   // r_sum and r_cnt
   if (threadIdx.x == 0) { s_hi = 0u; r_misc[0] = 0; r_misc[1] = 0; }
   __syncthreads();
-  const unsigned int* t_zero = tot + kJTotH + (kJOffZero - kJPacked);
-  const unsigned int* t_ecnt = tot + kJTotH + (kJOffEscCnt - kJPacked);
-  const unsigned int* t_flags = tot + kJTotH + (kJOffFlags - kJPacked);
-  const unsigned long long* t_esum = reinterpret_cast<const unsigned long long*>(tot + kJTotH + (kJOffEscSum - kJPacked));
+  static_assert(kJThreads >= kGcLevels, "thread g holds level g's counters");
   // ---- H into registers, once: row g (256 cells) is one 16-byte quad per lane, every wave takes rows wave, wave + 12, ...
   // (seventeen loads per lane, eight in flight).  Row sums (count, sum of depths per level) and the largest depth byte present
   // are wave reductions -- 64-bit LDS atomics from every quad were 20 of the tail's 55 us -- and the rows stay in registers for
@@ -1057,20 +1055,26 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   __shared__ unsigned int s_vmax, s_gmin, s_gmax;
   if (threadIdx.x == 0) { s_vmax = 0u; s_gmin = 0xffffffffu; s_gmax = 0u; }
   __syncthreads();
-  const unsigned long long tot_base = uniform_address(tot);
   constexpr int kRowsPerWave = (kGcLevels + kJWaves - 1) / kJWaves;   // 17
-  constexpr int kRowBatches = (kRowsPerWave + 7) / 8;                 // 3
-  u32x4 rowq[kRowBatches * 8];
+  u32x4 rowq[kRowsPerWave];
+  const __amdgpu_buffer_rsrc_t tot_rs = coherent_buffer(tot);
 #pragma unroll
-  for (int b = 0; b < kRowBatches; ++b) {
-    unsigned int off[8];
-    u32x4 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int g = wave + (b * 8 + j) * kJWaves; off[j] = (unsigned int)((g < kGcLevels ? g : 0) * 256 + 4 * lane) * 4u; }
-    ld_cg_x4_batch8(v, tot_base, off);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rowq[b * 8 + j] = v[j];
+  for (int k = 0; k < kRowsPerWave; ++k) {
+    const int g = wave + k * kJWaves;
+    rowq[k] = ld_cg_buf_x4(tot_rs, (unsigned int)(4 * lane) * 4u, (unsigned int)((g < kGcLevels ? g : 0) * 256) * 4u);
   }
+  // the per-level counters behind H and the flags ride in the same burst (they were three and one more round trips further down)
+  unsigned int pz = 0, pe = 0;
+  unsigned long long pes = 0;
+  u32x4 pflags = {0u, 0u, 0u, 0u};
+  if (threadIdx.x < kGcLevels) {
+    const unsigned int g4 = (unsigned int)threadIdx.x * 4u;
+    pz = __builtin_amdgcn_raw_buffer_load_b32(tot_rs, (int)((unsigned int)(kJTotH + (kJOffZero - kJPacked)) * 4u + g4), 0, 16);
+    pe = __builtin_amdgcn_raw_buffer_load_b32(tot_rs, (int)((unsigned int)(kJTotH + (kJOffEscCnt - kJPacked)) * 4u + g4), 0, 16);
+    const auto e2 = __builtin_amdgcn_raw_buffer_load_b64(tot_rs, (int)((unsigned int)(kJTotH + (kJOffEscSum - kJPacked)) * 4u + 2u * g4), 0, 16);
+    pes = (unsigned long long)e2[0] | ((unsigned long long)e2[1] << 32);
+  }
+  if (threadIdx.x == 0) pflags = ld_cg_buf_x4(tot_rs, (unsigned int)(kJTotH + (kJOffFlags - kJPacked)) * 4u, 0u);
   {
     unsigned int wave_top = 0;
 #pragma unroll
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   }
   __syncthreads();
   for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
-    const unsigned long long z = ld_cg(t_zero + g), ec = ld_cg(t_ecnt + g), es = ld_cg(t_esum + g);
+    const unsigned long long z = pz, ec = pe, es = pes;   // g == threadIdx.x: kJThreads >= kGcLevels
     const unsigned long long vs = r_sum[g], cs = r_cnt[g];
     r_sum[g] = vs + es;
     r_cnt[g] = cs + z + ec;
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   // histogram gets them from gc_tail_fixup, as raw depths) ----
   __shared__ unsigned int s_esc_total, s_list_over, s_bad_flags;
   if (threadIdx.x == 0) {
-    const u32x4 f4 = ld_cg_x4(t_flags);   // negative depth seen | escapes | a workgroup's counters wrapped | a list ran over: ONE round trip
+    const u32x4 f4 = pflags;   // negative depth seen | escapes | a workgroup's counters wrapped | a list ran over
     unsigned int fl_neg = f4.x;
     unsigned long long esc = f4.y;
     if ((n & 3) != 0) {
@@ -1181,11 +1185,20 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     const double ratio = rdmean / tg;
     bool bad = !(ratio < kFixMaxRatio);
     const unsigned int R = bad ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5);
+    // The reference's (int)(v * rdmean / tg + 0.5) without a division per cell: v * rdmean times the row's reciprocal is within a few
+    // ulp of the rounded quotient (< 1e-10 here: the quotient is below 2^17), so wherever that sum lies further than 1e-6 from an
+    // integer both truncate alike; a cell that does not (one in a million) takes the division.  (The division was a third of the
+    // tail: 68 of them per lane, 35 double-precision instructions each.)
+    const double inv_tg = 1.0 / tg;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int v = 4 * lane + j;
       if (v >= kByteEscape) continue;
-      const int r = (int)((double)v * rdmean / tg + 0.5);   // gccontent.cpp:89, truncation
+      const double t1 = (double)v * rdmean;
+      const double sa = t1 * inv_tg + 0.5;
+      const double fr = __builtin_amdgcn_fract(sa);
+      int r = (int)sa;
+      if (fr < 1e-6 || fr > 1.0 - 1e-6) r = (int)(t1 / tg + 0.5);   // gccontent.cpp:89, truncation
       const int rs = r > kByteSat ? kByteSat : r;
       unsigned int f = ((unsigned int)v * R + (1u << (kFixShift - 1))) >> kFixShift;
       f = f > (unsigned int)kByteSat ? (unsigned int)kByteSat : f;
@@ -1201,7 +1214,7 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     rtab[g] = (wide ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5)) | ((r_bad[g] || wide || r_cnt[g] == 0) ? 0x80000000u : 0u);
   }
   {
-    for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) { const unsigned int z = ld_cg(t_zero + g); if (z) atomicAdd(&r_hist[0], z); }   // (int)(0 * ratio + 0.5) = 0
+    if (threadIdx.x < kGcLevels && pz) atomicAdd(&r_hist[0], pz);   // (int)(0 * ratio + 0.5) = 0
     // the escapes the workgroups listed by position: the reference's expression on the int32 depth, window by the clamped rule
     if (s_esc_total != 0u && !esc_pending) {
       const int nlists = (int)gridDim.x;
@@ -2460,7 +2473,9 @@ void launch_fill(const FillList& fill, hipStream_t stream) {
 }
 void launch_n_transitions(const uint64_t* nbits, int64_t nwords, uint64_t* list, uint32_t* count, uint32_t cap, int64_t n, int dx,
                           PhaseParams* pp, int64_t* cbreak, int64_t* cum, unsigned int* counter, hipStream_t stream) {
-  RSI_LAUNCH(k_n_transitions, dim3(grid_for(nwords, kThreads)), dim3(kThreads), 0, stream, nbits, nwords, list,
+  // 256 workgroups: the launch ends with one same-address arrival atomic per workgroup (12 ns each: 2048 of them were 25 us of
+  // a kernel that reads 16 MB)
+  RSI_LAUNCH(k_n_transitions, dim3(std::min(grid_for(nwords, kThreads), 256)), dim3(kThreads), 0, stream, nbits, nwords, list,
                      count, cap, n, dx, pp, cbreak, cum, counter);
 }
 static int gc_hist_grid(int64_t n) {
@@ -2603,7 +2618,7 @@ void launch_cap_compact_bin8(const uint8_t* depth8, const int32_t* depth, const 
   const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * kResClasses * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
-  const int pg = fold_per_group(grid);
+  const int pg = fold_per_group_add(grid);
   const int ept = (m + 3) / 4;
 #define RSI_K48(MC, EP, SW) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin8<MC, EP, SW>));                                                  \
     RSI_LAUNCH((k_cap_compact_bin8<MC, EP, SW>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
@@ -2627,7 +2642,7 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
   const size_t lds = (size_t)maxc * kThreads * 16 + (size_t)vr * (vr <= 128 ? kK4jCols : kResClasses) * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   unsigned int* gs = static_cast<unsigned int*>(gsum);
-  const int pg = fold_per_group(grid);
+  const int pg = fold_per_group_add(grid);
 #define RSI_K48J(MC, EP, SW, FX) do { RSI_ALLOW_FULL_LDS((k_rescale_compact_bin8<MC, EP, SW, FX>));                                      \
     RSI_LAUNCH((k_rescale_compact_bin8<MC, EP, SW, FX>), dim3(grid), dim3(kThreads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, \
                cbreak, cum, nreg, ncompact, capval, m, TB, vr, rdc, binmed, binsum, res_hist, sl, gs, pg, counters,            \

@@ -97,7 +97,7 @@ struct ChainOut { GridMedian g[2]; uint32_t rawmin_inv; uint32_t pad[15]; };   /
 GridChain grid_chain(rsi_ctx* ctx) {
   uint8_t* small = ctx->small.as<uint8_t>();
   return GridChain{reinterpret_cast<MinMaxF*>(small + kOffMinMax), ctx->hist_f.as<uint32_t>(), kGridCap,
-                   reinterpret_cast<unsigned int*>(small + kOffDone) + 3 * kDoneStride};
+                   reinterpret_cast<unsigned int*>(small + kOffDone) + kDoneBinSlot};
 }
 // what the scan pass `pass` needs cleared: the first-L arrays, its work block, the run-boundary counter
 void scan_fill_list(rsi_ctx* ctx, int pass, int64_t nb, FillList& fl) {
@@ -328,10 +328,12 @@ class DeviceTester : public rsih::NeighbourTester {
             !ok(ctx->cand_i64.ensure(lwords * 8)))
           return false;
         if (split) {   // per-job records and folded histograms of the split form: zero when (re)allocated, left zero by every launch
-          const void* m0 = ctx->cand_mid.p; const void* h0 = ctx->cand_hist.p;
+          // (re)allocated = the capacity changed: the allocator may hand the freed address out again, with whatever lies behind
+          // the old extent -- comparing pointers missed exactly that, and a longer job list then started from stale counters
+          const size_t m0 = ctx->cand_mid.cap, h0 = ctx->cand_hist.cap;
           if (!ok(ctx->cand_mid.ensure(jobs.size() * sizeof(CandMid))) || !ok(ctx->cand_hist.ensure(jobs.size() * (size_t)kCandHistBins * 4))) return false;
-          if (ctx->cand_mid.p != m0 && !ok(hipMemsetAsync(ctx->cand_mid.p, 0, ctx->cand_mid.cap, ctx->stream))) return false;
-          if (ctx->cand_hist.p != h0 && !ok(hipMemsetAsync(ctx->cand_hist.p, 0, ctx->cand_hist.cap, ctx->stream))) return false;
+          if (ctx->cand_mid.cap != m0 && !ok(hipMemsetAsync(ctx->cand_mid.p, 0, ctx->cand_mid.cap, ctx->stream))) return false;
+          if (ctx->cand_hist.cap != h0 && !ok(hipMemsetAsync(ctx->cand_hist.p, 0, ctx->cand_hist.cap, ctx->stream))) return false;
         }
       }
       GateShared gs(ctx);
@@ -465,7 +467,7 @@ int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint,
   uint32_t* work = reinterpret_cast<uint32_t*>(small + kOffScanPass + (size_t)pass * kScanPassBytes);
   uint32_t* d_first_del = ctx->first_del.as<uint32_t>();
   uint32_t* d_first_dup = d_first_del + ((nb + 3) & ~int64_t(3));
-  unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone) + 3 * kDoneStride;
+  unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone) + kDoneBinSlot;
   uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
   const size_t work_bytes = 64 + ((size_t)scan_level_stride(Lmax) + (size_t)Lmax + 1) * 4;
   if (scan_tile_workspace_bytes(Lmax)) HIPCHK(ctx->scan_ws.ensure(scan_tile_workspace_bytes(Lmax)));   // scans too long for an LDS tile
@@ -578,7 +580,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     GateShared gs(ctx);
     Timer t(ctx, "level_sums");
     launch_level_sums(d_T, d_st1, nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(),
-                      reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4, fs_slot, ctx->stream);
+                      reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + kDoneBinSlot + 4, fs_slot, ctx->stream);
   }
   { Phase phc(ctx, "fs.wait"); HIPCHK(CTX_SYNC()); }
   if (clipped && !sweeps_stopped(wslot)) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer bins than the scan length, and a sweep reached them all (the reference exits in runmean)");
@@ -1592,7 +1594,7 @@ int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status
   HIPCHK(ctx->fs_out.ensure((size_t)(2 * kMaxL + 1) * 8 + 64));
   HIPCHK(hipMemcpyAsync(ctx->tnb.p, T, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->status1.p, status, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-  unsigned int* counter = reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + 3 * kDoneStride + 4;
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ctx->small.as<uint8_t>() + kOffDone) + kDoneBinSlot + 4;
   HIPCHK(hipMemsetAsync(ctx->fs_ws.p, 0, level_sums_head_bytes(kMaxL), ctx->stream));
   HIPCHK(hipMemsetAsync(counter, 0, 4, ctx->stream));
   const int nlev = 2 * Lmax + 1;

@@ -48,6 +48,10 @@ inline void set_global_error(const std::string& m) { std::lock_guard<std::mutex>
 inline thread_local double tl_grow = 1.0;
 inline thread_local double tl_grow_ms = 0.0;   // time this thread spent re-allocating during the current run
 
+// RSI_HOT_POISON=1 (debugging): every new device and pinned allocation is filled with 0xA5 instead of whatever the driver
+// hands out (zero pages in a fresh process, another context's leftovers in a long one)
+inline bool poison_allocations() { static const bool on = getenv("RSI_HOT_POISON") && atoi(getenv("RSI_HOT_POISON")) != 0; return on; }
+
 struct DevBuf {   // grow-only device allocation
   void* p = nullptr;
   size_t cap = 0;
@@ -61,6 +65,10 @@ struct DevBuf {   // grow-only device allocation
     const size_t want = (regrow ? 2 * scaled : scaled + scaled / 8) + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    if (e == hipSuccess && poison_allocations()) {   // RSI_HOT_POISON=1: a read of memory nobody wrote shows up at once
+      e = hipMemset(p, 0xA5, want);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // (the fill runs on the null stream: done before the context's own stream uses the buffer)
+    }
     tl_grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return e;
   }
@@ -81,6 +89,7 @@ struct PinBuf {   // grow-only pinned host allocation: destination of the large 
     const size_t want = scaled + scaled / 8 + 256;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
+    if (e == hipSuccess && poison_allocations()) memset(p, 0xA5, want);
     return e;
   }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -237,6 +246,7 @@ inline void* mb_alloc(rsi_ctx* ctx, size_t bytes) {
     if (hipHostGetDevicePointer(&dev_view, ctx->mailbox, 0) != hipSuccess || dev_view != (void*)ctx->mailbox) {   // unified addressing: same pointer
       (void)hipHostFree(ctx->mailbox); ctx->mailbox = nullptr; return nullptr;
     }
+    if (poison_allocations()) memset(ctx->mailbox, 0xA5, kMailboxBytes);
     ctx->mb_cap = kMailboxBytes;
   }
   const size_t need = (bytes + 63) & ~size_t(63);
@@ -306,6 +316,8 @@ constexpr size_t kOffRawMin = 5120;                               // uint32
 constexpr size_t kOffValMedian = 5184;                            // ValueMedian (24 bytes)
 constexpr size_t kOffDone = 5376;                                 // arrival counters of the in-kernel folds: kDoneStride uint32 per kernel
 constexpr size_t kDoneStride = 48;                                // >= kFoldGroups + 1
+constexpr size_t kDoneBinSlot = 4 * kDoneStride;                     // the bin-level kernels' counters: K4's slot (2) is two strides wide (kFoldGroupsAdd + 1 counters)
+static_assert(kOffDone + (kDoneBinSlot + 16) * 4 <= 6400 && kDoneStride >= 32 + 1 && 2 * kDoneStride >= 64 + 1, "arrival counters inside the header (device_util.h: kFoldGroups, kFoldGroupsAdd)");
 constexpr size_t kHeaderBytes = 6400;                             // everything above: cleared by the first kernel of a run (K1), handed to the host as one block
 constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:

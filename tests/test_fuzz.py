@@ -62,3 +62,18 @@ def test_a_pool_of_random_chromosomes_equals_one_context(flags):
             assert np.array_equal(got.noncode, want.noncode)
     pool.close()
     hot.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flags_index", [1, 2])
+def test_results_do_not_depend_on_what_fresh_allocations_hold(flags_index):
+    """RSI_HOT_POISON=1 fills every device and pinned allocation with 0xA5 (instead of the zero pages a fresh process gets, or another
+    context's leftovers in a long one).  Ten chromosomes of different sizes through ONE context, so that its buffers grow on the
+    way, each compared with the oracle (tools/uninit_probe.py, a child process: the switch is read once per process).  Round 4
+    found the split candidate tests starting from stale counters this way: a buffer that had grown at the same address was taken
+    for one that had not been reallocated."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSI_HOT_POISON="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "uninit_probe.py"), str(flags_index), "1"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "ALL SAME" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
