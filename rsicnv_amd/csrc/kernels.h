@@ -167,6 +167,14 @@ void launch_cap_compact_bin(const int32_t* src, int64_t n, const int64_t* cbreak
                             const void* exp_src, void* exp_dst, size_t exp_bytes, int vbase /* hist_window_base(cap median), or 0 */,
                             hipStream_t stream);
 
+// K4w: the same for caps of 254 .. 32766 (deep coverage): int32 in, 16-bit tile and 16-bit window counters in LDS, int32 out.
+// res_hist must be zero before the launch (the window's sums and the stray values are added to it); vbase as for K4.
+int cap_compact16_applies(int m, int32_t capval, int64_t ncompact);
+size_t cap_compact16_slab_bytes(int m, int64_t ncompact);
+void launch_cap_compact_bin16(const int32_t* src, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact,
+                              int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs,
+                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, int vbase, hipStream_t stream);
+
 // K4 fed from K3''s byte copy of the rescaled depth (rescaled8): the rescaled int32 array is never needed.  Applies when
 // cap_compact8_applies(): 1 <= capval < kByteSat (every capped value fits a byte, res_hist is overwritten) and m <= 104.
 // depth / gcbits / table (K2's [kGcLevels] level means + the mean of the positive depths): for the tiles at the chromosome's

@@ -1696,6 +1696,7 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
   const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
   const int parts = kThreads / TB;          // threads cooperating on one bin
   const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
+  const bool sw16 = capval >= 0 && capval < 32767 && (int64_t)m * capval < (int64_t)1 << 31;   // every value of the tile fits a 16-bit field with a spare bit
 
   // tile geometry: k = regions cut out at or before P0; a tile is `plain` when no region cuts it
   int k = 0;
@@ -1797,7 +1798,52 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
     const int32_t* x = s_val + b_local * m;
     int lo = 0x7fffffff, hi = (int)0x80000000;
     long long ssum = 0;
-    if (EPT > 0) {
+    if (EPT > 0 && sw16) {
+      // Values below 2^15 (a cap is in force and lies below): two to a register as 16-bit fields, bit 15 of each as the guard --
+      // #{x > t} of two values is one subtraction and one popcount, as in the byte kernels' median phase; slots past the bin
+      // hold 0xffff, above every t.  The median lies next to the bin's mean: 64 values around it bracket it on all but a
+      // handful of bins (the two counts that prove it, then six bisection steps); a wave with a bin outside its bracket
+      // bisects [0, cap].  32-bit sums: m * cap stays below 2^31.  (The int32 form below cost 40 of this kernel's 80 vector
+      // instructions per base at 300x: up to ten data-dependent steps of 26 compares over min .. max of the bin.)
+      constexpr int kPairs = (EPT + 1) / 2;
+      uint32_t pk[EPT > 0 ? kPairs : 1];
+      uint32_t s32 = 0;
+#pragma unroll
+      for (int i = 0; i < kPairs; ++i) {
+        const int j0 = part + parts * (2 * i), j1 = part + parts * (2 * i + 1);
+        const bool in0 = active && j0 < m, in1 = 2 * i + 1 < EPT && active && j1 < m;
+        const uint32_t a = in0 ? (uint32_t)x[j0] : 0xffffu, c = in1 ? (uint32_t)x[j1] : 0xffffu;
+        s32 += (in0 ? a : 0u) + (in1 ? c : 0u);
+        pk[i] = a | (c << 16) | 0x80008000u;
+      }
+      s32 = (uint32_t)parts_sum((int)s32, parts);
+      auto count_le = [&](int t) {   // #{x <= t} of the bin, t = -1 .. 32766
+        const uint32_t sub = (uint32_t)(t + 1) * 0x00010001u;
+        int gt = 0;
+#pragma unroll
+        for (int i = 0; i < kPairs; ++i) gt += __popc((pk[i] - sub) & 0x80008000u);
+        return 2 * kPairs * parts - parts_sum(gt, parts);
+      };
+      int blo = 0, bhi = capval, steps = 15;
+      {
+        const int est = (int)((float)s32 / (float)m);
+        int lo0 = est - 31;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        int hi0 = lo0 + 63;
+        hi0 = hi0 > capval ? capval : hi0;
+        lo0 = lo0 > hi0 ? hi0 : lo0;
+        const bool below = count_le(lo0 - 1) < kth;
+        const bool above = hi0 >= capval || count_le(hi0) >= kth;
+        if (__all((below && above) || !active)) { blo = lo0; bhi = hi0; steps = 6; }
+      }
+#pragma unroll 1
+      for (int it = 0; it < steps; ++it) {
+        const int mid = (blo + bhi) >> 1;
+        const int le = count_le(mid);
+        if (blo < bhi) { if (le >= kth) bhi = mid; else blo = mid + 1; }
+      }
+      lo = blo; ssum = (long long)s32;
+    } else if (EPT > 0) {
       // the thread's share of the bin in registers; slots past the bin hold INT_MAX (never <= mid)
       int r[EPT > 0 ? EPT : 1];
 #pragma unroll
@@ -2117,6 +2163,194 @@ __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(
   for (int e = threadIdx.x; e < vr * kResClasses; e += kThreads) st_cg(&slab[e], s_hist[e]);
   // res_hist is zero when the launch begins (K1's FillList): the groups' sums go straight into it
   if (!fold_slabs_add(hist_slabs, res_hist, vr * kResClasses, per_group, counters)) return;
+  export_words(exp_dst, exp_src, exp_bytes);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4w  cap_compact_bin16: K4 for caps of 254 .. 32766 (deep coverage, or a generous cap) in the shape of the byte kernels.
+// The source is the int32 array K4 would read (the GC-rescaled depth, or the raw depth under -NOGC); the tile lives in LDS as
+// 16-bit values, the median phase works on them two to a register (bit 15 of each field as the guard), the [value][MAD residue
+// class] histogram is a window of kK4Window values as 16-bit counters (32 KB; three workgroups per CU with the 16 KB tile) that
+// follows the depth (hist_window_base); values outside the window go to res_hist as global atomics, inline.  Output: the
+// capped, compacted depth as int32 (what every later stage of this envelope reads), bin medians and sums, res_hist.
+// The int32 kernel spent 640 us per 60 Mb at 300x on the same work (quads with a per-quad branch and an out-of-line slow
+// path that nearly every wave entered, two workgroups per CU, ten-step bisections over min .. max of each bin).
+constexpr int kW16 = 14;   // dwords (pairs of values) per thread in the median phase: 28 values x `parts` threads >= m + 1
+template <int MAXC>
+__global__ __launch_bounds__(kThreads, 3) void k_cap_compact_bin16(
+    const int32_t* __restrict__ src, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum, int nreg, int64_t ncompact,
+    int32_t capval, int m, int TB, int vb /* first value of the LDS window */, int32_t* __restrict__ rdc, int32_t* __restrict__ binmed,
+    int64_t* __restrict__ binsum, uint32_t* __restrict__ res_hist /* zero before the launch */, unsigned int* __restrict__ hist_slabs,
+    int per_group, unsigned int* __restrict__ counters, const void* exp_src, void* exp_dst, unsigned int exp_bytes, K4Regions inl) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint16_t* s_val = reinterpret_cast<uint16_t*>(smem);                                             // MAXC * 256 chunks of 16 values
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 32);     // [kK4Window][32] 16-bit counters
+  __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
+  constexpr int vr = kK4Window;
+  for (int e = threadIdx.x; e < vr * kResClasses / 2; e += kThreads) s_hist[e] = 0;
+  if (nreg <= kRegInline) {
+    for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
+    for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
+  } else {
+    for (int e = threadIdx.x; e < kRegLds && e < nreg; e += kThreads) s_break[e] = cbreak[e];
+    for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kThreads) s_cum[e] = cum[e];
+  }
+  __syncthreads();
+  const RegionTable R{cbreak, cum, nreg, s_break, s_cum};
+  const int64_t lim31 = (ncompact / 31) * 31;
+  const int64_t nb = ncompact / m;
+  const int tile_elems = TB * m;            // a multiple of 16
+  const int nchunks = tile_elems / 16;
+  const int64_t ntiles = (ncompact + tile_elems - 1) / tile_elems;
+  const int parts = kThreads / TB;
+  const int kth = (m + 1) / 2;              // rank of the median, m odd (rsi.cpp:2061)
+
+  // one value into the histogram: the LDS window's 16-bit counter, or res_hist itself (every value is in 0 .. cap < 2^15)
+  auto count_value = [&](int x, int cls) {
+    const unsigned int w = (unsigned int)(x - vb);
+    if (w < (unsigned int)vr) { const unsigned int idx = w * kResClasses + (unsigned int)cls; atomicAdd(&s_hist[idx >> 1], 1u << ((idx & 1u) << 4)); }
+    else atomicAdd(&res_hist[(size_t)(x < 0 ? 0 : x) * kResClasses + cls], 1u);
+  };
+  int k = 0;
+  auto geometry = [&](int64_t tile, int64_t& P0, int64_t& P1, bool& fast, int64_t& soff) {
+    P0 = tile * tile_elems;
+    P1 = (P0 + tile_elems < ncompact) ? P0 + tile_elems : ncompact;
+    while (k < nreg && R.brk(k) <= P0) ++k;   // tiles are visited in increasing order
+    const bool plain = (k >= nreg) || (R.brk(k) >= P1);
+    soff = P0 + R.shift(k);
+    fast = plain && P1 - P0 == tile_elems && P1 <= lim31;   // a whole tile, contiguous in the source, before the last partial stride of the 31 classes
+  };
+  int4 regs[MAXC][4];
+  auto request = [&](int64_t soff) {   // branch-free: chunks beyond the tile re-read chunk 0 (ignored later)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int kc = c * kThreads + (int)threadIdx.x;
+      const int32_t* sp = src + soff + 16 * (kc < nchunks ? kc : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const Quad4 v = *reinterpret_cast<const Quad4*>(sp + 4 * q); regs[c][q] = make_int4(v.x, v.y, v.z, v.w); }
+    }
+  };
+
+  int64_t P0, P1, soff; bool fast;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) { geometry(tile, P0, P1, fast, soff); if (fast) request(soff); }
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();   // s_val is free (and s_hist zeroed on the first trip)
+    if (fast) {
+      const uint32_t p0mod = (uint32_t)(P0 % 31);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int kc = c * kThreads + (int)threadIdx.x;
+        if (kc >= nchunks) continue;
+        int v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int4 d = regs[c][q];
+          v[4 * q] = d.x > capval ? capval : d.x; v[4 * q + 1] = d.y > capval ? capval : d.y;
+          v[4 * q + 2] = d.z > capval ? capval : d.z; v[4 * q + 3] = d.w > capval ? capval : d.w;
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = ((uint32_t)v[2 * i] & 0xffffu) | ((uint32_t)v[2 * i + 1] << 16);
+        *reinterpret_cast<uint4*>(s_val + 16 * kc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(s_val + 16 * kc + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        int32_t* out = rdc + P0 + 16 * (int64_t)kc;   // 64-byte aligned: P0 is a multiple of 16
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<int4*>(out + 4 * q) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        // sixteen atomics into [value][MAD residue class]: the class of element j is cls0 + j, minus 31 from the lane's wrap point on
+        const int cls0 = (int)((p0mod + 16u * (uint32_t)kc) % 31u);
+        const int jw = 31 - cls0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) count_value(v[j], cls0 + j - (j >= jw ? 31 : 0));
+      }
+    } else {
+      // ---- per-element path: contiguous source segments between removed regions; the chromosome's last, partial tile ----
+      int kk = k;
+      int64_t seg = P0;
+      while (seg < P1) {
+        const int64_t nxt = (kk < nreg && R.brk(kk) < P1) ? R.brk(kk) : P1;
+        const int64_t len = nxt - seg;
+        if (len > 0) {
+          const int64_t so = seg + R.shift(kk);
+          const int dst = (int)(seg - P0);
+          for (int64_t e = threadIdx.x; e < len; e += kThreads) {
+            int x = src[so + e];
+            if (x > capval) x = capval;
+            s_val[dst + e] = (uint16_t)x;
+            rdc[seg + e] = x;
+            const int64_t p = seg + e;
+            count_value(x, p < lim31 ? (int)((uint32_t)p % 31u) : 31);
+          }
+        }
+        seg = nxt;
+        if (kk < nreg && R.brk(kk) == nxt) ++kk;
+      }
+    }
+    __syncthreads();
+    // ---- request the next tile now: its loads fly during the median phase ----
+    const int64_t cur_tile = tile;
+    if (tile + gridDim.x < ntiles) { geometry(tile + gridDim.x, P0, P1, fast, soff); if (fast) request(soff); }
+    // ---- per-bin exact median (order statistic kth) and sum: `parts` threads per bin, the bin's dwords round robin ----
+    const int b_local = threadIdx.x / parts, part = threadIdx.x % parts;
+    const int64_t b = cur_tile * TB + b_local;
+    const bool active = b < nb;
+    const int B = b_local * m;                             // the bin is the values [B, B + m) of the tile
+    const int d0 = B >> 1, d1 = (B + m - 1) >> 1;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s_val);
+    uint32_t xo[kW16];
+    uint32_t ssum = 0;
+#pragma unroll
+    for (int i = 0; i < kW16; ++i) {
+      const int d = d0 + part + parts * i;
+      const uint32_t val = w[d <= d1 ? d : d1];
+      uint32_t keep = 0xffffffffu;
+      keep = 2 * d < B ? 0xffff0000u : keep;               // the low half lies before the bin
+      keep = 2 * d + 1 >= B + m ? keep & 0x0000ffffu : keep;   // the high half behind it
+      keep = (d <= d1 && active) ? keep : 0u;
+      const uint32_t in = val & keep;
+      ssum += (in & 0xffffu) + (in >> 16);
+      xo[i] = (val | ~keep) | 0x80008000u;                 // halves outside the bin: 0xffff, above every t
+    }
+    ssum = (uint32_t)parts_sum((int)ssum, parts);
+    auto count_le = [&](int t) {   // #{x <= t} of the bin, t = -1 .. 32766
+      const uint32_t sub = (uint32_t)(t + 1) * 0x00010001u;
+      int gt = 0;
+#pragma unroll
+      for (int i = 0; i < kW16; ++i) gt += __popc((xo[i] - sub) & 0x80008000u);
+      return 2 * kW16 * parts - parts_sum(gt, parts);
+    };
+    // 64 values around the bin's mean bracket its median on all but a handful of bins: the two counts that prove it, then six
+    // bisection steps; a wave with a bin outside its bracket bisects [0, cap] (the result is the same either way)
+    int lo = 0, hi = capval, steps = 15;
+    {
+      const int est = (int)((float)ssum / (float)m);
+      int lo0 = est - 31;
+      lo0 = lo0 < 0 ? 0 : lo0;
+      int hi0 = lo0 + 63;
+      hi0 = hi0 > capval ? capval : hi0;
+      lo0 = lo0 > hi0 ? hi0 : lo0;
+      const bool below = count_le(lo0 - 1) < kth;
+      const bool above = hi0 >= capval || count_le(hi0) >= kth;
+      if (__all((below && above) || !active)) { lo = lo0; hi = hi0; steps = 6; }
+    }
+#pragma unroll 1
+    for (int it = 0; it < steps; ++it) {
+      const int mid = (lo + hi) >> 1;
+      const int le = count_le(mid);
+      if (lo < hi) { if (le >= kth) hi = mid; else lo = mid + 1; }
+    }
+    if (active && part == 0) { binmed[b] = lo; binsum[b] = (int64_t)ssum; }
+  }
+  __syncthreads();
+  // ---- the window leaves as this workgroup's slab, unpacked (four counters per 16-byte store); the groups' sums go straight into
+  // res_hist's window ----
+  unsigned int* slab = hist_slabs + (size_t)blockIdx.x * vr * kResClasses;
+  for (int q = threadIdx.x; q < vr * kResClasses / 4; q += kThreads) {
+    const unsigned int a = s_hist[2 * q], c = s_hist[2 * q + 1];
+    u32x4 v4; v4.x = a & 0xffffu; v4.y = a >> 16; v4.z = c & 0xffffu; v4.w = c >> 16;
+    st_cg_x4(slab + 4 * q, v4);
+  }
+  if (!fold_slabs_add(hist_slabs, res_hist + (size_t)vb * kResClasses, vr * kResClasses, per_group, counters)) return;
   export_words(exp_dst, exp_src, exp_bytes);
 }
 
@@ -2657,6 +2891,41 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
     else { if (maxc == 1) RSI_K48J(1, 0, false, false); else RSI_K48J(2, 0, false, false); }
   }
 #undef RSI_K48J
+}
+// K4w applies under a cap of 254 .. 32766 with bins the register median phase holds, while no 16-bit counter of a workgroup's
+// window can wrap (a workgroup's share, one class of one value: share / 31 + one per tile)
+static void k416_geometry(int m, int64_t ncompact, int& grid, int& maxc) {
+  const int64_t tile = (int64_t)k48_bins_per_tile(m) * m;
+  const int64_t ntiles = (ncompact + tile - 1) / tile;
+  grid = (int)(ntiles < 256 * 3 ? (ntiles < 1 ? 1 : ntiles) : 256 * 3);
+  maxc = tile / 16 <= kThreads ? 1 : 2;
+}
+int cap_compact16_applies(int m, int32_t capval, int64_t ncompact) {
+  if (!(capval >= kByteSat && capval < 32767 && m <= 440 && (int64_t)m * capval < (int64_t)1 << 31)) return 0;
+  int grid, maxc;
+  k416_geometry(m, ncompact, grid, maxc);
+  const int64_t tile = (int64_t)k48_bins_per_tile(m) * m;
+  const int64_t tiles_per_wg = ((ncompact + tile - 1) / tile + grid - 1) / grid;
+  return tiles_per_wg * (tile / 31 + 2) < 60000 ? 1 : 0;
+}
+size_t cap_compact16_slab_bytes(int m, int64_t ncompact) {
+  int grid, maxc;
+  k416_geometry(m, ncompact, grid, maxc);
+  return (size_t)grid * kK4Window * kResClasses * 4;
+}
+void launch_cap_compact_bin16(const int32_t* src, const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact,
+                              int32_t capval, int m, int32_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs,
+                              unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, int vbase, hipStream_t stream) {
+  int grid, maxc;
+  k416_geometry(m, ncompact, grid, maxc);
+  const int TB = k48_bins_per_tile(m);
+  const size_t lds = (size_t)maxc * kThreads * 32 + (size_t)kK4Window * kResClasses * 2;
+  const int pg = fold_per_group_add(grid);
+#define RSI_K416(MC) do { RSI_ALLOW_FULL_LDS((k_cap_compact_bin16<MC>));                                                         \
+    RSI_LAUNCH((k_cap_compact_bin16<MC>), dim3(grid), dim3(kThreads), lds, stream, src, cbreak, cum, nreg, ncompact, capval, m, TB, vbase, \
+               rdc, binmed, binsum, res_hist, static_cast<unsigned int*>(slabs), pg, counters, exp_src, exp_dst, (unsigned int)exp_bytes, inl); } while (0)
+  if (maxc == 1) RSI_K416(1); else RSI_K416(2);
+#undef RSI_K416
 }
 unsigned int byte_escape_limit(int64_t n) { return (unsigned int)(n >> 3 > 0xffffffffll ? 0xffffffffll : n >> 3); }
 int hist_window_base(double center, int width) {   // [base, base + width) around the centre of the distribution; 0 up to ~160x

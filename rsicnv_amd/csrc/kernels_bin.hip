@@ -13,7 +13,7 @@ namespace rsik {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxGrid = 256 * 8;
+constexpr int kMaxGrid = 256 * 2;   // grid-stride kernels; most end with one same-address arrival atomic per workgroup (12 ns each)
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 inline int grid_for(int64_t items, int per_block) {
@@ -115,30 +115,53 @@ __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int
                                           unsigned int* s_h) {
   const uint32_t nl = use_lds ? (np < (uint32_t)use_lds ? np : (uint32_t)use_lds) : 0;   // buckets counted in LDS (use_lds = how many fit)
   auto lds_add = [&](uint32_t k, uint32_t c) { if (PACK16) atomicAdd(&s_h[k >> 1], c << ((k & 1u) << 4)); else atomicAdd(&s_h[k], c); };
-  if (use_lds) { for (uint32_t e = threadIdx.x; e < (PACK16 ? (nl + 1) / 2 : nl); e += kThreads) s_h[e] = 0; __syncthreads(); }
+  auto bucket = [&](float v) {
+    const double idx = ((double)v - ymin) / 0.01 + 0.5;        // wufunctions.cpp:396
+    uint32_t k = (uint32_t)(unsigned long long)idx;
+    return k >= np ? np - 1 : k;                               // cannot happen (np = range/dy + 2)
+  };
+  // Which nl buckets live in LDS: [wb, wb + nl).  A grid longer than that (values spread over more than 122: deep coverage --
+  // at 300x every bin's value lay beyond the first 12 288 buckets and took a global atomic, 280 us per launch instead of 40)
+  // gets its window around the median of 64 values sampled across the array; every workgroup samples the same positions.
+  __shared__ uint32_t s_wb;
+  if (threadIdx.x == 0) s_wb = 0u;
+  if (use_lds) { for (uint32_t e = threadIdx.x; e < (PACK16 ? (nl + 1) / 2 : nl); e += kThreads) s_h[e] = 0; }
+  if (use_lds && np > nl && threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    const int64_t i = (int64_t)(((unsigned long long)(2 * lane + 1) * (unsigned long long)nb) >> 7);   // the middle of the lane's 64th of the array
+    const bool valid = i < nb && !(mask && mask[i] != 0);
+    const uint32_t k = valid ? bucket(sel_value(x, i, use_abs, center)) : 0xffffffffu;
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)k, j);
+      rank += (kj < k || (kj == k && j < lane)) ? 1 : 0;     // invalid samples (all ones) rank last
+    }
+    const int nvalid = __popcll(__ballot(valid));
+    if (valid && rank == nvalid / 2) s_wb = k < nl / 2 ? 0u : (k - nl / 2 > np - nl ? np - nl : k - nl / 2);
+  }
+  if (use_lds) __syncthreads();
+  const uint32_t wb = use_lds ? s_wb : 0u;
+  auto count = [&](uint32_t k, uint32_t c) { if (k - wb < nl) lds_add(k - wb, c); else atomicAdd(&hist[k], c); };
   const int64_t nchunks = (nb + kHistRun - 1) / kHistRun;
   for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
     uint32_t pend_k = 0xffffffffu, pend_c = 0;
     const int64_t i0 = c * kHistRun, i1 = i0 + kHistRun < nb ? i0 + kHistRun : nb;
     for (int64_t i = i0; i < i1; ++i) {
       if (mask && mask[i] != 0) continue;
-      const float v = sel_value(x, i, use_abs, center);
-      const double idx = ((double)v - ymin) / 0.01 + 0.5;      // wufunctions.cpp:396
-      uint32_t k = (uint32_t)(unsigned long long)idx;
-      if (k >= np) k = np - 1;                                 // cannot happen (np = range/dy + 2)
+      const uint32_t k = bucket(sel_value(x, i, use_abs, center));
       if (k != pend_k) {
-        if (pend_c) { if (pend_k < nl) lds_add(pend_k, pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+        if (pend_c) count(pend_k, pend_c);
         pend_k = k; pend_c = 0;
       }
       ++pend_c;
     }
-    if (pend_c) { if (pend_k < nl) lds_add(pend_k, pend_c); else atomicAdd(&hist[pend_k], pend_c); }
+    if (pend_c) count(pend_k, pend_c);
   }
   if (use_lds) {
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < nl; e += kThreads) {
       const unsigned int c = PACK16 ? (s_h[e >> 1] >> ((e & 1u) << 4)) & 0xffffu : s_h[e];
-      if (c) atomicAdd(&hist[e], c);
+      if (c) atomicAdd(&hist[wb + e], c);
     }
   }
 }
@@ -221,16 +244,35 @@ __global__ __launch_bounds__(kThreads) void k_minmax_plan(const float* __restric
 // memory by the chain's last workgroup.
 struct ExportPair { const void* src[2]; void* dst[2]; unsigned int bytes[2]; };
 
-// hist_median_grid (hostmath.h) by one workgroup: the bucket in which the running count first reaches total/2
+// hist_median_grid (hostmath.h) by one workgroup: the bucket in which the running count first reaches total/2.
+// Two sweeps of coherent loads instead of one dependent load per bucket: every thread sums a contiguous stretch of buckets with
+// 16-byte loads, eight in flight; the stretch in which the count crosses total/2 is then read once more by the whole workgroup,
+// a few buckets per thread.  (One load and one wait per bucket was 30 of this kernel's 37 us on a 30x chromosome -- 12 000
+// buckets of 0.01 -- and 300 us at 300x, where the values span ten times the range.)
 __device__ inline void grid_walk_block(const uint32_t* __restrict__ hist, GridMedian* __restrict__ g) {
   __shared__ unsigned long long s_sum[kThreads];
+  __shared__ unsigned long long s_seen;
+  __shared__ unsigned int s_cross;
   const uint32_t np = g->np;
-  const uint32_t chunk = (np + kThreads - 1) / kThreads;
+  const uint32_t chunk = (((np + kThreads - 1) / kThreads) + 3u) & ~3u;   // whole quads
   const uint32_t b0 = threadIdx.x * chunk < np ? threadIdx.x * chunk : np;
   const uint32_t b1 = b0 + chunk < np ? b0 + chunk : np;
+  const __amdgpu_buffer_rsrc_t rs = coherent_buffer(hist);
   unsigned long long mine = 0;
-  for (uint32_t b = b0; b < b1; ++b) mine += ld_cg(hist + b);
+  for (uint32_t b = b0; b < b1; b += 32) {
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint32_t q = b + 4u * j; v[j] = ld_cg_buf_x4(rs, (q < b1 ? q : b0) * 4u, 0u); }   // (past the stretch: a valid quad, not counted)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t q = b + 4u * j;
+      const unsigned int c[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine += q + e < b1 ? c[e] : 0u;
+    }
+  }
   s_sum[threadIdx.x] = mine;
+  if (threadIdx.x == 0) s_cross = 0xffffffffu;
   __syncthreads();
   unsigned long long seen = 0, total = 0;
   for (int t = 0; t < kThreads; ++t) { const unsigned long long v = s_sum[t]; if (t < (int)threadIdx.x) seen += v; total += v; }
@@ -238,11 +280,27 @@ __device__ inline void grid_walk_block(const uint32_t* __restrict__ hist, GridMe
   // agent-scope stores: the same workgroup reads the record back through ld_cg for the export
   unsigned long long* med_bits = reinterpret_cast<unsigned long long*>(&g->med);
   if (threadIdx.x == 0) { st_cg(&g->count, total); if (r2 == 0) st_cg(med_bits, (unsigned long long)__double_as_longlong(g->ymin)); }
-  if (r2 != 0 && mine != 0 && seen < r2 && seen + mine >= r2) {
-    for (uint32_t b = b0; b < b1; ++b) {
-      const unsigned long long upto = seen + ld_cg(hist + b);
-      if (seen < r2 && upto >= r2) st_cg(med_bits, (unsigned long long)__double_as_longlong(g->ymin + (double)b * 0.01));
-      seen = upto;
+  if (r2 != 0 && mine != 0 && seen < r2 && seen + mine >= r2) { s_cross = b0; s_seen = seen; }   // exactly one thread
+  __syncthreads();
+  const uint32_t cb = s_cross;
+  if (cb == 0xffffffffu) return;   // (uniform)
+  const unsigned long long before = s_seen;
+  const uint32_t ce = cb + chunk < np ? cb + chunk : np;
+  const uint32_t per = (chunk + kThreads - 1) / kThreads;   // buckets of the crossing stretch per thread: 1 .. 16
+  const uint32_t m0 = cb + threadIdx.x * per < ce ? cb + threadIdx.x * per : ce;
+  const uint32_t m1 = m0 + per < ce ? m0 + per : ce;
+  unsigned long long part = 0;
+  for (uint32_t bb = m0; bb < m1; ++bb) part += ld_cg(hist + bb);
+  __syncthreads();   // s_sum is read no more
+  s_sum[threadIdx.x] = part;
+  __syncthreads();
+  unsigned long long run = before;
+  for (int t = 0; t < (int)threadIdx.x; ++t) run += s_sum[t];
+  if (part != 0 && run < r2 && run + part >= r2) {
+    for (uint32_t bb = m0; bb < m1; ++bb) {
+      const unsigned long long upto = run + ld_cg(hist + bb);
+      if (run < r2 && upto >= r2) st_cg(med_bits, (unsigned long long)__double_as_longlong(g->ymin + (double)bb * 0.01));
+      run = upto;
     }
   }
 }

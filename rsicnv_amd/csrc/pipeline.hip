@@ -1194,11 +1194,21 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       d_src = ctx->rd_gc.as<int32_t>();
     }
     const int vbase = want_cap ? hist_window_base(S.cap_median, kK4Window) : (P.gcadjust ? hist_window_base(S.gc_rdmean, kK4Window) : 0);
-    const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact, vbase) != 0;
-    if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
-    HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact, vbase)));
-    Timer t(ctx, "cap_compact_bin", true);
-    launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, vbase, st);
+    const char* w16_env = getenv("RSI_HOT_K4W");
+    if (want_cap && cap_compact16_applies(P.m, capval, ncompact) && !(w16_env && atoi(w16_env) == 0)) {
+      // K4w: a cap of 254 .. 32766 (deep coverage, or a generous cap): 16-bit tile and window counters.  RSI_HOT_K4W=0: the int32 kernel
+      HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
+      HIPCHK(ctx->slabs.ensure(cap_compact16_slab_bytes(P.m, ncompact)));
+      ctx->phases.push_back({"a5.k4w 16-bit tile", 1.0});
+      Timer t(ctx, "cap_compact_bin", true);
+      launch_cap_compact_bin16(d_src, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, vbase, st);
+    } else {
+      const bool overwrite = cap_compact_overwrites(P.m, capval, ncompact, vbase) != 0;
+      if (!overwrite) HIPCHK(hipMemsetAsync(d_res, 0, res_vals * kResClasses * 4, st));
+      HIPCHK(ctx->slabs.ensure(cap_compact_slab_bytes(P.m, capval, ncompact, vbase)));
+      Timer t(ctx, "cap_compact_bin", true);
+      launch_cap_compact_bin(d_src, n, d_cbreak, d_cum, inl, (int)noncode.size(), ncompact, capval, P.m, ctx->rdc.as<int32_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, d_bacc, ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, vbase, st);
+    }
   }
   BinAccum bacc;
   std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);

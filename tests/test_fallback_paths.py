@@ -254,7 +254,7 @@ DEEP_FLAGS = {"default": dict(), "med_m51": dict(m=51, trans=1), "nogc": dict(gc
 
 @pytest.mark.parametrize("flags", sorted(DEEP_FLAGS))
 @pytest.mark.parametrize("bimodal", [False, True])
-def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimodal, flags):
+def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimodal, flags, monkeypatch):
     """300x, overdispersed (2 % of the bases outside the int32 K4's 512-value LDS window: global atomics), and the same with the
     second half of the chromosome three times as deep (no window holds half of the values; cap at 2000; 1800 segments, 345 raw
     calls, candidate tests on int32 values in the thousands).  Median, SD, MAD, every array and the calls against the oracle.
@@ -280,6 +280,14 @@ def test_deep_coverage_overdispersed_and_bimodal(hot, hotlib, oracle_cls, bimoda
     if fl.get("gcadjust", 1):
         assert "a2-3.deep coverage" in dict(hot.phase_times())
     _deep_against_oracle(hot, res, O, gc=bool(fl.get("gcadjust", 1)))
+    # a cap of 254 .. 32766: K4w (16-bit tile and window counters); without a cap, and behind RSI_HOT_K4W=0, the int32 kernel
+    capped = fl.get("cap", 4.0) > 1
+    assert ("a5.k4w 16-bit tile" in dict(hot.phase_times())) == capped, dict(hot.phase_times())
+    if capped:
+        monkeypatch.setenv("RSI_HOT_K4W", "0")
+        res0 = hot.run(api.make_params(**fl), depth, fasta)
+        assert "a5.k4w 16-bit tile" not in dict(hot.phase_times())
+        _deep_against_oracle(hot, res0, O, gc=bool(fl.get("gcadjust", 1)))
 
 
 SWITCH_CASES = ["poisson_nb_m101", "gampois_nb_m101", "gampois_med_m51_cap4", "poisson_tail7"]
