@@ -2186,8 +2186,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_cap_compact_bin16(
   uint16_t* s_val = reinterpret_cast<uint16_t*>(smem);                                             // MAXC * 256 chunks of 16 values
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + (size_t)MAXC * kThreads * 32);     // [kK4Window][32] 16-bit counters
   __shared__ int64_t s_break[kRegLds], s_cum[kRegLds + 1];
+  __shared__ unsigned int s_extra[2 * kResClasses];   // rows of their own for the two values that pile up outside a window: 0 and the cap
   constexpr int vr = kK4Window;
   for (int e = threadIdx.x; e < vr * kResClasses / 2; e += kThreads) s_hist[e] = 0;
+  if (threadIdx.x < 2 * kResClasses) s_extra[threadIdx.x] = 0u;
   if (nreg <= kRegInline) {
     for (int e = threadIdx.x; e < nreg; e += kThreads) s_break[e] = inl.brk[e];
     for (int e = threadIdx.x; e <= nreg; e += kThreads) s_cum[e] = inl.cum[e];
@@ -2209,7 +2211,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_cap_compact_bin16(
   auto count_value = [&](int x, int cls) {
     const unsigned int w = (unsigned int)(x - vb);
     if (w < (unsigned int)vr) { const unsigned int idx = w * kResClasses + (unsigned int)cls; atomicAdd(&s_hist[idx >> 1], 1u << ((idx & 1u) << 4)); }
-    else atomicAdd(&res_hist[(size_t)(x < 0 ? 0 : x) * kResClasses + cls], 1u);
+    else if (x <= 0 || x == capval) atomicAdd(&s_extra[(x > 0 ? kResClasses : 0) + cls], 1u);   // uncovered stretches, capped pile-ups: thousands on one address
+    else atomicAdd(&res_hist[(size_t)x * kResClasses + cls], 1u);
   };
   int k = 0;
   auto geometry = [&](int64_t tile, int64_t& P0, int64_t& P1, bool& fast, int64_t& soff) {
@@ -2349,6 +2352,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_cap_compact_bin16(
     const unsigned int a = s_hist[2 * q], c = s_hist[2 * q + 1];
     u32x4 v4; v4.x = a & 0xffffu; v4.y = a >> 16; v4.z = c & 0xffffu; v4.w = c >> 16;
     st_cg_x4(slab + 4 * q, v4);
+  }
+  if (threadIdx.x < 2 * kResClasses) {
+    const unsigned int c = s_extra[threadIdx.x];
+    if (c) atomicAdd(&res_hist[(size_t)(threadIdx.x < kResClasses ? 0 : capval) * kResClasses + (threadIdx.x & (kResClasses - 1))], c);
   }
   if (!fold_slabs_add(hist_slabs, res_hist + (size_t)vb * kResClasses, vr * kResClasses, per_group, counters)) return;
   export_words(exp_dst, exp_src, exp_bytes);
