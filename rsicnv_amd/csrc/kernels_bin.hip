@@ -146,14 +146,31 @@ __device__ __forceinline__ void hist_body(const float* __restrict__ x, const int
   for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kThreads) {
     uint32_t pend_k = 0xffffffffu, pend_c = 0;
     const int64_t i0 = c * kHistRun, i1 = i0 + kHistRun < nb ? i0 + kHistRun : nb;
-    for (int64_t i = i0; i < i1; ++i) {
-      if (mask && mask[i] != 0) continue;
-      const uint32_t k = bucket(sel_value(x, i, use_abs, center));
+    auto one = [&](float xv) {
+      const float v = use_abs ? (float)fabs((double)xv - center) : xv;   // sel_value
+      const uint32_t k = bucket(v);
       if (k != pend_k) {
         if (pend_c) count(pend_k, pend_c);
         pend_k = k; pend_c = 0;
       }
       ++pend_c;
+    };
+    if (i1 - i0 == kHistRun) {
+      // a whole run: its eight values (and mask words) as 16-byte loads, all in flight at once -- element by element the loop
+      // paid a memory latency per value, most of the kernel's 37 us on a 60 Mb chromosome
+      static_assert(kHistRun == 8, "two quads per run");
+      const float4 a = *reinterpret_cast<const float4*>(x + i0), b = *reinterpret_cast<const float4*>(x + i0 + 4);
+      int4 ma = make_int4(0, 0, 0, 0), mb = ma;
+      if (mask) { ma = *reinterpret_cast<const int4*>(mask + i0); mb = *reinterpret_cast<const int4*>(mask + i0 + 4); }
+      const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const int mv[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (mv[e] == 0) one(xv[e]);
+    } else {
+      for (int64_t i = i0; i < i1; ++i) {
+        if (mask && mask[i] != 0) continue;
+        one(x[i]);
+      }
     }
     if (pend_c) count(pend_k, pend_c);
   }
@@ -228,13 +245,31 @@ __global__ __launch_bounds__(kThreads) void k_minmax_plan(const float* __restric
   const double c = center_ptr ? *center_ptr : center;
   uint32_t kmin = 0xffffffffu, kmax = 0;
   unsigned int bad = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
-    if (mask && mask[i] != 0) continue;
-    const float v = sel_value(x, i, use_abs, c);
+  auto one = [&](float xv) {
+    const float v = use_abs ? (float)fabs((double)xv - c) : xv;   // sel_value
     if (!(fabsf(v) <= 3.0e38f)) bad = 1;
     const uint32_t k = f32_key(v);
     kmin = k < kmin ? k : kmin;
     kmax = k > kmax ? k : kmax;
+  };
+  // four of a thread's strided elements per trip, their loads in flight together (one load and one wait per element was most of
+  // this kernel's 13 us)
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  for (; i + 3 * stride < nb; i += 4 * stride) {
+    float xv[4]; int mv[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = x[i + e * stride];
+    if (mask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mv[e] = mask[i + e * stride];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (mv[e] == 0) one(xv[e]);
+  }
+  for (; i < nb; i += stride) {
+    if (mask && mask[i] != 0) continue;
+    one(x[i]);
   }
   minmax_commit(kmin, kmax, bad, mm);
   if (last_block_done(counter)) grid_plan_block(mm, cap, hist, g);
@@ -937,12 +972,23 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   uint32_t* hist_u = hist_d + ((Lmax + 1 + kScanPad + 3) & ~3);   // scan_level_stride(Lmax)
   for (int e = threadIdx.x; e < 2 * (Lmax + 1); e += kThreads) s_l[e] = 0;
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kThreads) {
-    const uint32_t fd = first_del[i], fu = first_dup[i];
+  auto one = [&](uint32_t fd, uint32_t fu) {
     const bool hd = fd <= (uint32_t)Lmax, hu = fu <= (uint32_t)Lmax;
     if (hd) atomicAdd(&s_d[fd], 1u);
     if (hu) atomicAdd(&s_u[fu], 1u);
     if (hd && hu) { const uint32_t k = atomicAdd(&head[4], 1u); if (k < (uint32_t)kBothCap) { st_cg(&both[k].x, fd); st_cg(&both[k].y, fu); } }
+  };
+  {   // four of a thread's strided bins per trip: eight loads in flight instead of two
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 3 * stride < nb; i += 4 * stride) {
+      uint32_t fd[4], fu[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { fd[e] = first_del[i + e * stride]; fu[e] = first_dup[i + e * stride]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) one(fd[e], fu[e]);
+    }
+    for (; i < nb; i += stride) one(first_del[i], first_dup[i]);
   }
   __syncthreads();
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) {
