@@ -174,7 +174,7 @@ const char* rsi_pool_last_error(const rsi_pool* pool) {
 }
 
 static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
-                                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times, bool host_inputs) {
+                                 const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times, bool host_inputs, bool caller_first = false) {
   if (!pool || !p || nchrom < 0 || (nchrom > 0 && (!d_depth || !d_fasta || !n || !out))) return 0;
   auto R = std::make_shared<PoolRun>();
   R->params = *p;
@@ -196,7 +196,7 @@ static uint64_t pool_submit_impl(rsi_pool* pool, const rsi_params* p, int nchrom
     // a context sizes its workspace for the largest chromosome the pool has seen (read when a chromosome starts)
     for (rsi_ctx* c : pool->workers) c->reserve_n = std::max(c->reserve_n.load(), largest);
     pool->gate.few_chromosomes = nchrom <= kFewChromosomes && pool->queue.empty_locked();
-  });
+  }, caller_first);
 }
 
 static int pool_wait_impl(rsi_pool* pool, uint64_t ticket) {
@@ -212,12 +212,12 @@ static int pool_wait_impl(rsi_pool* pool, uint64_t ticket) {
 
 int rsi_pool_run(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,
                  const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
-  const uint64_t t = pool_submit_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false);
+  const uint64_t t = pool_submit_impl(pool, p, nchrom, d_depth, d_fasta, n, out, status, times, false, true);   // (the caller waits right away)
   return t ? pool_wait_impl(pool, t) : RSI_ERR_BAD_ARG;
 }
 int rsi_pool_run_host(rsi_pool* pool, const rsi_params* p, int nchrom, const int32_t* const* depth, const uint8_t* const* fasta,
                       const int64_t* n, rsi_result** out, int* status, rsi_batch_times* times) {
-  const uint64_t t = pool_submit_impl(pool, p, nchrom, reinterpret_cast<const void* const*>(depth), reinterpret_cast<const void* const*>(fasta), n, out, status, times, true);
+  const uint64_t t = pool_submit_impl(pool, p, nchrom, reinterpret_cast<const void* const*>(depth), reinterpret_cast<const void* const*>(fasta), n, out, status, times, true, true);
   return t ? pool_wait_impl(pool, t) : RSI_ERR_BAD_ARG;
 }
 uint64_t rsi_pool_submit(rsi_pool* pool, const rsi_params* p, int nchrom, const void* const* d_depth, const void* const* d_fasta,

@@ -42,8 +42,12 @@ struct RunQueue {
     return false;
   }
   // Queues the run and returns its ticket.  `before_publish(run)` runs under the mutex before any worker can see the run.
+  // caller_first: the submitting thread is about to wait_helping() for this run and the run is a single item -- the workers are
+  // not woken, the caller takes the item itself on the helpers' context (the same one every time: its buffers are allocated and
+  // warm, where whichever of a dozen woken workers wins the race may never have seen this kind of chromosome).  A caller that
+  // cannot take it (the helper's seat is occupied, or helping is off) wakes the workers from wait_helping().
   template <class Finish, class Before>
-  uint64_t submit(const std::shared_ptr<Run>& r, Finish&& finish, Before&& before_publish) {
+  uint64_t submit(const std::shared_ptr<Run>& r, Finish&& finish, Before&& before_publish, bool caller_first = false) {
     {
       std::lock_guard<std::mutex> lk(m);
       r->id = next_id++;
@@ -52,8 +56,16 @@ struct RunQueue {
       if (r->nitems == 0) { finish(*r); r->done = true; }
       else active.push_back(r);
     }
-    work_cv.notify_all();
+    if (!(caller_first && r->nitems == 1)) work_cv.notify_all();
     return r->id;
+  }
+  // under m: an item of the runs up to `upto` is still unclaimed
+  bool unclaimed_locked(uint64_t upto) const {
+    for (const auto& a : active) {
+      if (upto && a->id > upto) break;
+      if (a->claimed < a->nitems) return true;
+    }
+    return false;
   }
   bool empty_locked() const { return active.empty(); }
   // Blocks until there is an item to work on (true) or the queue is shut down (false).
@@ -106,6 +118,7 @@ struct RunQueue {
       std::shared_ptr<Run> r;
       int k = 0;
       if (!helper_busy && may_help() && claim_locked(r, k, mine->id)) {
+        if (r.get() != mine.get() && mine->claimed < mine->nitems) work_cv.notify_all();   // an older run's item first: mine is the workers' meanwhile
         helper_busy = true;
         lk.unlock();
         process(*r, k);
@@ -115,6 +128,7 @@ struct RunQueue {
         done_cv.notify_all();     // the helper's seat is free: another waiter may have claimable items
         continue;
       }
+      if (unclaimed_locked(mine->id)) work_cv.notify_all();   // not mine to take right now: the workers' (a caller-first run never woke them)
       done_cv.wait(lk);
     }
     for (auto it = unwaited.begin(); it != unwaited.end(); ++it) if (it->get() == mine.get()) { unwaited.erase(it); break; }

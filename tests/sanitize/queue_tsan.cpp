@@ -51,7 +51,7 @@ static int drive(int nworkers, int nclients, int rounds) {
         r->nitems = (round * 7 + c * 3 + j) % 26;        // 0 .. 25 items: empty runs too
         r->result.assign((size_t)r->nitems, 0);
         r->touched.assign((size_t)r->nitems, 0);
-        q.submit(r, finish, [](TestRun&) {});
+        q.submit(r, finish, [](TestRun&) {}, (round + j) % 2 == 0);   // every other run "caller first": a single item does not wake the workers
         mine.push_back(r);
       }
       if ((round + c) % 2) std::swap(mine.front(), mine.back());   // wait out of order
@@ -64,7 +64,7 @@ static int drive(int nworkers, int nclients, int rounds) {
           if (h.id > my_id) young_help.fetch_add(1);
           process(h, k);
           helpers_inside.fetch_sub(1);
-        }, finish, [] { return true; });
+        }, finish, [&] { return nworkers == 0 || (c + round) % 3 != 0; });   // with workers around, a caller that may not help now and then
         long want = 0;
         bool once = true;
         for (int k = 0; k < r->nitems; ++k) { want += (long)r->id * 1000 + k; once = once && r->touched[(size_t)k] == 1; }
