@@ -53,16 +53,20 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / rounds * 1e3, infl
 
-    per_genome_ms(allc, 3)
-    whole, infl = per_genome_ms(allc, 4 * args.rounds)
-    print(f"world 1: {whole:.2f} ms per genome ({infl} in flight)", flush=True)
+    def best_of(chroms, loops=3):
+        """the fastest of `loops` timed loops (a loop now and then is 10-25 % slow: 12.8 - 16.0 ms for the whole genome on one box)"""
+        per_genome_ms(chroms, 3)
+        runs = [per_genome_ms(chroms, 4 * args.rounds) for _ in range(loops)]
+        return min(r[0] for r in runs), runs[0][1], [round(r[0], 2) for r in runs]
+
+    whole, infl, loops = best_of(allc)
+    print(f"world 1: {whole:.2f} ms per genome ({infl} in flight; loops {loops})", flush=True)
     for world in args.worlds:
         parts = rd.lpt_assign(lengths, world)
         worst, per = 0.0, []
         for part in parts:
             mine = [allc[i] for i in part]
-            per_genome_ms(mine, 3)
-            ms, infl = per_genome_ms(mine, 4 * args.rounds)
+            ms, infl, _ = best_of(mine)
             per.append((len(part), sum(lengths[i] for i in part) / 1e6, ms))
             worst = max(worst, ms)
         print(f"world {world}: slowest share {worst:.2f} ms per genome ({infl} in flight) -> x{whole / worst:.2f} of one GPU; shares (chromosomes, Mb, ms): "
