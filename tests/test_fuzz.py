@@ -18,6 +18,13 @@ def test_random_chromosomes_and_flags_agree_with_the_oracle(seed):
     assert fuzz_probe.run(8, seed, max_bins=60_000) == 0
 
 
+def test_random_deep_chromosomes_agree_with_the_oracle():
+    """120x / 300x under caps of 2, 4 and 8 times the median, bins of 11 ... 439 bases: the 16-bit compaction kernel (K4w) in
+    every thread-per-bin class, the quantile histograms' sampled LDS window, the int32 candidate kernels."""
+    import fuzz_probe
+    assert fuzz_probe.run(8, 13, max_bins=60_000, deep=True) == 0
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("flags", [dict(), dict(m=51, trans=1), dict(gcadjust=0, cap=2.0), dict(m=201, trans=2, cap=-1.0)])
 def test_a_pool_of_random_chromosomes_equals_one_context(flags):

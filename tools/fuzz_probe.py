@@ -29,8 +29,9 @@ print("RESULT " + json.dumps(out))
 KEYS = ("start", "end", "type", "geno", "status", "length", "qscore", "score", "p1", "cnvmed", "cnvsd", "cnviqr", "refmed", "refsd", "refiqr")
 
 
-def run(ncases, seed, max_bins=250_000):
-    """Returns the number of cases that differ (or where only one side refused)."""
+def run(ncases, seed, max_bins=250_000, deep=False):
+    """Returns the number of cases that differ (or where only one side refused).  deep: coverage of 120x / 300x under a cap, every
+    bin-size class of the 16-bit compaction kernel (K4w: 2, 4, 8 and 16 threads per bin)."""
     from conftest import make_case
     from rsicnv_amd import api
     rng = np.random.default_rng(seed)
@@ -41,12 +42,14 @@ def run(ncases, seed, max_bins=250_000):
         n = int(rng.choice([60_000, 150_000, 400_000, 900_000, 2_000_000])) + int(rng.integers(0, 40))
         model = int(rng.integers(0, 2))
         mean = float(rng.choice([8, 15, 30, 30, 60, 120, 300]))
+        if deep: mean = float(rng.choice([120, 300, 300]))
         crowded = rng.random() < 0.3
         plan_kw = dict(n=n, seed=int(rng.integers(1, 1 << 30)), model=model, mean=mean, n_events=int(rng.integers(20, 60)) if crowded else int(rng.integers(1, 12)),
                        gaps=int(rng.integers(0, 4)), min_len=600 if crowded else 3000, max_len=int(rng.choice([3000, 8000])) if crowded else int(rng.choice([5000, 20000, 60000])),
                        end_n=int(rng.choice([0, 3000, 10000])), gap_len=int(rng.choice([200, 3000, 9000])))
         fl = dict(m=int(rng.choice([11, 51, 101, 101, 201, 439])), trans=int(rng.choice([0, 0, 1, 2])), cap=float(rng.choice([-1.0, 2.0, 4.0, 4.0])),
                   gcadjust=int(rng.choice([0, 1, 1, 1])), merge=int(rng.choice([0, 1, 1])))
+        if deep: fl.update(m=int(rng.choice([11, 51, 101, 201, 439])), cap=float(rng.choice([2.0, 4.0, 8.0])))
         if rng.random() < 0.5:   # the rarely touched knobs (rsi.cpp:34-98): score factor, MED threshold, neighbourhood size, minimum length,
                                  # margin, thinning budget, p-value bar
             fl.update(epsilon=float(rng.choice([0.5, 1.5, 3.0])), chklen=float(rng.choice([1.5, 2.5, 4.0])), minmlen=float(rng.choice([2.01, 3.01, 6.0])),
@@ -129,4 +132,4 @@ def run(ncases, seed, max_bins=250_000):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1, deep=len(sys.argv) > 3 and sys.argv[3] == "deep")
