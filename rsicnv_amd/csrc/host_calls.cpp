@@ -616,7 +616,38 @@ int to_reference(const std::vector<Region>& noncode, int p) {
 void test_block_segments(const CallerInput& in, IntSpan status, std::vector<Candidate>& segs) {
   const VecView bins{in.binmedint};
   std::vector<Candidate> T = segs;
-  for (int i = 0; i < (int)T.size(); ++i) test_candidate(in, bins, T, i);
+  // First round (rsi.cpp:430-436): test i sees which of the segments before it were just rejected (a rejected neighbour is no
+  // longer jumped over).  With a device tester and enough segments to pay for its four launches, all of them are tested in one
+  // batch against the list as it stands.  Such a result holds for test i unless a segment rejected since lies where i's LEFT
+  // walk went (the segments behind i are untouched when i's turn comes; its own fields do not change): every rejected
+  // segment must end before the last position that walk examined.  Comparing the whole plans, as the final tests do, is too
+  // strict here -- most block segments are rejected, and each rejection changes the 48-entry neighbour chains of all tests
+  // behind it, although the segments lie tens of thousands of bins apart and a walk covers a few hundred.  Anything else -- few
+  // segments, a rejected neighbour within reach, a test the device declined -- is the host loop (14 us per test: 0.5 ms of a
+  // 250 Mb chromosome's 3 ms).
+  constexpr int kBlockBatchMin = 24;
+  std::vector<TestPlan> plans;
+  std::vector<TestStats> stats;
+  std::vector<int> reach;
+  std::vector<char> ok;
+  bool sorted = true;
+  for (size_t i = 1; i < T.size(); ++i) sorted = sorted && T[i - 1].end < T[i].start;
+  for (const Candidate& c : T) sorted = sorted && c.status != -9;   // (nothing rejected before the round starts)
+  if (in.block_tester && sorted && (int)T.size() >= kBlockBatchMin) {
+    int cut = 0;
+    for (int i = 0; i < (int)T.size(); ++i) plans.push_back(plan_test(in, bins.size(), T, i, &cut));
+    if (!in.block_tester->test(plans, stats, reach, ok)) plans.clear();
+  }
+  int rejected_end = -1;   // the largest end among the segments rejected so far
+  for (int i = 0; i < (int)T.size(); ++i) {
+    if (!plans.empty() && ok[(size_t)i] && !(plans[(size_t)i].cut & 1) && rejected_end < reach[(size_t)i]) {
+      finish_judgement(in, stats[(size_t)i], T[i]);
+      if (in.prof) in.prof->block_batch_hits++;
+    } else {
+      test_candidate(in, bins, T, i);
+    }
+    if (T[i].status == -9 && T[i].end > rejected_end) rejected_end = T[i].end;
+  }
   for (int i = 0; i < (int)T.size(); ++i) {
     if (T[i].status != -9) continue;
     if (T[i].type == kDel && T[i].cnvmed < 0.7 * T[i].refmed) { T[i].geno = 1; T[i].p1 = in.P.p; continue; }

@@ -70,7 +70,7 @@ class DepthPager {
 // wall-clock split of the candidate stages (ms), filled when CallerInput::prof is set
 struct CallProfile {
   double fetch = 0, gather = 0, winmean = 0, quantiles = 0, variance = 0, sharpen = 0, merge = 0, final_tests = 0, device_ms = 0;
-  int tests = 0, spec_hits = 0, single_tests = 0, host_fallbacks = 0;
+  int tests = 0, spec_hits = 0, single_tests = 0, host_fallbacks = 0, block_batch_hits = 0;
 };
 
 // Statistics of one neighbourhood test (what isitcnv derives from its two arrays, rsi.cpp:113-147).
@@ -126,6 +126,7 @@ struct CallerInput {
   rsi_params P;
   CallProfile* prof = nullptr;
   NeighbourTester* tester = nullptr;   // when set, per-base candidate work runs on the device
+  NeighbourTester* block_tester = nullptr;   // the same on the BIN medians (areblockscnv): one batch for a scan's segments when there are many
   double RDmedian, RDsd;
   int64_t ncompact;                 // rsi::end with rsi::start = 1
   const std::vector<Region>* noncode;

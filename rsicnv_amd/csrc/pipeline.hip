@@ -1348,7 +1348,19 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       res->log_nb = !use_med;
       for (const Candidate& c : so.segs) segs_all.push_back(c);
       segs = so.segs;
-      { Phase ph(ctx, "a15.blocks"); rsih::test_block_segments(in, so.status2, segs); }   // areblockscnv, rsi.cpp:1847
+      {   // areblockscnv, rsi.cpp:1847: on the bin medians; a scan with many segments sends its first round to the device as one batch
+        Phase ph(ctx, "a15.blocks");
+        const char* bb_env = getenv("RSI_HOT_BLOCK_BATCH");   // 0: every block test on the host
+        DeviceTester block_tester(ctx, DepthRef{ctx->binmed.p, 4}, nb, RDmedian);
+        rsih::CallProfile bprof;
+        in.block_tester = (bb_env && atoi(bb_env) == 0) ? nullptr : &block_tester;
+        in.prof = &bprof;
+        rsih::test_block_segments(in, so.status2, segs);
+        in.block_tester = nullptr;
+        in.prof = nullptr;
+        if (block_tester.failed) return RSI_ERR_HIP;
+        if (bprof.block_batch_hits) ctx->phases.push_back({"a15.block batch hits", (double)bprof.block_batch_hits});
+      }
       return RSI_OK;
     };
     std::vector<Candidate> tested;

@@ -131,6 +131,19 @@ def test_config2_250mb_against_reference_golden(hot, hotlib):
     res2 = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
     ok, why = calls_equal(res.calls("calls_raw"), res2.calls("calls_raw"), rtol=0)
     assert ok, why
+    # the block tests' first round went to the device as one batch (a scan with two dozen segments and more); behind
+    # RSI_HOT_BLOCK_BATCH=0 all of them run on the host: the same blocks, the same calls
+    hits = dict(hot.phase_times()).get("a15.block batch hits", 0)
+    assert hits >= 24, dict(hot.phase_times())
+    os.environ["RSI_HOT_BLOCK_BATCH"] = "0"
+    try:
+        res3 = hot.run_device(api.make_params(**flags), d_rd.data_ptr(), d_fa.data_ptr(), plan["n"])
+    finally:
+        del os.environ["RSI_HOT_BLOCK_BATCH"]
+    assert "a15.block batch hits" not in dict(hot.phase_times())
+    for which in ("blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), res3.calls(which))
+        assert ok, f"{which}: {why}"
 
 
 def test_config4_one_60x_med_chromosome_against_reference_golden(hot, hotlib):
