@@ -89,9 +89,23 @@ __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __re
                                                             uint32_t cap, int64_t n, int dx, PhaseParams* __restrict__ pp,
                                                             int64_t* __restrict__ cbreak, int64_t* __restrict__ cum,
                                                             unsigned int* __restrict__ counter) {
-  for (int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * kThreads) {
-    const uint64_t cur = nbits[w];
-    const uint64_t prev_top = w > 0 ? (nbits[w - 1] >> 63) : 0;
+  // four of a thread's strided words per trip, their eight loads in flight together (256 workgroups: sixty dependent trips per
+  // thread on a 250 Mb chromosome otherwise)
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t w0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; w0 < nwords; w0 += 4 * stride) {
+    uint64_t curv[4], prevv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t w = w0 + e * stride;
+      curv[e] = w < nwords ? nbits[w] : 0;
+      prevv[e] = (w < nwords && w > 0) ? nbits[w - 1] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+    const int64_t w = w0 + e * stride;
+    if (w >= nwords) break;
+    const uint64_t cur = curv[e];
+    const uint64_t prev_top = prevv[e] >> 63;
     const uint64_t shifted = (cur << 1) | prev_top;
     uint64_t starts = cur & ~shifted, ends = ~cur & shifted;
     while (starts) {
@@ -105,6 +119,7 @@ __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __re
       ends &= ends - 1;
       const uint32_t k = atomicAdd(count, 1u);
       if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1) | 1ull);
+    }
     }
   }
   if (!pp) return;
