@@ -37,6 +37,26 @@ __device__ inline StepFn fs_compose(StepFn f, StepFn g) {   // first f, then g
   h.a1 = h.a1 < kStepSat ? h.a1 : kStepSat;
   return h;
 }
+// Ordered (non-commutative) inclusive composition over the workgroup's 256 functions: thread t gets f_0 ; f_1 ; ... ; f_t.
+// Inside a wave the six steps are DPP moves (row shifts, then lane 15 / 31 into the rows above: the lanes a step does not reach
+// receive {0, 0}, the identity), the four wave totals meet in LDS: ONE barrier where the LDS ladder took eight.  The caller
+// keeps a barrier between the reads of s_wt here and the next call.
+template <int CTRL, int ROWS, bool BOUND>
+__device__ inline StepFn dpp_move_fn(StepFn f) { return StepFn{dpp_move_i64<CTRL, ROWS, BOUND>(f.a0), dpp_move_i64<CTRL, ROWS, BOUND>(f.a1)}; }
+__device__ inline StepFn block_incl_scan_fn(StepFn x, StepFn* s_wt /* [kThreads / 64] */) {
+  x = fs_compose(dpp_move_fn<0x111, 0xF, true>(x), x);
+  x = fs_compose(dpp_move_fn<0x112, 0xF, true>(x), x);
+  x = fs_compose(dpp_move_fn<0x114, 0xF, true>(x), x);
+  x = fs_compose(dpp_move_fn<0x118, 0xF, true>(x), x);
+  x = fs_compose(dpp_move_fn<0x142, 0xA, false>(x), x);
+  x = fs_compose(dpp_move_fn<0x143, 0xC, false>(x), x);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 63) s_wt[wave] = x;
+  __syncthreads();
+  StepFn pre = {0, 0};
+  for (int w = 0; w < wave; ++w) pre = fs_compose(pre, s_wt[w]);
+  return fs_compose(pre, x);
+}
 // the step of adding x (a non-negative finite float) while the sum is in the binade with unit 2^ue
 __device__ inline StepFn fs_step(float x, int ue) {
   // x = m 2^e exactly (m a 24-bit integer, or 0): in units of 2^ue it is m 2^(e-ue), integer part X, remainder r
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
   __shared__ StepFn s_ta[kThreads], s_tb[kThreads];
   __shared__ int s_t0, s_wcnt[kThreads / 64];
   __shared__ unsigned int s_sbits, s_cur;
-  __shared__ StepFn s_sc[2][kThreads];
+  __shared__ StepFn s_wt[kThreads / 64];
   const int nlev = 2 * Lmax + 1;
   unsigned int* out_bits = reinterpret_cast<unsigned int*>(out);
   unsigned int* out_cnt = out_bits + nlev;
@@ -223,17 +243,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
             const int d = (ex - 150) - R.ue0;
             StepFn F = {0, 0};
             if ((int)threadIdx.x >= c && (int)threadIdx.x < bn) F = d == 0 ? R.f0 : (d == 1 ? R.f1 : StepFn{kStepSat, kStepSat});
-            int cur = 0;
-            s_sc[0][threadIdx.x] = F;
-            __syncthreads();
-            for (int dd = 1; dd < kThreads; dd <<= 1) {
-              StepFn G = s_sc[cur][threadIdx.x];
-              if ((int)threadIdx.x >= dd) G = fs_compose(s_sc[cur][threadIdx.x - dd], G);
-              s_sc[cur ^ 1][threadIdx.x] = G;
-              cur ^= 1;
-              __syncthreads();
-            }
-            F = s_sc[cur][threadIdx.x];
+            F = block_incl_scan_fn(F, s_wt);
             const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
             const long long St = S + ((S & 1) ? F.a1 : F.a0);
             const unsigned long long okm = __ballot(St < (1ll << 24));
@@ -310,17 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_fs_level_sums(const float* __restr
           const StepFn* fn = ex - 150 == ue ? s_ta : s_tb;
           StepFn F = {0, 0};
           if ((int)threadIdx.x >= t0) F = fn[threadIdx.x];   // own entry: no barrier needed before reading it
-          int cur = 0;
-          s_sc[0][threadIdx.x] = F;
-          __syncthreads();
-          for (int dd = 1; dd < kThreads; dd <<= 1) {
-            StepFn G = s_sc[cur][threadIdx.x];
-            if ((int)threadIdx.x >= dd) G = fs_compose(s_sc[cur][threadIdx.x - dd], G);
-            s_sc[cur ^ 1][threadIdx.x] = G;
-            cur ^= 1;
-            __syncthreads();
-          }
-          F = s_sc[cur][threadIdx.x];
+          F = block_incl_scan_fn(F, s_wt);
           const long long S = (long long)((bits & 0x7fffffu) | 0x800000u);
           const long long St = S + ((S & 1) ? F.a1 : F.a0);
           const bool ok = St < (1ll << 24);
