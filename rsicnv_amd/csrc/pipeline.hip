@@ -1310,8 +1310,15 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     in.short_neighbourhoods = &short_neighbourhoods;
     in.P = P; in.RDmedian = RDmedian; in.RDsd = S.RDsd; in.ncompact = ncompact; in.noncode = &noncode;
     HIPCHK(ctx->h_medint.ensure((size_t)nb * 4));
-    HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));   // complete at the scan's first wait
-    in.binmedint = rsih::IntSpan(ctx->h_medint.as<int>(), nb);   // read in place, after the scan's first wait
+    // The bin medians for the host's block tests: K4 is complete (the host has its statistics), so the copy needs no ordering
+    // against the stream -- it goes to a stream of its own and runs beside the transform, the quantile chains and the scan
+    // instead of in front of them (a blit of 30 - 170 us at the head of a lone chromosome's chain).  Joined before the block
+    // tests, and at the latest when this run ends (CopyJoin): the next run's K4 writes the same array.
+    HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIPCHK(hipEventRecord(ctx->copy_ev, ctx->copy_stream));
+    ctx->copy_pending = true;
+    struct CopyJoin { rsi_ctx* c; ~CopyJoin() { if (c->copy_pending) { c->copy_pending = false; (void)hipEventSynchronize(c->copy_ev); } } } copy_join{ctx};
+    in.binmedint = rsih::IntSpan(ctx->h_medint.as<int>(), nb);   // read in place, after join_copy()
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
       ScanOut so;
@@ -1350,6 +1357,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       segs = so.segs;
       {   // areblockscnv, rsi.cpp:1847: on the bin medians; a scan with many segments sends its first round to the device as one batch
         Phase ph(ctx, "a15.blocks");
+        if (ctx->copy_pending) { ctx->copy_pending = false; HIPCHK(hipEventSynchronize(ctx->copy_ev)); }   // the host copy of the bin medians
         const char* bb_env = getenv("RSI_HOT_BLOCK_BATCH");   // 0: every block test on the host
         DeviceTester block_tester(ctx, DepthRef{ctx->binmed.p, 4}, nb, RDmedian);
         rsih::CallProfile bprof;
@@ -1467,6 +1475,18 @@ void rsi_default_params(rsi_params* p) {   // rsi.cpp:34-98
   p->cap = 4.0; p->epsilon = 1.5; p->threshold = -1.0; p->chklen = 2.5; p->minmlen = 3.01; p->buffer = 0.05; p->p = 0.05;
 }
 
+// One side stream per DEVICE for the contexts' small device -> host copies that need no ordering against their kernels (the bin
+// medians for the block tests): a stream per context doubled a 16-worker pool's streams beyond the hardware queues, and the genome
+// took 45 ms instead of 13.  The copies of different chromosomes queue behind each other here (1.6 ms of copy time per genome).
+static hipStream_t shared_copy_stream(int device) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) streams[device] = nullptr;
+  return streams[device];
+}
+
 rsi_ctx* rsi_hot_create(int device, int* status) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -1478,7 +1498,9 @@ rsi_ctx* rsi_hot_create(int device, int* status) {
   rsi_ctx* ctx = new rsi_ctx();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming) != hipSuccess ||
+      (ctx->copy_stream = shared_copy_stream(device)) == nullptr ||
+      hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess) {
     set_global_error("hipSetDevice / hipStreamCreate failed");
     if (status) *status = RSI_ERR_HIP;
     delete ctx;
@@ -1496,6 +1518,7 @@ void rsi_hot_destroy(rsi_ctx* ctx) {
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   for (int b = 0; b < 2; ++b) if (ctx->text_pin[b]) (void)hipHostFree(ctx->text_pin[b]);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
+  if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);   // (copy_stream is the device's shared one: never destroyed)
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -129,6 +129,9 @@ struct rsi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t sync_ev = nullptr;   // event every wait on the stream polls (stream_wait)
+  hipStream_t copy_stream = nullptr;   // the bin medians' copy to the host (block tests) runs beside the transform and scan kernels
+  hipEvent_t copy_ev = nullptr;
+  bool copy_pending = false;
   std::string err;
   int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around the kernel named timing_kernel only
   std::string timing_kernel = "cap_compact_bin";
