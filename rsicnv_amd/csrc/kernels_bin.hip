@@ -1237,7 +1237,7 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
                       const GridChain& c, GridMedian* out, const GridExport* ex, const FillList* fill, hipStream_t stream) {
   const uint32_t bins = kLdsBins;
   int grid = grid_for(nb, kThreads * kHistRun * 2);
-  if (grid > 128) grid = 128;
+  if (grid > 256) grid = 256;
   // 16-bit LDS counters while a workgroup's share of the bins cannot make one wrap
   const bool pack16 = (nb + grid - 1) / grid + kHistRun < 65536;
   const size_t lds = pack16 ? (size_t)bins * 2 : (size_t)bins * 4;
