@@ -952,11 +952,32 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
 // and the pass counters in `work`, a copy of which goes to mapped host memory.
 // work: [ScanPassHead (64 bytes)] [hist_del] [hist_dup], scan_level_stride(Lmax) words each
 constexpr int kBothCap = 16384;
-__device__ inline uint32_t stop_level_walk(const unsigned int* s_l, int32_t Lmax, int64_t nb) {
-  unsigned long long cum = 0;
-  for (int L = 1; L <= Lmax; ++L) {
-    cum += s_l[L];
-    if ((double)(int)cum / (double)(int)nb > 0.2) return (uint32_t)L;
+// The first L whose cumulated share of the bins exceeds 0.2 (rsi.cpp:1217-1225), or Lmax: the whole workgroup calls it and gets the
+// same answer.  256 levels at a time -- a block scan of their counts, the reference's own expression per level, the smallest
+// level that passes -- where one thread used to walk the levels with a double division each (a hundred of them: 6 us per call,
+// two calls per launch).
+__device__ inline uint32_t stop_level_block(const unsigned int* s_l, int32_t Lmax, int64_t nb) {
+  __shared__ int s_wsum[kThreads / 64], s_wmin[kThreads / 64];
+  long long carry = 0;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int base = 1; base <= Lmax; base += kThreads) {
+    const int L = base + (int)threadIdx.x;
+    const int c = L <= Lmax ? (int)s_l[L] : 0;
+    const int incl = wave_incl_scan(c);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    long long before = carry, total = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { if (w < wave) before += s_wsum[w]; total += s_wsum[w]; }
+    const long long cum = before + incl;
+    int first = (L <= Lmax && (double)(int)cum / (double)(int)nb > 0.2) ? L : 0x7fffffff;
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(first, d); first = o < first ? o : first; }
+    if (lane == 0) s_wmin[wave] = first;
+    __syncthreads();
+    int best = 0x7fffffff;
+    for (int w = 0; w < kThreads / 64; ++w) best = s_wmin[w] < best ? s_wmin[w] : best;
+    __syncthreads();   // s_wsum / s_wmin are rewritten by the next round (and by the next call)
+    if (best != 0x7fffffff) return (uint32_t)best;
+    carry += total;
   }
   return (uint32_t)Lmax;
 }
@@ -999,10 +1020,7 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   if (!last_block_done(counter)) return;
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) { s_d[e] = ld_cg(hist_d + e); s_u[e] = ld_cg(hist_u + e); }
   __syncthreads();
-  __shared__ uint32_t s_ldel;
-  if (threadIdx.x == 0) s_ldel = stop_level_walk(s_d, Lmax, nb);
-  __syncthreads();
-  const uint32_t ldel = s_ldel;
+  const uint32_t ldel = stop_level_block(s_d, Lmax, nb);
   const uint32_t nboth = ld_cg(&head[4]);
   if (nboth <= (uint32_t)kBothCap) {
     for (uint32_t k = threadIdx.x; k < nboth; k += kThreads) {
@@ -1019,7 +1037,8 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   }
   __syncthreads();
   for (int e = threadIdx.x; e <= Lmax; e += kThreads) st_cg(&hist_u[e], s_u[e]);
-  if (threadIdx.x == 0) { st_cg(&head[2], ldel); st_cg(&head[3], stop_level_walk(s_u, Lmax, nb)); }
+  const uint32_t ldup = stop_level_block(s_u, Lmax, nb);
+  if (threadIdx.x == 0) { st_cg(&head[2], ldel); st_cg(&head[3], ldup); }
   sync_drained();
   export_words(host_copy, work, host_bytes);
 }
