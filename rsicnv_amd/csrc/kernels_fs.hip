@@ -168,13 +168,13 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_fns(const float* __restri
       }
     }
   }
-  s_f[0][threadIdx.x] = f0; s_f[1][threadIdx.x] = f1; s_cnt[threadIdx.x] = nm;
-  __syncthreads();
-  if (threadIdx.x < 2) {   // ordered composition over the 256 threads' functions (one lane per candidate)
-    StepFn acc = {0, 0};
-    for (int t = 0; t < kThreads; ++t) acc = fs_compose(acc, s_f[threadIdx.x][t]);
-    if (threadIdx.x == 0) { fns[blockIdx.x].ue0 = ue0; fns[blockIdx.x].f0 = acc; } else fns[blockIdx.x].f1 = acc;
+  {   // ordered composition over the 256 threads' functions, one scan per candidate binade: the last thread holds the chunk's function
+    const StepFn c0 = block_incl_scan_fn(f0, s_f[0]);
+    const StepFn c1 = block_incl_scan_fn(f1, s_f[1]);
+    if (threadIdx.x == kThreads - 1) { fns[blockIdx.x].ue0 = ue0; fns[blockIdx.x].f0 = c0; fns[blockIdx.x].f1 = c1; }
   }
+  s_cnt[threadIdx.x] = nm;
+  __syncthreads();
   for (int e = threadIdx.x; e < 2 * Lmax + 1; e += kThreads) { const unsigned int c = s_lev[e]; if (c) atomicAdd(&level_count[e], c); }
   int before = 0;
   for (int t = 0; t < (int)threadIdx.x; ++t) before += s_cnt[t];
