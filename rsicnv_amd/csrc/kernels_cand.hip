@@ -751,6 +751,58 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     return (int)(g.thin ? A[J.start + (int)((double)q / (double)g.nbody_eff * (double)g.nbody)] : A[J.start + q]);
   };
   int lo = 0x7fffffff, hi = (int)0x80000000; long long s1 = 0, s2 = 0;
+  if (sizeof(TD) == 1 && !g.thin) {
+    // Byte depth, no thinning (the usual case): ONE pass with 16-byte loads -- sixteen values each, four loads in flight per
+    // thread -- into a histogram over the byte values themselves; minimum, maximum, sum and sum of squares follow from its 256
+    // counters exactly, and the quantile walk starts at the minimum's counter.  The general form below reads the candidate
+    // twice, a value per load: 100 us for a candidate of 200 000 bases, the longest workgroup of the launch by far.
+    for (unsigned e = threadIdx.x; e < 260; e += kTestThreads) s_hist[e] = 0;
+    __syncthreads();
+    const uint8_t* B = reinterpret_cast<const uint8_t*>(A) + J.start;
+    for (int q0 = 16 * (int)threadIdx.x; q0 < width; q0 += 4 * 16 * kTestThreads) {
+      WalkBytes16 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = q0 + k * 16 * kTestThreads;
+        if (q + 16 <= width) v[k] = *reinterpret_cast<const WalkBytes16*>(B + q);
+        else {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v[k].w[w] = 0;
+          for (int j = 0; j < 16 && q + j < width; ++j) v[k].w[j >> 2] |= (uint32_t)B[q + j] << (8 * (j & 3));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = q0 + k * 16 * kTestThreads;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (q + j < width) atomicAdd(&s_hist[(v[k].w[j >> 2] >> (8 * (j & 3))) & 0xffu], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const long long c = s_hist[threadIdx.x];
+      if (c) { lo = (int)threadIdx.x; hi = (int)threadIdx.x; s1 = c * (long long)threadIdx.x; s2 = c * (long long)threadIdx.x * (long long)threadIdx.x; }
+    }
+    lo = block_reduce(lo, [](int a, int b2) { return a < b2 ? a : b2; }, s_i2);
+    hi = block_reduce(hi, [](int a, int b2) { return a > b2 ? a : b2; }, s_i2);
+    s1 = block_reduce(s1, [](long long a, long long b2) { return a + b2; }, s_l);
+    s2 = block_reduce(s2, [](long long a, long long b2) { return a + b2; }, s_l);
+    double q0 = lo, q1 = (double)s1 / (double)width, q2 = hi;
+    unsigned flags = 0;
+    if ((double)hi - (double)lo >= 1.0) {
+      const unsigned nbk = (unsigned)(hi - lo) + 2;
+      int qb[3];
+      hist_ranks(s_hist + lo, nbk, (size_t)width, s_scan, s_q, qb);
+      if (qb[0] >= 0) q0 = (double)lo + qb[0] * 1.0;
+      if (qb[1] >= 0) q1 = (double)lo + qb[1] * 1.0;
+      if (qb[2] >= 0) q2 = (double)lo + qb[2] * 1.0;
+    }
+    if (threadIdx.x == 0) {
+      M.body_flags = flags; M.body_min = lo; M.body_max = hi; M.body_s1 = (double)s1; M.body_s2 = (double)s2;
+      M.body_q[0] = q0; M.body_q[1] = q1; M.body_q[2] = q2;
+    }
+    return;
+  }
   // eight independent loads per thread and round: one after the other, each waiting for memory, the 200 000 values of a large
   // candidate took 120 us through this one workgroup
   for (int q0 = threadIdx.x; q0 < width; q0 += 8 * kTestThreads) {
