@@ -669,6 +669,7 @@ __device__ inline int cand_value(const CandJob& J, const CandGeom& g, const Cand
   return j < g.used0 ? b.left[J.top + 1 - g.used0 + j] : b.right[j - g.used0];
 }
 __device__ inline int cand_chunk_len(int n) { return (((n + kCandChunks - 1) / kCandChunks) + 3) & ~3; }
+constexpr int kCandP32MaxChunk = 16000000;   // 255 x this many bytes still fit 32 bits: chunk-local prefixes of byte depth are kept as uint32
 
 // launch 1: grid (2, njobs) -- the left and the right walk of every test side by side
 template <typename TD>
@@ -724,7 +725,11 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     const int cb = blockIdx.x * Lc;
     int ce = cb + Lc; if (ce > g.nref) ce = g.nref;
     long long carry = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.P[0] = 0;
+    // byte depth: a chunk's local prefix stays below 2^24 (62 500 values of at most 255), so it is kept in 32 bits -- half the bytes
+    // this launch writes and the next one reads (the prefixes were most of the split form's memory traffic)
+    uint32_t* const P32 = reinterpret_cast<uint32_t*>(b.P);
+    const bool p32 = sizeof(TD) == 1 && Lc <= kCandP32MaxChunk;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (p32) P32[0] = 0u; else b.P[0] = 0; }
     // sixteen consecutive values per thread and round (sixteen independent loads, ONE block scan): with four per round the
     // chunk's 62 000 values took sixteen rounds of barriers
     constexpr int kPer = 16;
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
       long long total;
       long long at = carry + block_exscan_i64(run, s_l, &total);
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) { at += v[k]; if (e + k < ce) b.P[e + k + 1] = at; }
+      for (int k = 0; k < kPer; ++k) { at += v[k]; if (e + k < ce) { if (p32) P32[e + k + 1] = (uint32_t)at; else b.P[e + k + 1] = at; } }
       carry += total;
     }
     if (threadIdx.x == 0) M.totals[blockIdx.x] = carry;
@@ -847,7 +852,8 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
 
 // launch 3: grid (kCandChunks, njobs) -- float window means of a chunk of windows, their extremes and moments
 __global__ __launch_bounds__(kTestThreads) void k_cand_means(const CandJob* __restrict__ jobs, int32_t* __restrict__ iscratch,
-                                                         long long* __restrict__ lscratch, CandMid* __restrict__ mid) {
+                                                         long long* __restrict__ lscratch, CandMid* __restrict__ mid,
+                                                         int p32 /* the chunk-local prefixes are 32-bit (byte depth, k_cand_prefix) */) {
   __shared__ long long s_off[kCandChunks];
   __shared__ double s_d[kMaxWaves];
   __shared__ float s_f[kMaxWaves];
@@ -859,7 +865,9 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_means(const CandJob* __re
   if (threadIdx.x == 0) { long long o = 0; for (int c = 0; c < kCandChunks; ++c) { s_off[c] = o; o += M.totals[c]; } }
   __syncthreads();
   const int Lc = cand_chunk_len(g.nref);
-  auto P_at = [&](int x) -> long long { return x == 0 ? 0ll : s_off[(x - 1) / Lc] + b.P[x]; };
+  const uint32_t* const P32 = reinterpret_cast<const uint32_t*>(b.P);
+  const bool use32 = p32 != 0 && Lc <= kCandP32MaxChunk;
+  auto P_at = [&](int x) -> long long { return x == 0 ? 0ll : s_off[(x - 1) / Lc] + (use32 ? (long long)P32[x] : b.P[x]); };
   const int Wc = cand_chunk_len(g.nwin);
   const int wb = blockIdx.x * Wc;
   int we = wb + Wc; if (we > g.nwin) we = g.nwin;
@@ -1006,7 +1014,7 @@ void launch_candidate_test_split(DepthRef d, int64_t ncompact, const CandJob* jo
   RSI_DEPTH_DISPATCH(d,
     RSI_LAUNCH(k_cand_prefix<int32_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid),
     RSI_LAUNCH(k_cand_prefix<uint8_t>, dim3(kCandChunks + 1, njobs), dim3(kTestThreads), lds, stream, rdc, jobs, iscratch, lscratch, mid));
-  RSI_LAUNCH(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid);
+  RSI_LAUNCH(k_cand_means, dim3(kCandChunks, njobs), dim3(kTestThreads), 0, stream, jobs, iscratch, lscratch, mid, d.bytes == 1 ? 1 : 0);
   RSI_LAUNCH(k_cand_hist, dim3(kCandChunks, njobs), dim3(kTestThreads), lds, stream, jobs, iscratch, lscratch, mid, ghist, outs);
 }
 size_t sharpen_workspace_bytes(int njobs) { return sharpen_zero_bytes(njobs) + (size_t)njobs * 2 * kEdgeChunks * (8 + 8 + 4); }
