@@ -736,8 +736,16 @@ __global__ __launch_bounds__(kTestThreads) void k_cand_prefix(const TD* __restri
     for (int t0 = cb; t0 < ce; t0 += kPer * kTestThreads) {
       const int e = t0 + kPer * (int)threadIdx.x;
       int v[kPer];
+      if (!g.thin && e + kPer <= ce && (e + kPer <= g.used0 || e >= g.used0)) {
+        // sixteen consecutive values from one side of the neighbourhood: four 16-byte loads (a 4-byte load per value makes the
+        // 64 lanes of every load touch 64 cache lines, sixteen times over)
+        const int32_t* src = e < g.used0 ? b.left + (J.top + 1 - g.used0 + e) : b.right + (e - g.used0);
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) v[k] = e + k < ce ? cand_value(J, g, b, e + k) : 0;
+        for (int q = 0; q < 4; ++q) { const WalkInts4 w4 = *reinterpret_cast<const WalkInts4*>(src + 4 * q); v[4 * q] = w4.x; v[4 * q + 1] = w4.y; v[4 * q + 2] = w4.z; v[4 * q + 3] = w4.w; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = e + k < ce ? cand_value(J, g, b, e + k) : 0;
+      }
       long long run = 0;
 #pragma unroll
       for (int k = 0; k < kPer; ++k) run += v[k];
