@@ -9,6 +9,7 @@
 #include <algorithm>
 #include "kernels.h"
 #include "device_util.h"
+#include "per_base_device.h"
 
 namespace rsik {
 
@@ -25,26 +26,6 @@ constexpr int kK4GcWords = 128;             // staged GC words of a K4j tile: (6
 constexpr int kK3Width = 512, kK3PhaseShift = 4, kK3Phases = 1 << kK3PhaseShift;   // K3': its LDS value histogram is [512 values][16 lane phases]
 constexpr int kValLds = 256;               // K3 / K3': values below this are counted in LDS, [value][32 lane phases]
 
-__device__ inline int lane_id() { return threadIdx.x & 63; }
-__device__ inline bool has_escape(uint32_t w) {   // any byte of w equal to 0xff
-  const uint32_t x = ~w;                          // a zero byte of x
-  return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
-}
-
-
-// Sum over the 2, 4, 8 or 16 consecutive lanes that share a bin (the median phases of K4' / K4j): neighbours at distance 1 and 2
-// through DPP quad permutes -- one VALU instruction each -- instead of ds_bpermute, which goes through the LDS pipeline and whose
-// latency sat seven times two deep in every bin's bisection.
-__device__ inline int dpp_xor1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }   // quad_perm [1, 0, 3, 2]
-__device__ inline int dpp_xor2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); }   // quad_perm [2, 3, 0, 1]
-__device__ inline int parts_sum(int x, int parts) {
-  x += dpp_xor1(x);
-  if (parts > 2) x += dpp_xor2(x);
-  for (int d = 4; d < parts; d <<= 1) x += __shfl_xor(x, d);
-  return x;
-}
-__device__ inline uint64_t dpp_xor1_u64(uint64_t x) { return (uint64_t)(uint32_t)dpp_xor1((int)(uint32_t)x) | ((uint64_t)(uint32_t)dpp_xor1((int)(uint32_t)(x >> 32)) << 32); }
-__device__ inline uint64_t dpp_xor2_u64(uint64_t x) { return (uint64_t)(uint32_t)dpp_xor2((int)(uint32_t)x) | ((uint64_t)(uint32_t)dpp_xor2((int)(uint32_t)(x >> 32)) << 32); }
 
 // ------------------------------------------------------------------------------------------
 // K1  fasta_classify: one thread per 16 bytes; 4 neighbouring lanes assemble one 64-bit word.
@@ -335,21 +316,6 @@ __device__ inline uint32_t wgc_field16(const WaveGc& t, uint32_t rel) {
   return (uint32_t)v & 0xffffu;
 }
 
-// the same two queries on a plain array of staged words (a workgroup's tile in K4j)
-__device__ inline uint32_t gcw_window(const uint64_t* __restrict__ word, uint32_t rel) {
-  const uint32_t k = rel >> 6, b = rel & 63;
-  const uint64_t w0 = word[k], w1 = word[k + 1], w2 = word[k + 2], w3 = word[k + 3], w4 = word[k + 4];
-  const uint32_t rem = 9 + b;
-  const uint64_t m3 = rem >= 64 ? ~0ull : ((1ull << rem) - 1);
-  const uint64_t m4 = rem > 64 ? ((1ull << (rem - 64)) - 1) : 0ull;
-  return (uint32_t)(__popcll(w0 >> b) + __popcll(w1) + __popcll(w2) + __popcll(w3 & m3) + __popcll(w4 & m4));
-}
-__device__ inline uint32_t gcw_field16(const uint64_t* __restrict__ word, uint32_t rel) {
-  const uint32_t k = rel >> 6, b = rel & 63;
-  uint64_t v = word[k] >> b;
-  if (b > 48) v |= word[k + 1] << (64 - b);
-  return (uint32_t)v & 0xffffu;
-}
 
 struct SubRegs { int4 q[4]; uint64_t gw; };
 
@@ -765,7 +731,6 @@ static_assert(kJPacked % 32 == 0 && kJBitWords <= 28 && kJSlabStride % 4 == 0, "
 constexpr int kJTotH = kGcLevels * 256;
 constexpr int kJTotWords = kJTotH + (kJSlabWords - kJPacked);
 constexpr int kJRh = 8192;                                       // rescaled values the tail counts in LDS (beyond: global atomics)
-constexpr int kFixShift = 22;                                    // fraction bits of K4j's fixed-point ratios
 constexpr double kFixMaxRatio = 3.99;                            // R = ratio * 2^22 stays below 2^24
 constexpr int kJEscPerWg = 63;                                   // escapes a workgroup lists by position (entry 0 of its list: their number)
 
@@ -1226,7 +1191,8 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   for (int g = threadIdx.x; g < kGcLevels; g += kJThreads) {
     const double ratio = rdmean / r_tab[g];
     const bool wide = !(ratio < kFixMaxRatio);
-    rtab[g] = (wide ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5)) | ((r_bad[g] || wide || r_cnt[g] == 0) ? 0x80000000u : 0u);
+    // bit 31: no verified ratio (take the exact expression); bit 30: the level does not occur at all (K4s: nothing to look out for)
+    rtab[g] = (wide ? 0u : (unsigned int)(ratio * (double)(1u << kFixShift) + 0.5)) | ((r_bad[g] || wide || r_cnt[g] == 0) ? 0x80000000u : 0u) | (r_cnt[g] == 0 ? 0x40000000u : 0u);
   }
   {
     if (threadIdx.x < kGcLevels && pz) atomicAdd(&r_hist[0], pz);   // (int)(0 * ratio + 0.5) = 0
@@ -1491,21 +1457,6 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, vb, width, phsh);
 }
 
-// The GC rescale without a division -- or any double arithmetic -- per base (f64 runs at half rate on gfx950, its
-// conversions at a quarter).  The reference's expression is (int)((double)d * rdmean / table[g] + 0.5) (gccontent.cpp:89:
-// product, IEEE division, truncation).  With ratio = (float)(rdmean / table[g]), f = fma((float)d, ratio, 0.5f) is within
-// 2^-23 (t + 0.5) of the reference's t + 0.5 (one rounding in the ratio, one in the fma; d < 2^24 is exact), so
-// floor(f) equals the reference's result unless f lies within tol = 2.5e-7 f + 1e-6 (twice that bound) of an integer.
-// Those bases raise `unsure` and the caller redoes them with the reference's own double expression: the result is the
-// reference's in every case; only one base in ten thousand takes the slow way.
-__device__ inline float rescale_f32(float d, float ratio, bool& unsure) {
-  const float f = __fmaf_rn(d, ratio, 0.5f);
-  const float fl = floorf(f);
-  const float fr = f - fl;
-  const float tol = __fmaf_rn(f, 2.5e-7f, 1.0e-6f);
-  unsure |= fabsf(fr - 0.5f) > 0.5f - tol;
-  return fl;
-}
 
 // ------------------------------------------------------------------------------------------
 // K3'  value histogram of the rescaled depth from the byte copy: wave-autonomous like K2 (sub-tiles of 1024 bases, 16
@@ -1660,14 +1611,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_value_hist8(const uint8_t* __re
 // Per value: cap, LDS store, one LDS atomic into the [value][MAD residue class] histogram.
 // Sum / sum of squares / median of the chromosome are all derived from that histogram on the host.
 struct __attribute__((packed, aligned(4))) Quad4 { int x, y, z, w; };   // 16 bytes, dword-aligned
-constexpr int kRegLds = 128;   // removed regions mirrored in LDS (the list is short; more stay in HBM; 128: K4j keeps four workgroups per CU with its 24 KB histogram)
-
-struct RegionTable {
-  const int64_t* cbreak; const int64_t* cum; int nreg;
-  int64_t* s_break; int64_t* s_cum;   // LDS mirror of the first kRegLds entries (+1 for cum)
-  __device__ int64_t brk(int k) const { return k < kRegLds ? s_break[k] : cbreak[k]; }
-  __device__ int64_t shift(int k) const { return k <= kRegLds ? s_cum[k] : cum[k]; }
-};
 
 // rare path (values outside the LDS range, partial quads): kept out of line
 __device__ __attribute__((noinline)) void hist_value(unsigned int* s_hist, uint32_t* __restrict__ res_hist, BinAccum* acc, int vr, int vb, int x, int cls, int pack16) {
@@ -1940,25 +1883,6 @@ __global__ __launch_bounds__(kThreads, (MAXV <= 8 ? 3 : 1)) void k_cap_compact_b
 // (ds_write_b128, conflict-free) and the per-bin median phase works on them four to a register.  Tiles that touch the
 // chromosome's ends (clamped windows, App. A Q1; the tail quirks of the 20-slice write-back, Q2/Q3) or are cut by a removed
 // region take a per-element path that recomputes the rescale from the int32 array.
-// #GC in [lo, lo + 201) straight from the mask in HBM (per-element path only)
-__device__ inline int gc_count201(const uint64_t* __restrict__ gcbits, int64_t lo) {
-  int c = 0;
-  int64_t p = lo;
-  const int64_t end = lo + 201;
-  while (p < end) {
-    const int64_t w = p >> 6;
-    const int b = (int)(p & 63);
-    int take = 64 - b;
-    if (p + take > end) take = (int)(end - p);
-    uint64_t x = gcbits[w] >> b;
-    if (take < 64) x &= (1ull << take) - 1;
-    c += __popcll(x);
-    p += take;
-  }
-  return c;
-}
-
-struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t x, y, z, w; };   // 16 bytes at any byte address (gfx950 loads them in one go)
 
 template <int MAXC, int EPT, bool SW7>
 __global__ __launch_bounds__(kThreads, 4) void k_cap_compact_bin8(

@@ -933,6 +933,9 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // launches the ordinary way whenever anything differs.  RSI_HOT_SPEC=0 switches it off.
   const char* spec_env = getenv("RSI_HOT_SPEC");
   const bool k4j_fix_off = getenv("RSI_HOT_K4J_FIX") && atoi(getenv("RSI_HOT_K4J_FIX")) == 0;   // the queued K4j always takes K2j's ratios
+  // K4 as three launches (kernels_k4s.hip: streaming half at eight waves per SIMD, the odd chunks exactly, the bin medians without
+  // LDS) wherever K2j's verified ratios exist; RSI_HOT_K4SPLIT=0: K4j, the one-kernel form
+  const bool k4_split = !(getenv("RSI_HOT_K4SPLIT") && atoi(getenv("RSI_HOT_K4SPLIT")) == 0);
   const bool spec = joint && !(spec_env && atoi(spec_env) == 0) && !k4j_fix_off && ctx->spec_capval >= 1 && ctx->spec_m == P.m && ctx->spec_cap == (double)P.cap &&
                     cap_compact8_applies(P.m, ctx->spec_capval);
   constexpr uint32_t kSpecMagic = 0x5bec5bec;
@@ -946,13 +949,21 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     spec_slot = static_cast<uint32_t*>(mb_alloc(ctx, spec_bytes));
     if (!spec_slot) return RSI_OK;   // no room in the mailbox: the ordinary way
     spec_slot[3] = kSpecMagic;       // BinAccum::pad: the kernel's export overwrites it with zero; still there = the kernel declined
-    HIPCHK(ctx->slabs.ensure(std::max(gc_joint_slab_bytes(n), cap_compact8_slab_bytes(P.m, guess, n))));
-    HIPCHK(ctx->rdc8.ensure((size_t)n + 64));
+    HIPCHK(ctx->slabs.ensure(std::max(gc_joint_slab_bytes(n), std::max(cap_compact8_slab_bytes(P.m, guess, n), rescale_compact_split_slab_bytes(guess, n)))));
+    HIPCHK(ctx->rdc8.ensure(rescale_compact_split_rdc_bytes(n)));
     HIPCHK(ctx->binmed.ensure((size_t)(n / P.m + 1) * 4));
     HIPCHK(ctx->binsum.ensure((size_t)(n / P.m + 1) * 8));
     K4Regions none;
     memset(&none, 0, sizeof(none));
     Timer t(ctx, "cap_compact_bin", true);
+    if (k4_split && rescale_compact_split_applies(P.m, guess, n, 0)) {
+      launch_rescale_compact_split(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
+                                   ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(),
+                                   reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p, d_done + 2 * kDoneStride,
+                                   ctx->hist_res.p, spec_slot, spec_bytes, reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off),
+                                   &d_acc->escapes, d_pp, st);
+      return RSI_OK;
+    }
     launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
                                 ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(),
                                 reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p, ctx->gsum.p, d_done + 2 * kDoneStride,
@@ -988,7 +999,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   };
   // the slab buffer serves K2 and K3 one after the other: size it for both before anything is in flight
   if (P.gcadjust) HIPCHK(ctx->slabs.ensure(std::max(std::max(gc_hist_slab_bytes(n), joint ? gc_joint_slab_bytes(n) : 0), std::max(gc_rescale_slab_bytes(n), value_hist8_slab_bytes(n)))));
-  if (spec) HIPCHK(ctx->slabs.ensure(std::max(gc_joint_slab_bytes(n), cap_compact8_slab_bytes(P.m, ctx->spec_capval, n))));   // before anything is in flight
+  if (spec) HIPCHK(ctx->slabs.ensure(std::max(gc_joint_slab_bytes(n), std::max(cap_compact8_slab_bytes(P.m, ctx->spec_capval, n), rescale_compact_split_slab_bytes(ctx->spec_capval, n)))));   // before anything is in flight
   int rc = joint ? issue_joint() : issue_gc_chain(1);
   if (rc != RSI_OK) return rc;
   if (spec && (rc = issue_k4j_spec()) != RSI_OK) return rc;
@@ -1167,8 +1178,19 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     const bool k4j_fix = joint_ok && !k4j_fix_off;
     const bool k4j = joint_ok || !(joint_env && atoi(joint_env) == 0);
     if (k4j && !k4j_fix) ctx->phases.push_back({"k4j.float rescale", 1.0});
+    const bool split = k4j && k4j_fix && k4_split && rescale_compact_split_applies(P.m, capval, ncompact, (int)noncode.size());
+    if (split) {
+      HIPCHK(ctx->slabs.ensure(rescale_compact_split_slab_bytes(capval, ncompact)));
+      HIPCHK(ctx->rdc8.ensure(rescale_compact_split_rdc_bytes(ncompact)));
+      ctx->phases.push_back({"k4.split", 1.0});
+    }
     Timer t(ctx, "cap_compact_bin", true);
-    if (k4j)   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
+    if (split)   // K4s + K4m
+      launch_rescale_compact_split(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+                                   ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
+                                   d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0,
+                                   reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off), &d_acc->escapes, nullptr, st);
+    else if (k4j)   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
       launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                                   ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                                   ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0,
@@ -1586,6 +1608,12 @@ int64_t rsi_hot_fetch_i32(rsi_ctx* ctx, const char* name, int32_t* out, int64_t 
   else if (s == "status1") { src = ctx->status1.p; cnt = ctx->nb; }
   else if (s == "status1f") { src = ctx->status1f.p; cnt = ctx->nb; }
   else if (s == "status2") { src = ctx->status2.p; cnt = ctx->nb; }
+  // diagnostics of the last run's per-base phase: K2j's fixed-point ratios per GC level (bit 31: not verified, bit 30: the level
+  // does not occur)
+  else if (s == "k4_ratios" && ctx->joint_tot.p) {
+    const size_t list_off = (gc_joint_totals_bytes() + 255) & ~size_t(255), lut_off = list_off + ((gc_joint_esc_list_bytes() + 255) & ~size_t(255));
+    src = ctx->joint_tot.as<uint8_t>() + lut_off; cnt = kGcLevels;
+  }
   if (!src) return fail(ctx, RSI_ERR_BAD_ARG, "unknown or unavailable array: " + s);
   if (out) {
     const int64_t k = std::min(cnt, cap);

@@ -320,7 +320,7 @@ constexpr size_t kOffValMedian = 5184;                            // ValueMedian
 constexpr size_t kOffDone = 5376;                                 // arrival counters of the in-kernel folds: kDoneStride uint32 per kernel
 constexpr size_t kDoneStride = 48;                                // >= kFoldGroups + 1
 constexpr size_t kDoneBinSlot = 4 * kDoneStride;                     // the bin-level kernels' counters: K4's slot (2) is two strides wide (kFoldGroupsAdd + 1 counters)
-static_assert(kOffDone + (kDoneBinSlot + 16) * 4 <= 6400 && kDoneStride >= 32 + 1 && 2 * kDoneStride >= 64 + 1, "arrival counters inside the header (device_util.h: kFoldGroups, kFoldGroupsAdd)");
+static_assert(kOffDone + (kDoneBinSlot + 16) * 4 <= 6400 && kDoneStride >= 32 + 1 && 2 * kDoneStride >= 64 + 2, "arrival counters inside the header (device_util.h: kFoldGroups, kFoldGroupsAdd)");
 constexpr size_t kHeaderBytes = 6400;                             // everything above: cleared by the first kernel of a run (K1), handed to the host as one block
 constexpr uint32_t kMaxTransitions = 1u << 16;
 constexpr size_t kOffNtrans = kHeaderBytes;                       // uint64[kMaxTransitions] N-run boundaries, right behind the header:

@@ -7,7 +7,9 @@ from rsicnv_amd import api, synth
 lib = api.load_library()
 torch.cuda.set_device(0)
 cases = []
-for cfg, chrom in ((3, 0), (4, 11), (5, 11)):
+sel = os.environ.get("PERBASE_CASES")   # e.g. "4:11" or "3:0,5:11": (config, chromosome index) pairs
+case_list = [tuple(int(x) for x in c.split(":")) for c in sel.split(",")] if sel else [(3, 0), (4, 11), (5, 11)]
+for cfg, chrom in case_list:
     p = synth.config_plan(cfg, chrom=chrom)
     d_fa = torch.empty(p["n"] + 64, dtype=torch.uint8, device="cuda"); d_rd = torch.empty(p["n"] + 16, dtype=torch.int32, device="cuda")
     synth.generate_device(lib, p, d_fa.data_ptr(), d_rd.data_ptr())
