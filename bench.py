@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
-    ap.add_argument("--workers", type=int, default=16, help="host threads / HIP streams per GPU (chromosomes in flight)")
+    ap.add_argument("--workers", type=int, default=0, help="host threads / HIP streams per GPU (chromosomes in flight); 0 = min(16, max(4, 2 x the "
+                    "host cores this rank may use)): sixteen on a box with eight cores and more per rank, fewer where eight ranks share sixteen cores")
     ap.add_argument("--inflight", type=int, default=0, help="steps (genomes) queued in the pool at once (rsi_pool_submit): the next genome's first "
                     "chromosomes run beside the last ones of the current genome.  0 = as many as keep the pool's workers busy with this rank's "
                     "share (2 for a whole genome, more for the few chromosomes of one rank among eight, at most 6); 1 = one genome at a time")
@@ -117,12 +118,10 @@ def main():
     # (one process per GPU, torch.distributed.run on 127.0.0.1), relays rank 0's line and exits with the launcher's code.  A
     # line with n_gpus != --gpus cannot come out of this file: a WORLD_SIZE that disagrees with --gpus is an error. ----
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher picks a free rendezvous port itself (binding one here and closing it again left a window in
+        # which somebody else could take it); --local-addr: the container's hostname may not resolve
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               os.path.abspath(__file__)] + sys.argv[1:]
         log("[bench] no launcher in the environment: starting", " ".join(cmd))
         raise SystemExit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,20 +145,33 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    # The host cores this rank may use: its share of the process's CPU set (RSI_BENCH_CPUS_PER_RANK=k: pretend the box grants k per
+    # rank -- the rehearsal of eight ranks on a sixteen-core host).  The pool's size follows it unless --workers says otherwise.
+    cores_per_rank = None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        cores_per_rank = max(1, len(allowed) // max(local_world, 1))
+        forced = int(os.environ.get("RSI_BENCH_CPUS_PER_RANK", "0"))
+        if forced > 0:
+            cores_per_rank = min(cores_per_rank, forced)
+    except (AttributeError, OSError):
+        allowed, forced = None, 0
+    if args.workers <= 0:
+        args.workers = 16 if cores_per_rank is None else min(16, max(4, 2 * cores_per_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
         # One slice of the allowed CPUs per rank (contiguous ids are normally one socket): a rank's dozen worker threads
         # and the runtime's helper threads then stay next to each other instead of wandering over both sockets.  Only
-        # when the slice is comfortably larger than the pool; RSI_BENCH_PIN=0 turns it off.
+        # when the slice is comfortably larger than the pool (or the slice was asked for); RSI_BENCH_PIN=0 turns it off.
         try:
-            allowed = sorted(os.sched_getaffinity(0))
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-            per = len(allowed) // max(local_world, 1)
-            if os.environ.get("RSI_BENCH_PIN", "1") != "0" and per >= args.workers + 4:
-                os.sched_setaffinity(0, set(allowed[cpu_slot * per:(cpu_slot + 1) * per]))
+            if allowed is not None and os.environ.get("RSI_BENCH_PIN", "1") != "0" and (forced > 0 or cores_per_rank >= args.workers + 4):
+                os.sched_setaffinity(0, set(allowed[cpu_slot * cores_per_rank:(cpu_slot + 1) * cores_per_rank]))
         except (AttributeError, OSError):
             pass
+    elif allowed is not None and forced > 0:
+        os.sched_setaffinity(0, set(allowed[:cores_per_rank]))
 
     lib = api.load_library()
     pool = api.RsiPool(local_rank, args.workers)
@@ -477,7 +489,8 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload_name(args), "chromosomes": len(plans), "genome_bases": genome_bases,
                        "bases_on_rank0": my_bases, "flags": flag_string(flags), "calls_per_genome": ncalls, "shard": args.shard,
-                       "parallelism": par, "steps_in_flight": max(1, args.inflight), "world_size": world,
+                       "parallelism": par, "steps_in_flight": max(1, args.inflight), "world_size": world, "workers": args.workers,
+                       "cores_per_rank": cores_per_rank,
                        "backend": (backend if world > 1 else "none (one rank)"), "rccl_version": rccl, "ranks": ranks_info},
             "one_genome_at_a_time": one_at_a_time,
             "roofline": roofline, "cpu_baseline": cpu,

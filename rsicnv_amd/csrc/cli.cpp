@@ -367,17 +367,27 @@ int main(int argc, char** argv) {
   // (each to the least loaded one), every device gets a pool whose workers take that device's chromosomes longest first;
   // nothing is exchanged between devices but the finished rows, which the main thread writes in header order. ----
   const int ndev = std::max(1, o.gpus), nwork = std::max(1, std::min(o.workers, 32));
+  // RSI_HOT_DEVICE_MAP=a,b,...: the HIP device behind logical device 0, 1, ... (default: -gpu, -gpu + 1, ...).  "0,0" runs the
+  // two-device code path on a box with one GPU: the partition, the per-device pools and the ordered writer are what is tested.
+  std::vector<int> devmap;
+  if (const char* dm = getenv("RSI_HOT_DEVICE_MAP")) {
+    std::stringstream ss(dm);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) if (!tok.empty()) devmap.push_back(atoi(tok.c_str()));
+  }
+  auto physical = [&](int d) { return d < (int)devmap.size() ? devmap[(size_t)d] : o.device + d; };
   std::vector<rsi_pool*> pools;
   for (int d = 0; d < ndev; ++d) {
     int st = 0;
-    rsi_pool* pl = rsi_pool_create(o.device + d, nwork, &st);
+    rsi_pool* pl = rsi_pool_create(physical(d), nwork, &st);
     if (!pl) {
       if (d == 0) { std::cerr << "rsicnv: " << rsi_hot_last_error(nullptr) << std::endl; return 1; }
-      std::cerr << "rsicnv: device " << o.device + d << " not available, using " << d << " device(s)" << std::endl;
+      std::cerr << "rsicnv: device " << physical(d) << " not available, using " << d << " device(s)" << std::endl;
       break;
     }
     pools.push_back(pl);
   }
+  std::cerr << "rsicnv: " << todo.size() << " chromosomes over " << pools.size() << " device(s), " << nwork << " in flight each" << std::endl;
   std::vector<std::vector<int>> per_dev(pools.size());
   {
     std::vector<int> order(todo.size());

@@ -1336,10 +1336,13 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     // against the stream -- it goes to a stream of its own and runs beside the transform, the quantile chains and the scan
     // instead of in front of them (a blit of 30 - 170 us at the head of a lone chromosome's chain).  Joined before the block
     // tests, and at the latest when this run ends (CopyJoin): the next run's K4 writes the same array.
+    // (the guard exists before the copy is queued, and the copy counts as pending from the moment it is: every return joins it;
+    // the join is a wait with a deadline that poisons the context like any other, pipeline_internal.h: join_copy)
+    struct CopyJoin { rsi_ctx* c; ~CopyJoin() { (void)join_copy(c); } } copy_join{ctx};
     HIPCHK(hipMemcpyAsync(ctx->h_medint.p, ctx->binmed.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
-    HIPCHK(hipEventRecord(ctx->copy_ev, ctx->copy_stream));
     ctx->copy_pending = true;
-    struct CopyJoin { rsi_ctx* c; ~CopyJoin() { if (c->copy_pending) { c->copy_pending = false; (void)hipEventSynchronize(c->copy_ev); } } } copy_join{ctx};
+    HIPCHK(hipEventRecord(ctx->copy_ev, ctx->copy_stream));
+    ctx->copy_recorded = true;
     in.binmedint = rsih::IntSpan(ctx->h_medint.as<int>(), nb);   // read in place, after join_copy()
 
     auto do_scan = [&](bool use_med, std::vector<Candidate>& segs) -> int {
@@ -1379,7 +1382,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
       segs = so.segs;
       {   // areblockscnv, rsi.cpp:1847: on the bin medians; a scan with many segments sends its first round to the device as one batch
         Phase ph(ctx, "a15.blocks");
-        if (ctx->copy_pending) { ctx->copy_pending = false; HIPCHK(hipEventSynchronize(ctx->copy_ev)); }   // the host copy of the bin medians
+        HIPCHK(join_copy(ctx));   // the host copy of the bin medians
         const char* bb_env = getenv("RSI_HOT_BLOCK_BATCH");   // 0: every block test on the host
         DeviceTester block_tester(ctx, DepthRef{ctx->binmed.p, 4}, nb, RDmedian);
         rsih::CallProfile bprof;

@@ -131,7 +131,7 @@ struct rsi_ctx {
   hipEvent_t sync_ev = nullptr;   // event every wait on the stream polls (stream_wait)
   hipStream_t copy_stream = nullptr;   // the bin medians' copy to the host (block tests) runs beside the transform and scan kernels
   hipEvent_t copy_ev = nullptr;
-  bool copy_pending = false;
+  bool copy_pending = false, copy_recorded = false;   // a copy is queued on copy_stream / copy_ev was recorded behind it
   std::string err;
   int timing = 0;   // 0 off, 1 HIP events around every launch, 2 around the per-base kernels only, 3 around the kernel named timing_kernel only
   std::string timing_kernel = "cap_compact_bin";
@@ -209,11 +209,10 @@ constexpr double kStreamWaitDeadlineMs = 60000.0;
 // spin, then naps (sixteen workers spinning two thousand queries per wait kept twelve cores busy for nothing: the step is
 // the same with none, and a pool of 24 workers on a 16-core box went from 14 to 25 ms with them).  A lone chromosome's waits
 // are short and nobody else wants the core: spin.  RSI_HOT_SPIN overrides the count.
-inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev, bool busy_pool = false) {
-  hipError_t e = hipEventRecord(ev, stream);
-  if (e != hipSuccess) return e;
+inline hipError_t event_wait(hipEvent_t ev, bool busy_pool = false) {   // an event that has been recorded
   static const int spin_env = [] { const char* v = getenv("RSI_HOT_SPIN"); return v ? atoi(v) : -1; }();
   const int spins = spin_env >= 0 ? spin_env : (busy_pool ? 50 : 2000);
+  hipError_t e = hipSuccess;
   for (int spin = 0; spin < spins; ++spin) {
     e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
@@ -230,6 +229,10 @@ inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev, bool busy_pool 
   }
   if (slack_before > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack_before, 0UL, 0UL, 0UL);
   return e;
+}
+inline hipError_t stream_wait(hipStream_t stream, hipEvent_t ev, bool busy_pool = false) {
+  const hipError_t e = hipEventRecord(ev, stream);
+  return e != hipSuccess ? e : event_wait(ev, busy_pool);
 }
 
 // Small transfers go through a pinned mailbox.  A hipMemcpyAsync on pageable memory is staged by the
@@ -286,6 +289,17 @@ inline hipError_t ctx_sync(rsi_ctx* ctx) {
   if (e == hipSuccess && launch != hipSuccess) e = launch;
   if (e == hipSuccess) for (const rsi_ctx::Pending& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
   ctx->pending.clear();
+  return e;
+}
+// The bin medians' copy to the host runs on the device's shared copy stream (pipeline.hip, bin_level_stages).  Its join has the
+// deadline and the consequences of every other wait: a copy that does not come back within it poisons the context (the DMA may
+// still write h_medint).  A copy that was queued but whose event could not be recorded is waited for on the stream itself.
+inline hipError_t join_copy(rsi_ctx* ctx) {
+  if (!ctx->copy_pending) return hipSuccess;
+  ctx->copy_pending = false;
+  hipError_t e = ctx->copy_recorded ? event_wait(ctx->copy_ev, ctx->gate != nullptr && !ctx->gate->lonely()) : hipStreamSynchronize(ctx->copy_stream);
+  ctx->copy_recorded = false;
+  if (e == hipErrorLaunchTimeOut) ctx->poisoned = true;
   return e;
 }
 inline void mailbox_reset(rsi_ctx* ctx) { ctx->mb_used = 0; ctx->pending.clear(); }

@@ -4,6 +4,7 @@
 // submission order.
 #include "pipeline_internal.h"
 #include "run_queue.h"
+#include "retire.h"
 #include <memory>
 #include <thread>
 
@@ -50,16 +51,17 @@ struct rsi_pool {
   rsip::RunQueue<PoolRun> queue;                               // run_queue.h: runs in submission order, items claimed oldest run first
   std::mutex trace_mu;
   mutable std::mutex err_mu;                                   // `err`
-  std::atomic<int> healthy{0};                                 // workers whose context still takes runs
-  std::vector<char> parked;                                    // per worker: left the healthy count (its own thread / the helper's seat only)
+  rsip::RetirePolicy retire;                                   // retire.h: who stops claiming when contexts are poisoned
 
-  // A worker whose context has been poisoned (a wait gave up with kernels still queued) fails every run at once: left in the
-  // rotation it would claim and fail chromosome after chromosome faster than the healthy workers can take them.  It stops
-  // claiming instead -- unless it is the last one, which keeps claiming so that queued runs fail instead of waiting for ever.
+  // A worker whose context has been poisoned (a wait gave up with kernels still queued) fails every run at once: it stops
+  // claiming -- unless nobody with a thread of its own would be left to drain the queue (retire.h).  A retirement is the pool's
+  // error text until a run's own failure replaces it.
   bool retire_if_poisoned(size_t w) {
-    if (!workers[w]->poisoned) return false;
-    if (!parked[w]) { parked[w] = 1; healthy.fetch_sub(1); }
-    return healthy.load() > 0;
+    return retire.should_stop(w, workers[w]->poisoned, [this](size_t who) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      err = "pool worker " + std::to_string(who) + " retired: its context is unusable (an earlier wait gave up with kernels still queued)";
+      set_global_error(err);
+    });
   }
 
   void process(size_t w, PoolRun& R, int k) {
@@ -141,8 +143,7 @@ rsi_pool* rsi_pool_create(int device, int nworkers, int* status) {
     c->gate_shared = iso && iso[0] == '1';   // default off: bin-level kernels of other chromosomes overlap the per-base phase
     pool->workers.push_back(c);
   }
-  pool->healthy = (int)pool->workers.size();
-  pool->parked.assign(pool->workers.size(), 0);
+  pool->retire.reset(pool->workers.size());
   for (size_t w = 1; w < pool->workers.size(); ++w) pool->threads.emplace_back([pool, w] { pool->worker_loop(w); });
   if (status) *status = RSI_OK;
   return pool;

@@ -134,6 +134,14 @@ def test_cli_walks_all_chromosomes_of_a_bam(hotlib, tmp_path):
     assert open(out2).read().replace(out2, out) == text.replace(out2, out)
     log2 = open(out2 + ".log").read()
     assert [l for l in log2.splitlines() if l.startswith("#processing")] == [l for l in log.splitlines() if l.startswith("#processing")]
+    # -gpus 2 with both logical devices mapped to the one GPU of the box (RSI_HOT_DEVICE_MAP): the partition over devices, a pool
+    # per device and the ordered writer give the same file again
+    out3 = str(tmp_path / "all_two.txt")
+    r = subprocess.run([exe, "rsi", "-b", bam, "-f", fa, "-o", out3, "-np", "-gpus", "2", "-workers", "2"], capture_output=True, timeout=300,
+                       env=dict(os.environ, RSI_HOT_DEVICE_MAP="0,0"))
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert "over 2 device(s)" in r.stderr.decode()
+    assert open(out3).read().replace(out3, out) == text.replace(out3, out)
 
 
 @pytest.mark.gpu

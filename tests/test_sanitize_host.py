@@ -61,3 +61,20 @@ def test_pool_run_queue_under_tsan(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "queue_tsan")], capture_output=True, text=True, timeout=250)
     assert r.returncode == 0 and "queue harness ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
+
+
+@pytest.mark.timeout(300)
+def test_pool_retirement_policy_under_tsan(tmp_path):
+    """Who stops taking chromosomes when contexts are poisoned (rsicnv_amd/csrc/retire.h): with all but one threaded
+    worker poisoned and runs submitted but not waited for the queue drains; with every worker poisoned the last claiming thread
+    goes on; a pool of one keeps its only seat; nobody retires while nothing is poisoned."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run(["g++", "-fsanitize=thread", "-x", "c++", "-", "-o", str(tmp_path / "probe")], input=b"int main(){return 0;}",
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ cannot link the ThreadSanitizer runtime here")
+    r = subprocess.run(["make", "-f", "tests/sanitize/Makefile", "tests/sanitize/retire_tsan"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "retire_tsan")], capture_output=True, text=True, timeout=250)
+    assert r.returncode == 0 and "retire harness ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
