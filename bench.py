@@ -526,7 +526,7 @@ def side_measurements(lib, pool, dev, args):
     out = {"single_chromosome_configs": {}, "t_device_h2d": {}}
     pool.set_timing(0)
     hot = api.RsiHot(dev.index or 0)
-    host_case = None
+    host_case = host_case250 = None
     for cfg, label in ((2, "configs[1]: one 60 Mb chromosome, 30x Poisson"), (3, "configs[2]: one 250 Mb chromosome, 30x gamma-Poisson + GC")):
         sp = synth.config_plan(cfg)
         n = sp["n"]
@@ -563,6 +563,8 @@ def side_measurements(lib, pool, dev, args):
                                       "note": "rsi_hot_run: pinned host depth + FASTA -> results on the host, one context"}
         if cfg == 2:
             host_case = (fasta_np.copy(), depth_np.copy())
+        else:
+            host_case250 = (fasta_np.copy(), depth_np.copy())
         del h_rd, h_fa
     hot.close()
     # ---- the genome from pinned host memory through the pool (rsi_pool_run_host): every worker moves its chromosome over its
@@ -604,6 +606,31 @@ def side_measurements(lib, pool, dev, args):
                             "note": "rsicnv rsi -f REF -d RDFILE -c chrS on configs[1] (process start, FASTA, depth text parse, device path, output file)"}
     except Exception as e:   # a side measurement must not take the bench line down
         out["t_e2e"] = {"error": str(e)[:200]}
+    # ---- the same for configs[2]: 250 Mb, 2.9 GB of depth text (loaddata.cpp:473-539, rsi.cpp:2069-2259) ----
+    try:
+        import shutil
+        fasta_np, depth_np = host_case250
+        if shutil.disk_usage("/tmp").free < 6 * (1 << 30):
+            raise RuntimeError("less than 6 GB free under /tmp")
+        exe = os.path.join(ROOT, "rsicnv_amd", "bin", "rsicnv")
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            tw = time.perf_counter()
+            fa, rdf = synth.write_case_files(lib, fasta_np, depth_np, d)
+            tw = time.perf_counter() - tw
+            best, calls = None, 0
+            for _ in range(2):
+                t3 = time.perf_counter()
+                r = subprocess.run([exe, "rsi", "-f", fa, "-d", rdf, "-c", "chrS", "-o", os.path.join(d, "out.txt"), "-np"], capture_output=True, timeout=600)
+                dt3 = time.perf_counter() - t3
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+                best = dt3 if best is None else min(best, dt3)
+                calls = sum(1 for l in open(os.path.join(d, "out.txt")) if not l.startswith("#"))
+            out["t_e2e_250Mb"] = {"s": round(best, 3), "bases_per_s": round(depth_np.size / best, 1), "calls": calls, "text_bytes": os.path.getsize(rdf),
+                                  "files_written_in_s": round(tw, 1),
+                                  "note": "rsicnv rsi -f REF -d RDFILE -c chrS on configs[2] (process start, FASTA, depth text parse from the page cache, device path, output file)"}
+    except Exception as e:
+        out["t_e2e_250Mb"] = {"error": str(e)[:200]}
     return out
 
 
