@@ -58,8 +58,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per base of the per-base kernels
+# (K4 is two launches since round 5: `cap_compact_bin` = K4s, SURVEY's row P3 -- read 4 + 1, write 4 per base, + 12 per bin -- and
+# `bin_median` = K4m, which an ideally fused pipeline would not need: it is charged the byte per base it reads plus its 12 bytes per bin)
 ALGO_BYTES_PER_BASE = {"gc_hist": 5.0, "gc_joint_hist": 5.0, "value_hist8": 9.0, "gc_rescale": 9.0, "cap_compact_bin": 9.1,
-                       "fasta_classify": 1.0, "value_hist": 4.0}
+                       "fasta_classify": 1.0, "value_hist": 4.0, "bin_median": 1.12}
 WHOLE_PATH_BYTES_PER_BASE = {101: 23.7, 51: 24.3}   # SURVEY 8d, GC on
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz = 1.23e12 /s

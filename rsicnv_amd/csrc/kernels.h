@@ -200,17 +200,18 @@ void launch_rescale_compact_bin8(const uint8_t* depth8, const int32_t* depth, co
 // K4 as two launches (kernels_k4s.hip): K4s -- rescale, cap, compaction, byte store, residue-class histogram, wave-autonomous at
 // eight waves per SIMD, fixed point in the loop, the chunks it cannot do that way (region cuts, chromosome ends, escape bytes, GC
 // levels without a verified ratio) exactly behind it -- and K4m -- the bins' medians and sums from the bytes K4s leaves, no LDS.
-// Same arguments and results as launch_rescale_compact_bin8 with rtab (no gsum: the groups' sums are atomic adds) wherever
+// Together the arguments and results of launch_rescale_compact_bin8 with rtab (no gsum: the groups' sums are atomic adds) wherever
 // rescale_compact_split_applies(); slabs: rescale_compact_split_slab_bytes(); rdc8: rescale_compact_split_rdc_bytes() (padded to
 // whole sub-tiles); escapes: K2j's count of depths of 255 and more (GcAccum::escapes, device memory).
 int rescale_compact_split_applies(int m, int32_t capval, int64_t ncompact, int nreg);
 size_t rescale_compact_split_slab_bytes(int32_t capval, int64_t ncompact);
 size_t rescale_compact_split_rdc_bytes(int64_t ncompact);
-void launch_rescale_compact_split(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                                  const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
-                                  int m, uint8_t* rdc8, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs,
-                                  unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, const unsigned int* rtab,
-                                  const unsigned int* escapes, PhaseParams* pp, hipStream_t stream);
+void launch_rescale_compact_stream(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                                   const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                                   int m, uint8_t* rdc8, uint32_t* res_hist, void* slabs, unsigned int* counters, const void* exp_src, void* exp_dst,
+                                   size_t exp_bytes, const unsigned int* rtab, const unsigned int* escapes, PhaseParams* pp, hipStream_t stream);
+void launch_bin_median8(const uint8_t* rdc8, int64_t ncompact, int32_t capval, int m, int32_t* binmed, int64_t* binsum, const PhaseParams* pp,
+                        hipStream_t stream);
 
 // ---- K5: NB variance-stabilising transform (negative_binomial_transfer, rsi.cpp:1155-1185) ----
 // raw[b] = (float)(2 sqrt(r) log(sqrt(q) + sqrt(1+q))), q = (sum+0.25)/(m2*r-0.5); *rawmin_bits =

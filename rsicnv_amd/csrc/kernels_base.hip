@@ -806,7 +806,17 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     else negs = 1u;
   };
 
-  auto trip = [&](const SubRegs& cur, SubRegs& nxt, int64_t sub) {
+  // The streaming loop takes the INTERIOR sub-tiles (no window clamped at a chromosome end: all but the first and the last one
+  // or two); its body has no branch around a global load or store -- every wave makes the same number of trips, a trip without
+  // a sub-tile of its own repeats a harmless one with increments of zero and its byte copy sent to the array's padding -- so
+  // that the compiler's wait counts are exact: with the edge sub-tiles' per-element loop and a conditional request inside, every
+  // trip began by waiting for ALL memory operations in flight, the previous trip's store included (a memory round trip per trip
+  // in the open).  The edge sub-tiles follow behind the loop.
+  const int64_t first_in = 1;                                             // sub-tile 0 starts at base 0 < 101
+  int64_t end_in = (n - 101) / kSubBases;                                 // interior: base + 1023 <= n - 102  <=>  sub < (n - 101) / 1024
+  end_in = end_in < first_in ? first_in : end_in;
+  const int64_t pad8 = ((n + kSubBases - 1) / kSubBases) * kSubBases;     // the byte copy's padding: n + 2048 bytes are allocated
+  auto interior_trip = [&](const SubRegs& cur, int64_t sub, bool mine) {
     const int64_t base = sub * kSubBases;
     const int64_t first_bit = base - kGcLeft * 64;
     {
@@ -814,64 +824,85 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
       const uint64_t word = (lane < kSubLds && w >= 0 && w < nwords) ? cur.gw : 0;
       if (lane < kSubLds + 1) G.word[lane] = word;
     }
-    if (sub + stride < nsub) sub_request(nxt, depth, gcbits, nwords, (sub + stride) * kSubBases, n, lane);
     __builtin_amdgcn_wave_barrier();
     const int64_t i0 = base + 16 * (int64_t)lane;
-    const bool interior = base >= 101 && base + kSubBases - 1 <= n - 102;   // no edge clamping in this sub-tile
-    if (interior) {
-      const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
-      uint32_t cnt = wgc_window(G, rel);
-      const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
-      const int v[16] = {cur.q[0].x, cur.q[0].y, cur.q[0].z, cur.q[0].w, cur.q[1].x, cur.q[1].y, cur.q[1].z, cur.q[1].w,
-                         cur.q[2].x, cur.q[2].y, cur.q[2].z, cur.q[2].w, cur.q[3].x, cur.q[3].y, cur.q[3].z, cur.q[3].w};
-      unsigned bad = 0;
+    const uint32_t rel = (uint32_t)(i0 - 100 - first_bit);
+    uint32_t cnt = wgc_window(G, rel);
+    const uint32_t leave = wgc_field16(G, rel), enter = wgc_field16(G, rel + 201);
+    const int v[16] = {cur.q[0].x, cur.q[0].y, cur.q[0].z, cur.q[0].w, cur.q[1].x, cur.q[1].y, cur.q[1].z, cur.q[1].w,
+                       cur.q[2].x, cur.q[2].y, cur.q[2].z, cur.q[2].w, cur.q[3].x, cur.q[3].y, cur.q[3].z, cur.q[3].w};
+    unsigned bad = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) bad |= (unsigned)((unsigned)(v[j] - 1) >= 254u);
-      if (!bad) {   // the common case, straight-line: sixteen LDS atomics into [GC level][value pair]
+    for (int j = 0; j < 16; ++j) bad |= (unsigned)((unsigned)(v[j] - 1) >= 254u);
+    if (!bad) {   // the common case, straight-line: sixteen LDS atomics into [GC level][value pair]
+      const unsigned int one = mine ? 1u : 0u;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (!no_atomics) atomicAdd(cell(cnt, v[j]), 1u << ((v[j] & 1) << 4));
-          cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
-        }
-        nfast += 16;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if ((unsigned)(v[j] - 1) < 254u) { atomicAdd(cell(cnt, v[j]), 1u << ((v[j] & 1) << 4)); ++nfast; }
-          else odd_value(v[j], cnt, i0 + j);
-          cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
-        }
-      }
-      uint32_t w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = sat8(v[4 * k]) | (sat8(v[4 * k + 1]) << 8) | (sat8(v[4 * k + 2]) << 16) | (sat8(v[4 * k + 3]) << 24);
-      *reinterpret_cast<uint4*>(d8 + i0) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {          // edge sub-tiles: the reference's clamped windows (App. A Q1), whole quads only
       for (int j = 0; j < 16; ++j) {
-        const int64_t i = i0 + j;
-        if ((i & ~(int64_t)3) + 4 > n) break;
-        int64_t lo = i - 100;
-        if (lo < 0) lo = 0;
-        if (lo > n - 202) lo = n - 202;
-        const uint32_t g = wgc_window(G, (uint32_t)(lo - first_bit));
-        const int val = depth[i];
-        if ((unsigned)(val - 1) < 254u) { atomicAdd(cell(g, val), 1u << ((val & 1) << 4)); ++nfast; }
-        else odd_value(val, g, i);
-        d8[i] = (uint8_t)sat8(val);
+        if (!no_atomics) atomicAdd(cell(cnt, v[j]), one << ((v[j] & 1) << 4));
+        cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
+      }
+      nfast += mine ? 16u : 0u;
+    } else if (mine) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if ((unsigned)(v[j] - 1) < 254u) { atomicAdd(cell(cnt, v[j]), 1u << ((v[j] & 1) << 4)); ++nfast; }
+        else odd_value(v[j], cnt, i0 + j);
+        cnt = cnt - ((leave >> j) & 1u) + ((enter >> j) & 1u);
       }
     }
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = sat8(v[4 * k]) | (sat8(v[4 * k + 1]) << 8) | (sat8(v[4 * k + 2]) << 16) | (sat8(v[4 * k + 3]) << 24);
+    *reinterpret_cast<uint4*>(d8 + (mine ? i0 : pad8 + 16 * (int64_t)lane)) = make_uint4(w[0], w[1], w[2], w[3]);
     __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
   };
+  auto edge_subtile = [&](int64_t sub) {   // the reference's clamped windows (App. A Q1), whole quads only, straight from memory
+    const int64_t base = sub * kSubBases;
+    const int64_t first_bit = base - kGcLeft * 64;
+    {
+      const int64_t w = base / 64 - kGcLeft + lane;
+      if (lane < kSubLds + 1) G.word[lane] = (lane < kSubLds && w >= 0 && w < nwords) ? gcbits[w] : 0ull;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = base + 16 * (int64_t)lane;
+    for (int j = 0; j < 16; ++j) {
+      const int64_t i = i0 + j;
+      if ((i & ~(int64_t)3) + 4 > n) break;
+      int64_t lo = i - 100;
+      if (lo < 0) lo = 0;
+      if (lo > n - 202) lo = n - 202;
+      const uint32_t g = wgc_window(G, (uint32_t)(lo - first_bit));
+      const int val = depth[i];
+      if ((unsigned)(val - 1) < 254u) { atomicAdd(cell(g, val), 1u << ((val & 1) << 4)); ++nfast; }
+      else odd_value(val, g, i);
+      d8[i] = (uint8_t)sat8(val);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
 
-  SubRegs ra, rb;
-  int64_t sub = (int64_t)blockIdx.x * kJWaves + wave;
-  if (sub < nsub) sub_request(ra, depth, gcbits, nwords, sub * kSubBases, n, lane);
-  while (sub < nsub) {
-    trip(ra, rb, sub);
-    sub += stride;
-    if (sub >= nsub) break;
-    trip(rb, ra, sub);
-    sub += stride;
+  {
+    const int64_t gw = (int64_t)blockIdx.x * kJWaves + wave;                 // this wave's number among all
+    const int64_t nin = end_in - first_in;                                    // interior sub-tiles
+    int64_t ntrips = (nin + stride - 1) / stride;
+    ntrips += ntrips & 1;                                                     // two register sets used alternately: an even number of trips
+    const int64_t safe = nin > 0 ? first_in : 0;                              // what a trip without a sub-tile of its own repeats (sub-tile 0 if there is no interior one: n >= 4040, so its loads are in range)
+    auto sub_of = [&](int64_t t, bool& mine) { const int64_t sdx = first_in + gw + t * stride; mine = sdx < end_in; return mine ? sdx : safe; };
+    SubRegs ra, rb;
+    bool ma, mb;
+    int64_t sa = sub_of(0, ma), sb = 0;
+    sub_request(ra, depth, gcbits, nwords, sa * kSubBases, n, lane);
+    for (int64_t t = 0; t < ntrips; t += 2) {
+      sb = sub_of(t + 1, mb);
+      sub_request(rb, depth, gcbits, nwords, sb * kSubBases, n, lane);
+      interior_trip(ra, sa, ma && nin > 0);
+      sa = sub_of(t + 2, ma);
+      sub_request(ra, depth, gcbits, nwords, sa * kSubBases, n, lane);
+      interior_trip(rb, sb, mb && nin > 0);
+    }
+    // the edge sub-tiles: dealt round robin to the waves from the far end of the grid (the near end's waves carry the remainder
+    // of the interior ones)
+    const int64_t nedge = first_in + (nsub - end_in);
+    for (int64_t e = (stride - 1 - gw); e < nedge; e += stride) edge_subtile(e < first_in ? e : end_in + (e - first_in));
   }
   __syncthreads();
   // ---- did a 16-bit field wrap?  The fields must add up to what the lanes counted into them ----

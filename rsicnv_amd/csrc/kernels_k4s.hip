@@ -148,7 +148,9 @@ struct S4Lds {
   unsigned long long odd[kS4Waves][2 * kS4MaxTrips + 4];   // per wave, trip and kilobyte: the chunks (bit = lane) left to the exact pass behind the loop
   int64_t brk[kRegLds], cum[kRegLds + 1];
 };
-template <bool COLS64>
+// RAW: the bytes are final values already (the raw depth under -NOGC, K3''s rescaled bytes on the three-pass chain; saturated at 254 =
+// "this much or more", above any cap this kernel takes): no GC words, no windows, no ratios -- cap, compaction, histogram only.
+template <bool COLS64, bool RAW>
 __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
     const uint8_t* __restrict__ d8, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits, int64_t n, int64_t nwords,
     const double* __restrict__ table /* [kGcLevels] + rdmean */, const int64_t* __restrict__ cbreak, const int64_t* __restrict__ cum, int nreg,
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
     nreg = pp->nreg; ncompact = pp->ncompact; capval = pp->capval;
   }
   for (int e = threadIdx.x; e < vr * cols; e += kS4Threads) s_hist[e] = 0;
-  for (int e = threadIdx.x; e < kGcLevels; e += kS4Threads) L.rt[e] = rtab[e];
+  if (!RAW) for (int e = threadIdx.x; e < kGcLevels; e += kS4Threads) L.rt[e] = rtab[e];
   if (threadIdx.x < 8) L.badbits[threadIdx.x] = 0u;
   if (nreg <= kRegInline && !pp) {
     for (int e = threadIdx.x; e < nreg; e += kS4Threads) L.brk[e] = inl.brk[e];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
     for (int e = threadIdx.x; e <= kRegLds && e <= nreg; e += kS4Threads) L.cum[e] = cum[e];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kGcLevels; e += kS4Threads) {
+  if (!RAW) for (int e = threadIdx.x; e < kGcLevels; e += kS4Threads) {
     const unsigned int r = L.rt[e];
     if ((r >> 31) & ~(r >> 30) & 1u) atomicOr(&L.badbits[e >> 5], 1u << (e & 31));
   }
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
   struct { const int64_t* b; const int64_t* c; __device__ int64_t brk(int k) const { return b[k]; } __device__ int64_t shift(int k) const { return c[k]; } } R{L.brk, L.cum};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* const sgw = L.gw[wave];
-  const bool anybad = (L.badbits[0] | L.badbits[1] | L.badbits[2] | L.badbits[3] | L.badbits[4] | L.badbits[5] | L.badbits[6]) != 0u;
-  const bool anyesc = *escapes != 0u;
+  const bool anybad = !RAW && (L.badbits[0] | L.badbits[1] | L.badbits[2] | L.badbits[3] | L.badbits[4] | L.badbits[5] | L.badbits[6]) != 0u;
+  const bool anyesc = !RAW && *escapes != 0u;
 
   const int64_t lim31 = (ncompact / 31) * 31;
   const int64_t zone = n - 201;             // no fast sub-tile may reach this base (the tail quirks, the clamped windows i >= n-101)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
   // Every wave makes the same, even number of trips; lane t works out trip t's source offset once, before the loop (a search of
   // the region table per trip cost two hundred scalar instructions): the loop reads its three words with v_readlane.
   const int ntrips = (int)((nsub + stride - 1) / stride);   // <= kS4MaxTrips (the launcher checks)
-  int64_t g_soff = 128;   // lane t: trip t  (n >= 4040 under GC adjustment, gccontent.cpp:66: the first kilobyte and its mask words exist)
+  int64_t g_soff = RAW ? 0 : 128;   // lane t: trip t  (n >= 4040 under GC adjustment, gccontent.cpp:66: the first kilobytes and their mask words exist; RAW: the byte array is padded by 2048)
   {
     const int64_t s = sub0 + (int64_t)lane * stride;
     if (lane < ntrips && s < nsub) {
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.brk(mid) <= P0) lo = mid + 1; else hi = mid; }
       const bool plain = lo >= nreg || R.brk(lo) >= P1;
       const int64_t so = P0 + R.shift(lo);
-      if (plain && P1 <= lim31 && so >= 101 && so + kS4Sub <= zone) g_soff = so | ((int64_t)1 << 62);   // bit 62: fast
+      if (plain && P1 <= lim31 && (RAW ? so + kS4Sub <= n : (so >= 101 && so + kS4Sub <= zone))) g_soff = so | ((int64_t)1 << 62);   // bit 62: fast
     }
   }
   auto geometry = [&](int t, int64_t& soff, bool& fast) {   // t uniform; a trip behind the last: not fast
@@ -230,8 +232,10 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
     const Bytes16 b1 = *reinterpret_cast<const Bytes16*>(d8 + so + 1024 + 16 * (int64_t)lane);
     r.b0 = make_uint4(b0.x, b0.y, b0.z, b0.w);
     r.b1 = make_uint4(b1.x, b1.y, b1.z, b1.w);
-    const int64_t w = ((soff - 100) >> 6) + lane;
-    r.gw = gcbits[(lane < kS4GcWords && w < nwords) ? w : 0];
+    if (!RAW) {
+      const int64_t w = ((soff - 100) >> 6) + lane;
+      r.gw = gcbits[(lane < kS4GcWords && w < nwords) ? w : 0];
+    }
   };
   const uint32_t lane16 = (16u * (uint32_t)lane) % 31u;
   // sixteen mask bits from staged bit r on: two dwords and a funnel shift
@@ -244,35 +248,39 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
       *reinterpret_cast<uint4*>(rdc8 + s * kS4Sub + 1024 + 16 * (int64_t)lane) = make_uint4(cur.b1.x + (uint32_t)cur.gw, cur.b1.y, cur.b1.z, cur.b1.w);
       return;
     }
-    const int64_t gw0 = (soff - 100) >> 6;
-    const uint64_t myw = (gw0 + lane < nwords) ? cur.gw : 0ull;
-    if (lane < kS4GcWords) { sgw[2 * lane] = (uint32_t)myw; sgw[2 * lane + 1] = (uint32_t)(myw >> 32); }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t r0 = (uint32_t)(soff - 100 - (gw0 << 6));          // 0 .. 63, uniform
-    const uint32_t relA = r0 + 16u * (uint32_t)lane;                    // the lane's first window of A, in staged bits; B's: 1024 further
-    const uint32_t leaveA = field16(relA), enterA = field16(relA + 201), leaveB = field16(relA + 1024), enterB = field16(relA + 1225);
-    __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
-    // The lane's first window counts: the kilobyte's first plus what the lanes before it gained and lost -- ONE wave scan for both
-    // kilobytes (net + 16 in 16-bit fields: six DPP adds) instead of five 64-bit popcounts with masks per lane and kilobyte.
-    // A kilobyte's first window: its 201 bits lie in the words lanes 0 .. 4 (A) and 16 .. 20 (B) hold -- each counts its share
-    // (shift and mask chosen by lane, no branch), five lane reads add them up.
-    const int gainA = __popc(enterA), lossA = __popc(leaveA), gainB = __popc(enterB), lossB = __popc(leaveB);
-    const int biased = (gainA - lossA + 16) | ((gainB - lossB + 16) << 16);
-    const int excl = wave_incl_scan(biased) - biased;   // fields: the lanes' sums before this one, + 16 lane
-    uint32_t cfirstA, cfirstB;
-    {
-      const uint32_t rem = 9u + r0;                                       // bits of the window behind the first three words: 9 .. 72
-      const uint64_t m3 = rem >= 64u ? ~0ull : ((1ull << rem) - 1), m4 = rem > 64u ? ((1ull << (rem - 64u)) - 1) : 0ull;   // (scalar)
-      const int role = lane & 15;
-      const uint64_t mk = role == 3 ? m3 : (role == 4 ? m4 : ~0ull);
-      const int share = __popcll((myw >> (role == 0 ? r0 : 0u)) & mk);
-      cfirstA = (uint32_t)(__builtin_amdgcn_readlane(share, 0) + __builtin_amdgcn_readlane(share, 1) + __builtin_amdgcn_readlane(share, 2) +
-                           __builtin_amdgcn_readlane(share, 3) + __builtin_amdgcn_readlane(share, 4));
-      cfirstB = (uint32_t)(__builtin_amdgcn_readlane(share, 16) + __builtin_amdgcn_readlane(share, 17) + __builtin_amdgcn_readlane(share, 18) +
-                           __builtin_amdgcn_readlane(share, 19) + __builtin_amdgcn_readlane(share, 20));
+    uint32_t leaveA = 0, enterA = 0, leaveB = 0, enterB = 0, cntA = 0, cntB = 0;
+    int gainA = 0, lossA = 0, gainB = 0, lossB = 0;
+    if (!RAW) {
+      const int64_t gw0 = (soff - 100) >> 6;
+      const uint64_t myw = (gw0 + lane < nwords) ? cur.gw : 0ull;
+      if (lane < kS4GcWords) { sgw[2 * lane] = (uint32_t)myw; sgw[2 * lane + 1] = (uint32_t)(myw >> 32); }
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t r0 = (uint32_t)(soff - 100 - (gw0 << 6));          // 0 .. 63, uniform
+      const uint32_t relA = r0 + 16u * (uint32_t)lane;                    // the lane's first window of A, in staged bits; B's: 1024 further
+      leaveA = field16(relA); enterA = field16(relA + 201); leaveB = field16(relA + 1024); enterB = field16(relA + 1225);
+      __builtin_amdgcn_wave_barrier();   // the slot is rewritten by the next trip
+      // The lane's first window counts: the kilobyte's first plus what the lanes before it gained and lost -- ONE wave scan for both
+      // kilobytes (net + 16 in 16-bit fields: six DPP adds) instead of five 64-bit popcounts with masks per lane and kilobyte.
+      // A kilobyte's first window: its 201 bits lie in the words lanes 0 .. 4 (A) and 16 .. 20 (B) hold -- each counts its share
+      // (shift and mask chosen by lane, no branch), five lane reads add them up.
+      gainA = __popc(enterA); lossA = __popc(leaveA); gainB = __popc(enterB); lossB = __popc(leaveB);
+      const int biased = (gainA - lossA + 16) | ((gainB - lossB + 16) << 16);
+      const int excl = wave_incl_scan(biased) - biased;   // fields: the lanes' sums before this one, + 16 lane
+      uint32_t cfirstA, cfirstB;
+      {
+        const uint32_t rem = 9u + r0;                                       // bits of the window behind the first three words: 9 .. 72
+        const uint64_t m3 = rem >= 64u ? ~0ull : ((1ull << rem) - 1), m4 = rem > 64u ? ((1ull << (rem - 64u)) - 1) : 0ull;   // (scalar)
+        const int role = lane & 15;
+        const uint64_t mk = role == 3 ? m3 : (role == 4 ? m4 : ~0ull);
+        const int share = __popcll((myw >> (role == 0 ? r0 : 0u)) & mk);
+        cfirstA = (uint32_t)(__builtin_amdgcn_readlane(share, 0) + __builtin_amdgcn_readlane(share, 1) + __builtin_amdgcn_readlane(share, 2) +
+                             __builtin_amdgcn_readlane(share, 3) + __builtin_amdgcn_readlane(share, 4));
+        cfirstB = (uint32_t)(__builtin_amdgcn_readlane(share, 16) + __builtin_amdgcn_readlane(share, 17) + __builtin_amdgcn_readlane(share, 18) +
+                             __builtin_amdgcn_readlane(share, 19) + __builtin_amdgcn_readlane(share, 20));
+      }
+      cntA = cfirstA + ((uint32_t)excl & 0xffffu) - 16u * (uint32_t)lane;
+      cntB = cfirstB + ((uint32_t)excl >> 16) - 16u * (uint32_t)lane;
     }
-    const uint32_t cntA = cfirstA + ((uint32_t)excl & 0xffffu) - 16u * (uint32_t)lane;
-    const uint32_t cntB = cfirstB + ((uint32_t)excl >> 16) - 16u * (uint32_t)lane;
     // An escape byte (the value is in the int32 array), or a window count within reach of a level whose ratio did not verify
     // (the thinly populated levels next to N runs and soft-masked stretches, whose mean depth is a mix: ratios of 4 and more):
     // the lane's sixteen positions of that kilobyte are left to the exact pass.  So is every lane of a sub-tile that is not `fast`.
@@ -306,11 +314,11 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
     const uint32_t nlA = ~leaveA & 0xffffu, nlB = ~leaveB & 0xffffu;
     const uint32_t De = (oddA ? 0u : (enterA & 0x5555u) + (nlA & 0x5555u)) | ((oddB ? 0u : (enterB & 0x5555u) + (nlB & 0x5555u)) << 16);
     const uint32_t Do = (oddA ? 0u : ((enterA >> 1) & 0x5555u) + ((nlA >> 1) & 0x5555u)) | ((oddB ? 0u : ((enterB >> 1) & 0x5555u) + ((nlB >> 1) & 0x5555u)) << 16);
-    const unsigned int* rpA = L.rt + (oddA ? 100u : cntA) - 16;
-    const unsigned int* rpB = L.rt + (oddB ? 100u : cntB) - 16;
+    const unsigned int* rpA = L.rt + (oddA || RAW ? 100u : cntA) - 16;
+    const unsigned int* rpB = L.rt + (oddB || RAW ? 100u : cntB) - 16;
     // A's four quads, then B's; the ratios of the next quad are requested before the current one is worked on: one LDS round
     // trip per trip in the open instead of eight
-    unsigned int rq[4], rn[4];
+    unsigned int rq[4] = {0, 0, 0, 0}, rn[4] = {0, 0, 0, 0};
     auto fetch = [&](int qi, unsigned int (&r)[4]) {   // qi = 4 (B ? 1 : 0) + q
       const int q = qi & 3, hb = qi >> 2;
 #pragma unroll
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
         rp += __builtin_amdgcn_ubfe((j & 1) ? Do : De, 16 * hb + 2 * (j >> 1), 2);
       }
     };
-    fetch(0, rq);
+    if (!RAW) fetch(0, rq);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       uint32_t pk[4];
@@ -329,13 +337,13 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
       const unsigned int inc = hb ? incB : incA;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (4 * hb + q < 7) fetch(4 * hb + q + 1, rn);
+        if (!RAW && 4 * hb + q < 7) fetch(4 * hb + q + 1, rn);
         const uint32_t w = hb ? (q == 0 ? cur.b1.x : q == 1 ? cur.b1.y : q == 2 ? cur.b1.z : cur.b1.w) : (q == 0 ? cur.b0.x : q == 1 ? cur.b0.y : q == 2 ? cur.b0.z : cur.b0.w);
         int v[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           // (byte * R + 2^21) >> 22, R < 2^24: the multiply looks at R's low 24 bits only
-          const uint32_t x = (__umul24((w >> (8 * t)) & 0xffu, rq[t]) + (1u << (kFixShift - 1))) >> kFixShift;
+          const uint32_t x = RAW ? (w >> (8 * t)) & 0xffu : (__umul24((w >> (8 * t)) & 0xffu, rq[t]) + (1u << (kFixShift - 1))) >> kFixShift;
           v[t] = (int)(x > (uint32_t)capval ? (uint32_t)capval : x);
         }
         pk[q] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
@@ -349,8 +357,10 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
 #pragma unroll
           for (int t = 0; t < 4; ++t) atomicAdd((4 * q + t >= jw ? ha - 31 : ha) + v[t] * kResClasses + (4 * q + t), inc);
         }
+        if (!RAW) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) rq[t] = rn[t];
+          for (int t = 0; t < 4; ++t) rq[t] = rn[t];
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the quads apart: hoisting all the byte extractions costs a register each
       }
       // (a marked lane's bytes are garbage until the exact pass rewrites them; the array is padded to whole sub-tiles)
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
   __syncthreads();
   // ---- the exact pass: the workgroup's marked chunks, per element, with the reference's own expression ----
   {
-    const double rdmean = table[kGcLevels];
+    const double rdmean = RAW ? 0.0 : table[kGcLevels];
     // the 20-slice write-back's tail (App. A Q2/Q3): cells n-201 .. n-201+r-1 carry the rescaled depth of the last r bases,
     // computed with the fresh edge window [n-201, n-1]; the last r bases keep their raw depth
     const int64_t S20 = n / 20, r20 = n - 20 * S20;
@@ -400,8 +410,8 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
       int lo = 0, hi = nreg;   // regions with brk <= pc (upper bound)
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.brk(mid) <= pc) lo = mid + 1; else hi = mid; }
       const int64_t i = pc + R.shift(lo);   // source index; the value K3 + its tail fixup would have left there:
-      const bool quirk = r20 >= 2 && i >= n - 201 && i < n - 201 + r20;
-      E.raw = !quirk && i >= 20 * S20;
+      const bool quirk = !RAW && r20 >= 2 && i >= n - 201 && i < n - 201 + r20;
+      E.raw = RAW || (!quirk && i >= 20 * S20);
       E.d = depth[quirk ? 20 * S20 + (i - (n - 201)) : i];
       int64_t wl = i - 100;
       wl = wl < 0 ? 0 : wl;
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(kS4Threads, 6) void k_rescale_compact_stream(
       // #GC in [lo, lo + 201): the five words the window can touch, their loads independent of each other
       const int64_t k = E.lo >> 6;
       const int64_t k4 = k + 4 < nwords ? k + 4 : nwords - 1;   // (touched only when the window reaches it, and then it exists)
-      E.w[0] = gcbits[k]; E.w[1] = gcbits[k + 1]; E.w[2] = gcbits[k + 2]; E.w[3] = gcbits[k + 3]; E.w[4] = gcbits[k4];
+      if (!RAW) { E.w[0] = gcbits[k]; E.w[1] = gcbits[k + 1]; E.w[2] = gcbits[k + 2]; E.w[3] = gcbits[k + 3]; E.w[4] = gcbits[k4]; }
+      else { E.w[0] = E.w[1] = E.w[2] = E.w[3] = E.w[4] = 0; }
     };
     auto finish = [&](const Elem& E) {
       const uint32_t bsh = (uint32_t)(E.lo & 63);
@@ -612,27 +623,30 @@ size_t rescale_compact_split_slab_bytes(int32_t capval, int64_t ncompact) {
 }
 size_t rescale_compact_split_rdc_bytes(int64_t ncompact) { return (size_t)(((ncompact + kS4Sub - 1) / kS4Sub + 1) * kS4Sub + 64); }
 
-void launch_rescale_compact_split(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
-                                  const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
-                                  int m, uint8_t* rdc, int32_t* binmed, int64_t* binsum, uint32_t* res_hist, void* slabs,
-                                  unsigned int* counters, const void* exp_src, void* exp_dst, size_t exp_bytes, const unsigned int* rtab,
-                                  const unsigned int* escapes, PhaseParams* pp, hipStream_t stream) {
+void launch_rescale_compact_stream(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
+                                   const int64_t* cbreak, const int64_t* cum, const K4Regions& inl, int nreg, int64_t ncompact, int32_t capval,
+                                   int m, uint8_t* rdc, uint32_t* res_hist, void* slabs, unsigned int* counters, const void* exp_src, void* exp_dst,
+                                   size_t exp_bytes, const unsigned int* rtab, const unsigned int* escapes, PhaseParams* pp, hipStream_t stream) {
   const int vr = k4s_vr(capval);   // pp != NULL: capval is the caller's guess (it fixes vr and SW7), ncompact an upper bound
   const int grid = k4s_grid(ncompact);
   const size_t lds = (size_t)vr * (vr <= 128 ? kS4Cols : kResClasses) * 4;
   unsigned int* sl = static_cast<unsigned int*>(slabs);
   const int pg = fold_per_group_add(grid);
   const bool sw7 = capval <= 127;
-  if (vr <= 128) {
-    RSI_ALLOW_FULL_LDS(k_rescale_compact_stream<true>);
-    RSI_LAUNCH(k_rescale_compact_stream<true>, dim3(grid), dim3(kS4Threads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, cbreak, cum, nreg,
-               ncompact, capval, m, vr, sw7 ? 1 : 0, rdc, res_hist, sl, pg, counters, exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab, escapes, pp);
-  } else {
-    RSI_ALLOW_FULL_LDS(k_rescale_compact_stream<false>);
-    RSI_LAUNCH(k_rescale_compact_stream<false>, dim3(grid), dim3(kS4Threads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, cbreak, cum, nreg,
-               ncompact, capval, m, vr, sw7 ? 1 : 0, rdc, res_hist, sl, pg, counters, exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab, escapes, pp);
-  }
-  // the bins' medians and sums from the bytes the launch above leaves: PARTS lanes per bin, seven dwords each
+#define RSI_K4S(C64, RW) do { RSI_ALLOW_FULL_LDS((k_rescale_compact_stream<C64, RW>));                                                                   \
+    RSI_LAUNCH((k_rescale_compact_stream<C64, RW>), dim3(grid), dim3(kS4Threads), lds, stream, depth8, depth, gcbits, n, n / 64 + 1, table, cbreak, cum, \
+               nreg, ncompact, capval, m, vr, sw7 ? 1 : 0, rdc, res_hist, sl, pg, counters, exp_src, exp_dst, (unsigned int)exp_bytes, inl, rtab, escapes, pp); } while (0)
+  const bool rawmode = rtab == nullptr;   // the bytes are final values (the caller has no ratios to hand over: -NOGC, the three-pass chain)
+  if (vr <= 128) { if (rawmode) RSI_K4S(true, true); else RSI_K4S(true, false); }
+  else { if (rawmode) RSI_K4S(false, true); else RSI_K4S(false, false); }
+#undef RSI_K4S
+}
+
+// the bins' medians and sums from the bytes the launch above leaves: PARTS lanes per bin, seven dwords each
+void launch_bin_median8(const uint8_t* rdc, int64_t ncompact, int32_t capval, int m, int32_t* binmed, int64_t* binsum, const PhaseParams* pp,
+                        hipStream_t stream) {
+  const int vr = k4s_vr(capval);
+  const bool sw7 = capval <= 127;
   const int parts = m <= 52 ? 2 : (m <= 104 ? 4 : (m <= 216 ? 8 : 16));
   const int64_t nb = ncompact / m;
   const int64_t ntrips = (nb + 64 / parts - 1) / (64 / parts);

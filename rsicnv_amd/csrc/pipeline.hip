@@ -4,6 +4,7 @@
 // C ABI.  There is no CPU fallback anywhere in this file: every array-sized computation is a
 // kernel from kernels_base.hip / kernels_bin.hip / kernels_cand.hip; the host only walks
 // device-built histograms and runs the candidate list logic (host_calls.cpp).
+#include <new>
 #include "pipeline_internal.h"
 
 using namespace rsik;
@@ -957,11 +958,13 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     memset(&none, 0, sizeof(none));
     Timer t(ctx, "cap_compact_bin", true);
     if (k4_split && rescale_compact_split_applies(P.m, guess, n, 0)) {
-      launch_rescale_compact_split(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
-                                   ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(),
-                                   reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p, d_done + 2 * kDoneStride,
-                                   ctx->hist_res.p, spec_slot, spec_bytes, reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off),
-                                   &d_acc->escapes, d_pp, st);
+      launch_rescale_compact_stream(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
+                                    ctx->rdc8.as<uint8_t>(), reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p,
+                                    d_done + 2 * kDoneStride, ctx->hist_res.p, spec_slot, spec_bytes,
+                                    reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off), &d_acc->escapes, d_pp, st);
+      t.~Timer();   // (closes the streaming half's bracket: the medians have their own)
+      new (&t) Timer(ctx, "bin_median", true);
+      launch_bin_median8(ctx->rdc8.as<uint8_t>(), n, guess, P.m, ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_pp, st);
       return RSI_OK;
     }
     launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
@@ -1185,11 +1188,15 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       ctx->phases.push_back({"k4.split", 1.0});
     }
     Timer t(ctx, "cap_compact_bin", true);
-    if (split)   // K4s + K4m
-      launch_rescale_compact_split(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
-                                   ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
-                                   d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0,
-                                   reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off), &d_acc->escapes, nullptr, st);
+    if (split) {   // K4s, K4m
+      launch_rescale_compact_stream(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
+                                    ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), d_res, ctx->slabs.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot,
+                                    exp_slot ? exp_bytes : 0, reinterpret_cast<const unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off),
+                                    &d_acc->escapes, nullptr, st);
+      t.~Timer();   // (closes the streaming half's bracket: the medians have their own)
+      new (&t) Timer(ctx, "bin_median", true);
+      launch_bin_median8(ctx->rdc8.as<uint8_t>(), ncompact, capval, P.m, ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), nullptr, st);
+    }
     else if (k4j)   // K4j: from the byte copy of the RAW depth (K2 and K2j both leave it), rescaling on the way
       launch_rescale_compact_bin8(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                                   ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
@@ -1205,7 +1212,21 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     HIPCHK(ctx->rdc8.ensure((size_t)ncompact + 64));
     ctx->rdc_is_bytes = true;
     ctx->phases.push_back({"a5.nogc byte path", 1.0});
+    const bool split = k4_split && rescale_compact_split_applies(P.m, capval, ncompact, (int)noncode.size());
+    if (split) {
+      HIPCHK(ctx->slabs.ensure(rescale_compact_split_slab_bytes(capval, ncompact)));
+      HIPCHK(ctx->rdc8.ensure(rescale_compact_split_rdc_bytes(ncompact)));
+      ctx->phases.push_back({"k4.split", 1.0});
+    }
     Timer t(ctx, "cap_compact_bin", true);
+    if (split) {   // K4s without ratios (the bytes are the values), K4m
+      launch_rescale_compact_stream(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, d_cbreak, d_cum, inl, (int)noncode.size(),
+                                    ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), d_res, ctx->slabs.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot,
+                                    exp_slot ? exp_bytes : 0, nullptr, nullptr, nullptr, st);
+      t.~Timer();
+      new (&t) Timer(ctx, "bin_median", true);
+      launch_bin_median8(ctx->rdc8.as<uint8_t>(), ncompact, capval, P.m, ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), nullptr, st);
+    } else
     launch_cap_compact_bin8(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, inl, (int)noncode.size(),
                             ncompact, capval, P.m, ctx->rdc8.as<uint8_t>(), ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_res, ctx->slabs.p,
                             ctx->gsum.p, d_done + 2 * kDoneStride, ctx->hist_res.p, exp_slot, exp_slot ? exp_bytes : 0, st, 1);

@@ -323,8 +323,14 @@ def _check_split_off(hot, res, second):
     assert "candidate_test_one_wg" in kernels and "candidate_test" not in kernels, kernels
 
 
+def _check_k4split_off(hot, res, second):
+    """K4j, the one-kernel form of round 4 (kernels_base.hip), instead of K4s + K4m (kernels_k4s.hip)."""
+    phases, kernels = _ran(hot)
+    assert "k4.split" not in phases and "bin_median" not in kernels and "cap_compact_bin" in kernels, (phases, kernels)
+
+
 SWITCHES = {"RSI_HOT_JOINT": _check_joint_off, "RSI_HOT_SPEC": _check_spec_off, "RSI_HOT_K4J_FIX": _check_fix_off,
-            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off}
+            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off, "RSI_HOT_K4SPLIT": _check_k4split_off}
 
 
 @pytest.mark.parametrize("switch", sorted(SWITCHES))
@@ -351,5 +357,6 @@ def test_alternative_paths_behind_the_switches(hot, hotlib, switch):
     assert "gc_joint_hist" in kernels and "gc_hist" not in kernels
     assert "spec.k4j accepted" in phases, phases
     assert "k4j.float rescale" not in phases
+    assert "bin_median" in kernels            # K4 as K4s + K4m (the queued launch too)
     assert res.stats["scan_tiles_listed"] > 0
     assert "candidate_test" in kernels and "candidate_test_one_wg" not in kernels

@@ -31,7 +31,8 @@ if "--json" in sys.argv:
     import json
     out, bases = sys.argv[sys.argv.index("--json") + 1], int(sys.argv[sys.argv.index("--json") + 2])
     names_map = {"k_gc_hist": "gc_hist", "k_gc_rescale": "gc_rescale", "k_cap_compact_bin": "cap_compact_bin_int32",
-                 "k_cap_compact_bin8": "cap_compact_bin_r2", "k_rescale_compact_bin8": "cap_compact_bin", "k_value_hist8": "value_hist8",
+                 "k_cap_compact_bin8": "cap_compact_bin_r2", "k_rescale_compact_bin8": "cap_compact_bin_k4j", "k_rescale_compact_stream": "cap_compact_bin",
+                 "k_bin_median8": "bin_median", "k_value_hist8": "value_hist8",
                  "k_fasta_classify": "fasta_classify", "k_gc_joint_hist": "gc_joint_hist", "k_rsi_scan": "rsi_scan", "k_scan_detect": "scan_detect"}
     d = {"source": os.path.basename(root.rstrip("/")), "bases_per_launch": bases, "kernels": {}}
     for k, short in names_map.items():
