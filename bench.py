@@ -692,9 +692,12 @@ def genome_from_host(lib, pool, dev, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     return {"chromosomes": len(host), "bases": total, "ms": round(dt * 1e3, 2), "bases_per_s": round(total / dt, 1),
-            "h2d_GBps": round(5.0 * total / dt / 1e9, 1), "calls": sum(len(r.calls("calls")) for r in res),
-            "note": "rsi_pool_run_host: pinned host depth + FASTA of the 3 Gb genome's chromosomes (as many as a third of the free host memory "
-                    "holds, longest first) -> results on the host; the pool of the main line, each chromosome's transfer on its worker's stream"}
+            "input_GBps": round(5.0 * total / dt / 1e9, 1), "link_bytes_per_base": 2.0, "link_GBps": round(2.0 * total / dt / 1e9, 1),
+            "calls": sum(len(r.calls("calls")) for r in res),
+            "note": "rsi_pool_run_host: pinned host depth (int32) + FASTA of the 3 Gb genome's chromosomes (as many as a third of the free host "
+                    "memory holds, longest first) -> results on the host; every worker narrows its chromosome's depth to bytes on the host (AVX2, "
+                    "the long ones on two threads), sends 1 + 1 bytes per base over PCIe on its own stream and widens on the device; "
+                    "input_GBps = the 5 bytes per base of caller memory consumed per second"}
 
 
 def fallback_envelope(lib, pool, dev):

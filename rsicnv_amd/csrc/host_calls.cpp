@@ -3,6 +3,7 @@
 // /root/reference/src).  Compiled with -ffp-contract=off: the statistics below decide which
 // candidates survive, so they have to round like the reference's x86-64 build.
 #include "host_calls.h"
+#include <immintrin.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +30,43 @@ void bucket_indices_sse2(const float* x, size_t n, double lo, double dy, uint32_
 void bucket_indices_f32(const float* x, size_t n, double lo, double dy, uint32_t* idx) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
   if (avx2) bucket_indices_avx2(x, n, lo, dy, idx); else bucket_indices_sse2(x, n, lo, dy, idx);
+}
+
+// ---- depth from host memory, narrowed before it crosses PCIe (rsi_hot_run, pipeline.hip) ----
+// dst[i] = src[i] for 0 <= src[i] < 255, else 255 ("look in the list"); the values that do not fit go to (esc_pos, esc_val), up to
+// `cap` of them.  Returns their number (more than cap: the caller sends the int32 array as before).  The caller's array is what
+// the reference's loaders leave in Array<int> RD (loaddata.cpp:519-531); at sequencing depths next to nothing escapes.
+namespace {
+inline int64_t narrow_scalar(const int32_t* src, int64_t i0, int64_t i1, uint8_t* dst, int32_t* esc_pos, int32_t* esc_val, int64_t cap, int64_t nesc) {
+  for (int64_t i = i0; i < i1; ++i) {
+    const int32_t v = src[i];
+    if ((uint32_t)v < 255u) dst[i] = (uint8_t)v;
+    else { dst[i] = 255; if (nesc < cap) { esc_pos[nesc] = (int32_t)i; esc_val[nesc] = v; } ++nesc; }
+  }
+  return nesc;
+}
+__attribute__((target("avx2"))) int64_t narrow_avx2(const int32_t* src, int64_t n, uint8_t* dst, int32_t* esc_pos, int32_t* esc_val, int64_t cap) {
+  int64_t nesc = 0, i = 0;
+  const __m256i order = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+  const __m256i ff = _mm256_set1_epi8((char)0xff);
+  for (; i + 32 <= n; i += 32) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 8));
+    const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 16)), d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 24));
+    // clamp at 255 first (the second pack reads its input as SIGNED 16 bits: 65535 would come out as 0), then 32 -> 16 -> 8; the packs
+    // interleave the 128-bit halves: one permute puts the dwords back in order
+    const __m256i lim = _mm256_set1_epi32(255);
+    const __m256i bytes = _mm256_permutevar8x32_epi32(_mm256_packus_epi16(_mm256_packus_epi32(_mm256_min_epi32(a, lim), _mm256_min_epi32(b, lim)),
+                                                                          _mm256_packus_epi32(_mm256_min_epi32(c, lim), _mm256_min_epi32(d, lim))), order);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), bytes);
+    const int neg = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_or_si256(_mm256_or_si256(a, b), _mm256_or_si256(c, d))));   // a negative depth saturates to 0
+    if (neg | _mm256_movemask_epi8(_mm256_cmpeq_epi8(bytes, ff))) nesc = narrow_scalar(src, i, i + 32, dst, esc_pos, esc_val, cap, nesc);
+  }
+  return narrow_scalar(src, i, n, dst, esc_pos, esc_val, cap, nesc);
+}
+}  // namespace
+int64_t narrow_depth_u8(const int32_t* src, int64_t n, uint8_t* dst, int32_t* esc_pos, int32_t* esc_val, int64_t cap) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  return avx2 ? narrow_avx2(src, n, dst, esc_pos, esc_val, cap) : narrow_scalar(src, 0, n, dst, esc_pos, esc_val, cap, 0);
 }
 
 double normal_cdf(double x) {

@@ -146,4 +146,8 @@ void test_block_segments(const CallerInput& in, IntSpan status, std::vector<Cand
 void call_from_segments(const CallerInput& in, std::vector<Candidate> segs, DepthPager& depth,
                         std::vector<Candidate>& blocks, std::vector<Candidate>& raw, std::vector<Candidate>& kept);
 
+// Depth from host memory, narrowed to bytes before it crosses PCIe: dst[i] = src[i] where 0 <= src[i] < 255, else 255 with the value
+// listed in (esc_pos, esc_val) (up to cap entries).  Returns the number of values that did not fit (may exceed cap).
+int64_t narrow_depth_u8(const int32_t* src, int64_t n, uint8_t* dst, int32_t* esc_pos, int32_t* esc_val, int64_t cap);
+
 }  // namespace rsih

@@ -389,6 +389,7 @@ struct CandOut {
 // The capped, compacted depth as the candidate kernels see it: int32 (bytes = 4) or, behind K4', one byte per base (bytes = 1).
 struct DepthRef { const void* p; int bytes; };
 void launch_widen_u8(const uint8_t* src, int64_t n, int32_t* dst, hipStream_t stream);   // the int32 form of a byte array
+void launch_patch_i32(int32_t* dst, const int32_t* pos, const int32_t* val, int64_t cnt, hipStream_t stream);   // dst[pos[k]] = val[k]
 void launch_range_sums(DepthRef rdc, const void* ranges /* int2 lo,hi inclusive */, int nranges, long long* sums, hipStream_t stream);
 // one launch = one call of optimize_with_derivative for every job; ws: sharpen_workspace_bytes(ws_jobs) bytes laid out for
 // ws_jobs >= njobs jobs, whose first sharpen_workspace_zero_bytes(ws_jobs) are zero before the first launch (each launch

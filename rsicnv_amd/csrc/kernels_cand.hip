@@ -1058,4 +1058,14 @@ void launch_widen_u8(const uint8_t* src, int64_t n, int32_t* dst, hipStream_t st
   RSI_LAUNCH(k_widen_u8, dim3((unsigned int)blocks), dim3(256), 0, stream, src, n, dst);
 }
 
+// dst[pos[k]] = val[k]: the depths that did not fit a byte, behind launch_widen_u8 (rsi_hot_run's narrowed upload)
+__global__ __launch_bounds__(256) void k_patch_i32(int32_t* __restrict__ dst, const int32_t* __restrict__ pos, const int32_t* __restrict__ val, int64_t cnt) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * 256) dst[pos[k]] = val[k];
+}
+void launch_patch_i32(int32_t* dst, const int32_t* pos, const int32_t* val, int64_t cnt, hipStream_t stream) {
+  if (cnt <= 0) return;
+  const int64_t blocks = std::min<int64_t>((cnt + 255) / 256, 1024);
+  RSI_LAUNCH(k_patch_i32, dim3((unsigned int)blocks), dim3(256), 0, stream, dst, pos, val, cnt);
+}
+
 }  // namespace rsik

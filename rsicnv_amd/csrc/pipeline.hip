@@ -1596,7 +1596,51 @@ int rsi_hot_run(rsi_ctx* ctx, const rsi_params* p, const int32_t* depth, const u
   HIPCHK(ctx->in_depth.ensure((size_t)(n + 4) * 4));
   HIPCHK(ctx->in_fasta.ensure((size_t)n + 64));
   ctx->n_in = n;
-  HIPCHK(copy_h2d(ctx, ctx->in_depth.p, depth, (size_t)n * 4));
+  // The depth crosses PCIe as BYTES where that pays: the host narrows its int32 array (AVX2: ten gigabytes a second and core)
+  // into pinned memory, the values of 255 and more -- next to none at sequencing depths -- travel as a list, the device widens
+  // again (1 + 4 bytes per base of HBM traffic, 0.1 ms per 100 Mb): 2 bytes per base over the link instead of 5.  One thread
+  // narrows slower than the link copies, so this is for a pool whose workers each bring a chromosome of their own (the link
+  // is what sixteen of them share); a lone call copies the array as it is.  RSI_HOT_H2D_NARROW=0 / 1 forces either.
+  const char* narrow_v = getenv("RSI_HOT_H2D_NARROW");
+  const int narrow_env = narrow_v ? atoi(narrow_v) : -1;
+  const bool narrow = n >= (1 << 18) && (narrow_env >= 0 ? narrow_env != 0 : (ctx->gate != nullptr && !ctx->gate->lonely()));
+  bool narrowed = false;
+  if (narrow) {
+    Phase ph(ctx, "h2d.narrow");
+    const int64_t cap = n / 64 + 16;
+    const size_t list_off = ((size_t)n + 63) & ~size_t(63);
+    HIPCHK(ctx->h_d8.ensure(list_off + (size_t)cap * 8));
+    uint8_t* h8 = ctx->h_d8.as<uint8_t>();
+    int32_t* hpos = reinterpret_cast<int32_t*>(h8 + list_off);
+    int32_t* hval = hpos + cap;
+    // a long chromosome's narrowing on two threads (its caller's and one more): at ten gigabytes a second the 1 GB of a 250 Mb
+    // chromosome is what a pooled genome's makespan would otherwise end on
+    int64_t nesc = 0;
+    const char* split_v = getenv("RSI_HOT_H2D_SPLIT_MIN");   // (bases from which two threads narrow; tests lower it)
+    if (n >= (split_v ? atoll(split_v) : (long long)96 << 20)) {
+      const int64_t half = (n / 2) & ~(int64_t)63, cap0 = cap / 2, cap1 = cap - cap0;
+      int64_t ne1 = 0;
+      std::thread helper([&] { ne1 = rsih::narrow_depth_u8(depth + half, n - half, h8 + half, hpos + cap0, hval + cap0, cap1); });
+      const int64_t ne0 = rsih::narrow_depth_u8(depth, half, h8, hpos, hval, cap0);
+      helper.join();
+      if (ne0 <= cap0 && ne1 <= cap1) {   // the second half's entries move up behind the first's, their positions counted from the array's start
+        for (int64_t k = 0; k < ne1; ++k) { hpos[ne0 + k] = hpos[cap0 + k] + (int32_t)half; hval[ne0 + k] = hval[cap0 + k]; }
+        nesc = ne0 + ne1;
+      } else nesc = cap + 1;
+    } else nesc = rsih::narrow_depth_u8(depth, n, h8, hpos, hval, cap);
+    if (nesc <= cap) {
+      HIPCHK(ctx->in_d8.ensure((size_t)n + 64));
+      HIPCHK(hipMemcpyAsync(ctx->in_d8.p, h8, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      launch_widen_u8(ctx->in_d8.as<uint8_t>(), n, ctx->in_depth.as<int32_t>(), ctx->stream);
+      if (nesc > 0) {
+        HIPCHK(ctx->in_esc.ensure((size_t)cap * 8));
+        HIPCHK(hipMemcpyAsync(ctx->in_esc.p, hpos, (size_t)cap * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_patch_i32(ctx->in_depth.as<int32_t>(), ctx->in_esc.as<int32_t>(), ctx->in_esc.as<int32_t>() + cap, nesc, ctx->stream);
+      }
+      narrowed = true;
+    }
+  }
+  if (!narrowed) HIPCHK(copy_h2d(ctx, ctx->in_depth.p, depth, (size_t)n * 4));
   HIPCHK(copy_h2d(ctx, ctx->in_fasta.p, fasta, (size_t)n));
   HIPCHK(CTX_SYNC());
   return rsi_hot_run_device(ctx, p, ctx->in_depth.p, ctx->in_fasta.p, n, out);

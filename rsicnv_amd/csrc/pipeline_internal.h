@@ -140,6 +140,8 @@ struct rsi_ctx {
   size_t event_next = 0;
   // workspace
   DevBuf in_depth, in_fasta;                 // staging for the host-pointer entry point
+  DevBuf in_d8, in_esc;                      // ... its narrowed form: the depth as bytes, the values that did not fit (pos | val)
+  PinBuf h_d8;                               // pinned: the bytes and the list on their way to the device
   DevBuf text_dev[2], text_wg;               // depth text ingestion: two chunks of file bytes in HBM, per-workgroup order records
   char* text_pin[2] = {nullptr, nullptr};    // pinned staging for the file bytes
   size_t text_pin_cap = 0;

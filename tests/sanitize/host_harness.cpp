@@ -191,9 +191,43 @@ static void span_checks() {
   CHECK(sparse.at(100)[999] == dense[1099] && *sparse.at(4999) == dense[4999] && *sparse.at(50) == 0, "sparse span: at()");
 }
 
+// rsi_hot_run's narrowed upload (host_calls.cpp: narrow_depth_u8): bytes + list give the int32 array back, value for value --
+// depths of 254 / 255 / 256, 32767 / 32768 / 65535 / 65536 (a saturating pack reads 16-bit intermediates as SIGNED: the first
+// version turned everything from 32768 on into 0), INT32_MAX, negative ones; every length around the 32-value vector loop; a list
+// that is too short reports how many there were.
+static void narrow_checks() {
+  uint64_t rs = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+  const int32_t odd[] = {254, 255, 256, 300, 32767, 32768, 65535, 65536, 70000, 1 << 24, 2147483647, -1, -2147483647 - 1, 0};
+  for (int64_t n : {0, 1, 31, 32, 33, 63, 64, 65, 1000, 700001}) {
+    std::vector<int32_t> d((size_t)n);
+    for (auto& x : d) x = (int32_t)(rnd() % 90);
+    for (int k = 0; k < 14 && n > 0; ++k) d[(size_t)(rnd() % (uint64_t)n)] = odd[k];
+    for (int k = 0; k < 200 && n > 1000; ++k) d[(size_t)(rnd() % (uint64_t)n)] = (int32_t)(255 + rnd() % 3000000);
+    const int64_t cap = n / 64 + 16;
+    std::vector<uint8_t> b((size_t)n + 64, 0xAB);
+    std::vector<int32_t> pos((size_t)cap), val((size_t)cap);
+    const int64_t ne = rsih::narrow_depth_u8(d.data(), n, b.data(), pos.data(), val.data(), cap);
+    int64_t expect = 0;
+    for (int32_t x : d) expect += (uint32_t)x >= 255u;
+    CHECK(ne == expect, "narrow_depth_u8: %lld escapes reported, %lld present (n = %lld)", (long long)ne, (long long)expect, (long long)n);
+    if (ne <= cap) {
+      std::vector<int32_t> back((size_t)n);
+      for (int64_t i = 0; i < n; ++i) back[(size_t)i] = b[(size_t)i];
+      for (int64_t k = 0; k < ne; ++k) { CHECK(pos[(size_t)k] >= 0 && pos[(size_t)k] < n && b[(size_t)pos[(size_t)k]] == 255, "narrow_depth_u8: bad list entry"); back[(size_t)pos[(size_t)k]] = val[(size_t)k]; }
+      CHECK(back == d, "narrow_depth_u8: bytes + list do not give the array back (n = %lld)", (long long)n);
+    }
+    for (int k = 0; k < 64; ++k) CHECK(b[(size_t)n + k] == 0xAB, "narrow_depth_u8 wrote behind the array");
+  }
+  std::vector<int32_t> deep(4096, 1000), pos(8), val(8);
+  std::vector<uint8_t> b(4096 + 64);
+  CHECK(rsih::narrow_depth_u8(deep.data(), 4096, b.data(), pos.data(), val.data(), 8) == 4096, "narrow_depth_u8: a list that is too short must report the full count");
+}
+
 int main(int argc, char** argv) {
   quantile_checks();
   span_checks();
+  narrow_checks();
   orc_params P;
   orc_default_params(&P);
   candidate_stage_case(0x5A11, 400007, 0, P);

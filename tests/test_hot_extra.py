@@ -639,3 +639,43 @@ def test_filterstatus_level_sums_are_the_sequential_float_sums(hot, case):
     T = rng.gamma(9.0, 3.0, 5000).astype(np.float32); T[1234] = -1.0
     _, c = hot.debug_level_sums(T, np.zeros(5000, dtype=np.int32), Lmax)
     assert c[Lmax] == -1
+
+
+@pytest.mark.gpu
+def test_depth_narrowed_on_the_host_arrives_unchanged(hot, hotlib, monkeypatch):
+    """rsi_hot_run's narrowed upload (the depth crosses PCIe as bytes, the values of 255 and more as a list; the device widens
+    and patches): what reaches the device is the caller's int32 array, value for value -- including a handful of deep and of
+    absurd values -- and the run's results are those of the plain upload (the reference's golden file).  More escapes than the
+    list holds: the plain upload, same results."""
+    import golden_util as gu
+    from conftest import make_case
+    from rsicnv_amd import api
+    monkeypatch.setenv("RSI_HOT_H2D_NARROW", "1")
+    for _ in range(2):
+        gu.check_hip_against_golden(hot, hotlib, "gampois_nb_m101")
+    _, fasta, depth = make_case(hotlib, dict(n=700_000, seed=0xD8, model=1, n_events=4, gaps=1, max_len=15000, end_n=4000, gap_len=5000))
+    depth = depth.copy()
+    rng = np.random.default_rng(5)
+    pos = rng.choice(np.arange(20_000, 680_000), size=300, replace=False)
+    depth[pos[:100]] = 255
+    depth[pos[100:200]] = rng.integers(256, 4000, size=100)
+    depth[pos[200:]] = rng.integers(70_000, 2_000_000, size=100)
+    res_n = hot.run(api.make_params(), depth, fasta)
+    assert np.array_equal(hot.fetch("depth_in"), depth)
+    monkeypatch.setenv("RSI_HOT_H2D_SPLIT_MIN", "300000")      # the two-thread form a long chromosome takes
+    hot.run(api.make_params(), depth, fasta)
+    assert np.array_equal(hot.fetch("depth_in"), depth)
+    monkeypatch.delenv("RSI_HOT_H2D_SPLIT_MIN")
+    calls_n = [(c["start"], c["end"], c["type"], c["score"]) for c in res_n.calls("calls")]
+    stats_n = (res_n.stats["RDmedian"], res_n.stats["RDsd"], res_n.stats["byte_escapes"])
+    monkeypatch.setenv("RSI_HOT_H2D_NARROW", "0")
+    res_p = hot.run(api.make_params(), depth, fasta)
+    assert np.array_equal(hot.fetch("depth_in"), depth)
+    assert calls_n == [(c["start"], c["end"], c["type"], c["score"]) for c in res_p.calls("calls")]
+    assert stats_n == (res_p.stats["RDmedian"], res_p.stats["RDsd"], res_p.stats["byte_escapes"]) and stats_n[2] == 300
+    # more values of 255 and more than the list holds (n / 64): the plain upload
+    monkeypatch.setenv("RSI_HOT_H2D_NARROW", "1")
+    deep = depth.copy()
+    deep[rng.choice(700_000, size=30_000, replace=False)] = 300
+    hot.run(api.make_params(), deep, fasta)
+    assert np.array_equal(hot.fetch("depth_in"), deep)
