@@ -21,7 +21,7 @@ a cohort, weak scaling), reported with that label.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Steps are SUBMITTED to the pool (rsi_pool_submit) and waited for, gathered and turned into rows on a second host thread:
-`config.steps_in_flight` genomes are queued at once (2 for a whole genome on one GPU, as many as fill the pool's 16 workers for
+`config.steps_in_flight` genomes are queued at once (2 for a whole genome on one GPU, as many as fill the pool's workers for
 a rank's few chromosomes; `--inflight 1` = one genome at a time), the way samples arrive in production -- the first
 chromosomes of genome k + 1 run beside the last ones of genome k.  Every step's rows are produced and hashed inside the timed
 region; the timer is read after the last step's rows exist (barrier + synchronize on both sides, max over ranks).
@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
-    ap.add_argument("--workers", type=int, default=0, help="host threads / HIP streams per GPU (chromosomes in flight); 0 = min(16, max(4, 2 x the "
+    ap.add_argument("--workers", type=int, default=0, help="host threads / HIP streams per GPU (chromosomes in flight); 0 = min(20, max(4, 2 x the "
                     "host cores this rank may use)): sixteen on a box with eight cores and more per rank, fewer where eight ranks share sixteen cores")
     ap.add_argument("--inflight", type=int, default=0, help="steps (genomes) queued in the pool at once (rsi_pool_submit): the next genome's first "
                     "chromosomes run beside the last ones of the current genome.  0 = as many as keep the pool's workers busy with this rank's "
@@ -160,7 +160,7 @@ def main():
     except (AttributeError, OSError):
         allowed, forced = None, 0
     if args.workers <= 0:
-        args.workers = 16 if cores_per_rank is None else min(16, max(4, 2 * cores_per_rank))
+        args.workers = 20 if cores_per_rank is None else min(20, max(4, 2 * cores_per_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)

@@ -5,6 +5,7 @@
 //
 // Built with -ffp-contract=off and IEEE division/sqrt: every double expression below has to round
 // like the reference's x86-64 build.
+#include <type_traits>
 #include "kernels.h"
 #include "device_util.h"
 
@@ -431,50 +432,59 @@ __global__ __launch_bounds__(kThreads) void k_i32_to_f32_mm(const int32_t* __res
 constexpr int kScanTile = 256;    // one bin per lane: the tile's critical path is one lane's walk over L
 constexpr uint32_t kUnmarked = 0xffffffffu;
 
-struct ScanLds {     // plain base pointers and one stride: nothing here is indexed at run time, so it stays in registers
+// IX: the type of a staged index or count -- 16 bits while the staged stretch has fewer than 32 768 bins (every scan whose tile
+// fits LDS, and the device-memory tiles up to Lmax = kScanNarrowL), 32 bits for the scans beyond (a computed length above
+// 32 000 bins: rsi.cpp:1286-1289 with a large -threshold or a very noisy chromosome)
+template <class IX>
+struct ScanLdsT {    // plain base pointers and one stride: nothing here is indexed at run time, so it stays in registers
+  using index = IX;
   double* P;        // count + 1
   double* tot;      // kThreads
   uint32_t* TB;     // mark levels: [DEL, DUP][kcap + 1 levels][count]
   int* M;           // count: bin medians (the rare straddling median test reads the window)
-  uint16_t* CB;     // four prefix-count arrays CL, CG, CTd, CTu, `stride` apart (count + 1 used)
-  uint16_t* RB;     // four position-by-rank arrays, `stride` apart
-  uint16_t* PF;     // count: predicate bits of each staged bin (bit q = predicate q)
+  IX* CB;           // four prefix-count arrays CL, CG, CTd, CTu, `stride` apart (count + 1 used)
+  IX* RB;           // four position-by-rank arrays, `stride` apart
+  IX* PF;           // count: predicate bits of each staged bin (bit q = predicate q)
   int stride;       // count + 2
   int count, kcap;
-  __device__ uint16_t& C(int q, int x) const { return CB[q * stride + x]; }
-  __device__ uint16_t& R(int q, int r) const { return RB[q * stride + r]; }
+  __device__ IX& C(int q, int x) const { return CB[(size_t)q * stride + x]; }
+  __device__ IX& R(int q, int r) const { return RB[(size_t)q * stride + r]; }
   __device__ uint32_t* level(int side, int k) const { return TB + ((size_t)side * (kcap + 1) + k) * count; }
 };
 enum { kCL = 0, kCG = 1, kCTd = 2, kCTu = 3 };
+constexpr int kScanNarrowL = 32000;   // 256 + 2 (Lmax / 2 + 1) staged bins stay below 32 768: 16-bit indices
 
-__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap) {
+__host__ __device__ inline size_t scan_lds_bytes(int count, int kcap, int ix_bytes = 2) {
   size_t b = ((size_t)(count + 1) + kThreads) * sizeof(double);
   b += 2 * (size_t)(kcap + 1) * count * 4 + (size_t)count * 4;
-  b += 9 * (size_t)(count + 2) * 2;
+  b += 9 * (size_t)(count + 2) * ix_bytes;
   return b;
 }
-__device__ inline void scan_lds_carve(ScanLds& S, double* sm, int count, int kcap) {
+template <class SL>
+__device__ inline void scan_lds_carve(SL& S, double* sm, int count, int kcap) {
   S.count = count; S.kcap = kcap; S.stride = count + 2;
   S.P = sm;
   S.tot = S.P + count + 1;
   S.TB = reinterpret_cast<uint32_t*>(S.tot + kThreads);
   S.M = reinterpret_cast<int*>(S.TB + 2 * (size_t)(kcap + 1) * count);
-  S.CB = reinterpret_cast<uint16_t*>(S.M + count);
-  S.RB = S.CB + 4 * S.stride;
-  S.PF = S.RB + 4 * S.stride;
+  S.CB = reinterpret_cast<typename SL::index*>(S.M + count);
+  S.RB = S.CB + 4 * (size_t)S.stride;
+  S.PF = S.RB + 4 * (size_t)S.stride;
 }
 
 // first staged position >= x where predicate q holds, vhi when none; last position <= x, vlo-1 when none
-__device__ inline int scan_next(const ScanLds& S, int q, int x, int vhi) {
+template <class SL>
+__device__ inline int scan_next(const SL& S, int q, int x, int vhi) {
   const int r = S.C(q, x);
   return r < (int)S.C(q, S.count) ? (int)S.R(q, r) : vhi;
 }
-__device__ inline int scan_prev(const ScanLds& S, int q, int x, int vlo) {
+template <class SL>
+__device__ inline int scan_prev(const SL& S, int q, int x, int vlo) {
   const int r = S.C(q, x + 1);
   return r > 0 ? (int)S.R(q, r - 1) : vlo - 1;
 }
-
-__device__ inline void scan_mark(const ScanLds& S, int side, int lo, int hi, int L) {
+template <class SL>
+__device__ inline void scan_mark(const SL& S, int side, int lo, int hi, int L) {
   const int len = hi - lo + 1;
   int k = 31 - __clz(len);
   k = k > S.kcap ? S.kcap : k;
@@ -487,13 +497,14 @@ __device__ inline void scan_mark(const ScanLds& S, int side, int lo, int hi, int
 // Trim walks and marks of one hit that passed the median test, for the window [w0, w0+L-1] (staged
 // indices), when the lane has no run to continue (see scan_sweep).  side 0 = DEL, 1 = DUP; vlo/vhi:
 // staged indices inside the chromosome are [vlo, vhi); ends: bit 0 = the tile touches the chromosome
-// start, bit 1 = its end.  Returns i1 | i2 << 12 (the trimmed interval, possibly empty), or -1 when a
+// start, bit 1 = its end.  Returns i1 | i2 << 32 (the trimmed interval, possibly empty), or -1 when a
 // walk left the staged range.  Out of line: it is the rare case; it finds the tile's LDS through the
 // kernel's dynamic LDS symbol, so every access stays an LDS access.
-__device__ __noinline__ int scan_hit_slow(int count, int kcap, int w0, int L, int side, int vlo, int vhi, int ends,
-                                          uint32_t* counters, double* gtile /* NULL: the tile is the kernel's dynamic LDS */) {
+template <class SL>
+__device__ __noinline__ long long scan_hit_slow(int count, int kcap, int w0, int L, int side, int vlo, int vhi, int ends,
+                                                uint32_t* counters, double* gtile /* NULL: the tile is the kernel's dynamic LDS */) {
   extern __shared__ __align__(16) double sm[];
-  ScanLds S;
+  SL S;
   if (gtile) scan_lds_carve(S, gtile, count, kcap); else scan_lds_carve(S, sm, count, kcap);
   const int qm = side ? kCG : kCL, qt = side ? kCTu : kCTd;
   // the four trim walks in the reference's order (rsi.cpp:1211-1214 / 1241-1244), bounded to the chromosome
@@ -508,7 +519,7 @@ __device__ __noinline__ int scan_hit_slow(int count, int kcap, int w0, int L, in
     return -1;
   }
   if (i1 <= i2) scan_mark(S, side, i1, i2, L);
-  return i1 | (i2 << 16);
+  return (long long)i1 | ((long long)i2 << 32);
 }
 
 struct ScanTile { int vlo, vhi, fl_del, ce_dup, ends; double lim_del, lim_dup; double* gtile; };
@@ -545,8 +556,8 @@ struct ScanMid { int upto, a, b; };
 // gained -- is read for all eight lengths at once, before the first hit is looked at: inside an event every lane hits at every
 // L, and three dependent LDS round trips per hit add up over a hundred hits.  The rare cases (first hit of a run, a bin whose
 // median predicate fails, the straddling median) still go to LDS when they come up.
-template <int SIDE>
-__device__ inline void scan_hits_side(const ScanLds& S, const ScanTile& t, unsigned hs, int relc, int L0, int Lmax, ScanRun& run,
+template <int SIDE, class SL>
+__device__ inline void scan_hits_side(const SL& S, const ScanTile& t, unsigned hs, int relc, int L0, int Lmax, ScanRun& run,
                                       ScanMid& mid, uint32_t* counters) {
   constexpr int qm = SIDE ? kCG : kCL, qt = SIDE ? kCTu : kCTd;
   int cw[kScanPad];          // bins of the window beyond the median limit
@@ -602,8 +613,8 @@ __device__ inline void scan_hits_side(const ScanLds& S, const ScanTile& t, unsig
       }
       if (lo_m <= hi_m) scan_mark(S, SIDE, lo_m, hi_m, L);
     } else if (pass) {
-      const int r = scan_hit_slow(S.count, S.kcap, w0, L, SIDE, t.vlo, t.vhi, t.ends, counters, t.gtile);
-      if (r >= 0) { now.lastL = L; now.i1 = r & 0xffff; now.i2 = (r >> 16) & 0x7fff; }
+      const long long r = scan_hit_slow<SL>(S.count, S.kcap, w0, L, SIDE, t.vlo, t.vhi, t.ends, counters, t.gtile);
+      if (r >= 0) { now.lastL = L; now.i1 = (int)(r & 0xffffffffll); now.i2 = (int)(r >> 32); }
     }
     run = now;
   }
@@ -612,8 +623,8 @@ __device__ inline void scan_hits_side(const ScanLds& S, const ScanTile& t, unsig
 // [Lbeg, Lfin]: the lengths this workgroup looks at (Lbeg = 1 mod kScanPad, whole groups): a tile's lengths are split over
 // several workgroups (k_rsi_scan).  A lane that starts in the middle has no run to continue: its first hit takes the general
 // path (scan_hit_slow), exactly as the first hit of a run does, and smallest-L-wins is an atomicMin whoever comes first.
-template <bool EDGE>
-__device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const double* __restrict__ thr_del,
+template <bool EDGE, class SL>
+__device__ inline void scan_sweep(const SL& S, const ScanTile& t, const double* __restrict__ thr_del,
                                   const double* __restrict__ thr_dup, int relc, int Lmax, int Lend, int Lbeg, int Lfin, uint32_t* counters) {
   double p_lo = S.P[relc - ((Lbeg - 1) >> 1)], p_hi = 0.0;   // the left end of the window of length Lbeg - 1
   ScanRun run_del = {-1, 0, 0}, run_dup = {-1, 0, 0};
@@ -639,8 +650,8 @@ __device__ inline void scan_sweep(const ScanLds& S, const ScanTile& t, const dou
       hits |= (hd ? 1u << u : 0u) | (hu ? 0x100u << u : 0u);
     }
     if (!__ballot(hits != 0)) continue;
-    if (__ballot((hits & 0xffu) != 0)) scan_hits_side<0>(S, t, hits & 0xffu, relc, L0, Lmax, run_del, mid_del, counters);
-    if (__ballot((hits >> 8) != 0)) scan_hits_side<1>(S, t, hits >> 8, relc, L0, Lmax, run_dup, mid_dup, counters);
+    if (__ballot((hits & 0xffu) != 0)) scan_hits_side<0, SL>(S, t, hits & 0xffu, relc, L0, Lmax, run_del, mid_del, counters);
+    if (__ballot((hits >> 8) != 0)) scan_hits_side<1, SL>(S, t, hits >> 8, relc, L0, Lmax, run_dup, mid_dup, counters);
   }
 }
 
@@ -790,7 +801,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_detect(const float* __restric
 // GTILE: the tile lives in device memory (gws + blockIdx.x * gbytes) instead of LDS -- scans longer than kScanLdsL.  Same code;
 // the waves of a workgroup share a CU and its L1, so what one wave stored is what another loads once every wave's stores are
 // done (drain) and the workgroup has met at the barrier.
-template <bool INL, bool GTILE>
+// WIDE (device-memory tiles only): 32-bit staged indices, for the scans whose staged stretch has 32 768 bins and more.
+template <bool INL, bool GTILE, bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__ T, const int32_t* __restrict__ medint,
                                                        ScanParams sp, const double* __restrict__ thr_del_mem,
                                                        const double* __restrict__ thr_dup_mem,
@@ -804,7 +816,10 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
   const int halo = Lmax / 2 + 1;
   const int count = kScanTile + 2 * halo;          // staged bins
   auto tile_sync = [&]() { if (GTILE) drain(); __syncthreads(); };
-  ScanLds S;
+  static_assert(GTILE || !WIDE, "a tile with 32-bit indices lives in device memory");
+  using IX = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
+  using SL = ScanLdsT<IX>;
+  SL S;
   double* const gtile = GTILE ? reinterpret_cast<double*>(gws + (size_t)blockIdx.x * gbytes) : nullptr;
   if (GTILE) scan_lds_carve(S, gtile, count, kcap); else scan_lds_carve(S, sm, count, kcap);
   __shared__ int s_c[4][kThreads];
@@ -855,7 +870,7 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
       rc[kCTu] += (in && !((double)v < tmed));       // where a DUP value walk stops (rsi.cpp:1241, 1243)
       S.P[e + 1] = run;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S.C(q, e + 1) = (uint16_t)rc[q];
+      for (int q = 0; q < 4; ++q) S.C(q, e + 1) = (IX)rc[q];
     }
     S.tot[threadIdx.x] = run;
 #pragma unroll
@@ -891,11 +906,11 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int after = (int)S.C(q, e + 1) + o4[q];
-          S.C(q, e + 1) = (uint16_t)after;
-          if (after != before[q]) { S.R(q, before[q]) = (uint16_t)e; bits |= 1u << q; }   // e is the before[q]-th bin with predicate q
+          S.C(q, e + 1) = (IX)after;
+          if (after != before[q]) { S.R(q, before[q]) = (IX)e; bits |= 1u << q; }   // e is the before[q]-th bin with predicate q
           before[q] = after;
         }
-        S.PF[e] = (uint16_t)bits;
+        S.PF[e] = (IX)bits;
       }
     }
     for (int d = 32; d >= 1; d >>= 1) inexact += __shfl_xor(inexact, d);
@@ -918,8 +933,8 @@ __global__ __launch_bounds__(kThreads) void k_rsi_scan(const float* __restrict__
       int Lend = (i < sp.nb && hmax >= 0) ? (int)(hmax < Lmax ? 2 * hmax + 1 : Lmax) : 0;
       if (Lend > Lmax) Lend = Lmax;
       const int relc = Lend > 0 ? rel : halo;   // lanes without a bin read a harmless address
-      if (edge_tile) scan_sweep<true>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
-      else scan_sweep<false>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
+      if (edge_tile) scan_sweep<true, SL>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
+      else scan_sweep<false, SL>(S, tile, thr_del, thr_dup, relc, Lmax, Lend, Lbeg, Lfin, counters);
     }
     tile_sync();
     // ---- push the block levels down to single bins ----
@@ -956,13 +971,14 @@ constexpr int kBothCap = 16384;
 // same answer.  256 levels at a time -- a block scan of their counts, the reference's own expression per level, the smallest
 // level that passes -- where one thread used to walk the levels with a double division each (a hundred of them: 6 us per call,
 // two calls per launch).
-__device__ inline uint32_t stop_level_block(const unsigned int* s_l, int32_t Lmax, int64_t nb) {
+template <class Load>
+__device__ inline uint32_t stop_level_block(Load count_at /* count_at(L): bins first marked at length L */, int32_t Lmax, int64_t nb) {
   __shared__ int s_wsum[kThreads / 64], s_wmin[kThreads / 64];
   long long carry = 0;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   for (int base = 1; base <= Lmax; base += kThreads) {
     const int L = base + (int)threadIdx.x;
-    const int c = L <= Lmax ? (int)s_l[L] : 0;
+    const int c = L <= Lmax ? (int)count_at(L) : 0;
     const int incl = wave_incl_scan(c);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
@@ -981,6 +997,9 @@ __device__ inline uint32_t stop_level_block(const unsigned int* s_l, int32_t Lma
   }
   return (uint32_t)Lmax;
 }
+// WIDE_L: the two per-L histograms do not fit LDS (Lmax beyond 20 000): every count goes straight to the histograms in device memory
+// (atomics), and the last workgroup walks them there.  Same results; the scans that long are slow elsewhere.
+template <bool WIDE_L>
 __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restrict__ first_del, const uint32_t* __restrict__ first_dup,
                                                          int64_t nb, int32_t Lmax, uint32_t* __restrict__ work,
                                                          uint2* __restrict__ both, unsigned int* __restrict__ counter,
@@ -991,8 +1010,11 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
   uint32_t* head = work;                  // [0] escapes [1] inexact (the scan) [2] ldel [3] ldup [4] both-count [5] last run start + 1
   uint32_t* hist_d = work + 16;
   uint32_t* hist_u = hist_d + ((Lmax + 1 + kScanPad + 3) & ~3);   // scan_level_stride(Lmax)
-  for (int e = threadIdx.x; e < 2 * (Lmax + 1); e += kThreads) s_l[e] = 0;
-  __syncthreads();
+  if (WIDE_L) { s_d = hist_d; s_u = hist_u; }
+  else {
+    for (int e = threadIdx.x; e < 2 * (Lmax + 1); e += kThreads) s_l[e] = 0;
+    __syncthreads();
+  }
   auto one = [&](uint32_t fd, uint32_t fu) {
     const bool hd = fd <= (uint32_t)Lmax, hu = fu <= (uint32_t)Lmax;
     if (hd) atomicAdd(&s_d[fd], 1u);
@@ -1011,16 +1033,23 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
     }
     for (; i < nb; i += stride) one(first_del[i], first_dup[i]);
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) {
-    const unsigned int c = s_d[e], u = s_u[e];
-    if (c) atomicAdd(&hist_d[e], c);
-    if (u) atomicAdd(&hist_u[e], u);
+  if (!WIDE_L) {
+    __syncthreads();
+    for (int e = threadIdx.x; e <= Lmax; e += kThreads) {
+      const unsigned int c = s_d[e], u = s_u[e];
+      if (c) atomicAdd(&hist_d[e], c);
+      if (u) atomicAdd(&hist_u[e], u);
+    }
   }
   if (!last_block_done(counter)) return;
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) { s_d[e] = ld_cg(hist_d + e); s_u[e] = ld_cg(hist_u + e); }
-  __syncthreads();
-  const uint32_t ldel = stop_level_block(s_d, Lmax, nb);
+  if (!WIDE_L) {
+    for (int e = threadIdx.x; e <= Lmax; e += kThreads) { s_d[e] = ld_cg(hist_d + e); s_u[e] = ld_cg(hist_u + e); }
+    __syncthreads();
+  }
+  // (WIDE_L: the counts are read where the atomics left them -- ld_cg, past this CU's cache)
+  auto del_at = [&](int L) { return WIDE_L ? ld_cg(hist_d + L) : s_d[L]; };
+  auto dup_at = [&](int L) { return WIDE_L ? ld_cg(hist_u + L) : s_u[L]; };
+  const uint32_t ldel = stop_level_block(del_at, Lmax, nb);
   const uint32_t nboth = ld_cg(&head[4]);
   if (nboth <= (uint32_t)kBothCap) {
     for (uint32_t k = threadIdx.x; k < nboth; k += kThreads) {
@@ -1028,16 +1057,18 @@ __global__ __launch_bounds__(kThreads) void k_level_stop(const uint32_t* __restr
       if (fd <= ldel) atomicSub(&s_u[fu], 1u);
     }
   } else {   // the list overflowed: this workgroup recounts the DUP histogram with the exclusion
-    for (int e = threadIdx.x; e <= Lmax; e += kThreads) s_u[e] = 0;
+    for (int e = threadIdx.x; e <= Lmax; e += kThreads) { if (WIDE_L) st_cg(&hist_u[e], 0u); else s_u[e] = 0; }
+    if (WIDE_L) drain();
     __syncthreads();
     for (int64_t i = threadIdx.x; i < nb; i += kThreads) {
       const uint32_t fu = first_dup[i];
       if (fu <= (uint32_t)Lmax && !(first_del[i] <= ldel)) atomicAdd(&s_u[fu], 1u);
     }
   }
+  if (WIDE_L) drain();   // this workgroup's atomics have landed before any of its threads reads the counts again
   __syncthreads();
-  for (int e = threadIdx.x; e <= Lmax; e += kThreads) st_cg(&hist_u[e], s_u[e]);
-  const uint32_t ldup = stop_level_block(s_u, Lmax, nb);
+  if (!WIDE_L) for (int e = threadIdx.x; e <= Lmax; e += kThreads) st_cg(&hist_u[e], s_u[e]);
+  const uint32_t ldup = stop_level_block(dup_at, Lmax, nb);
   if (threadIdx.x == 0) { st_cg(&head[2], ldel); st_cg(&head[3], ldup); }
   sync_drained();
   export_words(host_copy, work, host_bytes);
@@ -1267,66 +1298,87 @@ void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_a
   if (pack16) RSI_LAUNCH(k_hist_walk<true>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins);
   else { RSI_ALLOW_FULL_LDS(k_hist_walk<false>); RSI_LAUNCH(k_hist_walk<false>, dim3(grid), dim3(kThreads), lds, stream, x, mask, nb, use_abs, center, d_center, out, c.hist, c.counters + 1, e, f, bins); }
 }
-constexpr int kGTileGrid = 256;   // workgroups of the device-memory-tile form (one workspace slice each)
-static void scan_tile_shape(int Lmax, int& count, int& kcap, bool& gtile) {
+constexpr int kGTileGrid = 256;   // workgroups of the device-memory-tile form (one workspace slice each) ...
+constexpr size_t kGTileBudget = size_t(8) << 30;   // ... fewer where 256 slices would take more than this (Lmax beyond 300 000)
+struct ScanShape { int count, kcap, grid; bool gtile, wide; size_t tile_bytes; };
+static ScanShape scan_tile_shape(int Lmax) {
+  ScanShape sh;
   const int halo = Lmax / 2 + 1;
-  count = kScanTile + 2 * halo;
+  sh.count = kScanTile + 2 * halo;
   // block-level cap: floor(log2(Lmax)), at most 6
-  kcap = 0;
-  while ((2 << kcap) <= Lmax && kcap < 6) ++kcap;
-  gtile = Lmax > kScanLdsL;
+  sh.kcap = 0;
+  while ((2 << sh.kcap) <= Lmax && sh.kcap < 6) ++sh.kcap;
+  sh.gtile = Lmax > kScanLdsL;
+  sh.wide = Lmax > kScanNarrowL;
   // in LDS: lowered until the tile fits
-  if (!gtile) while (kcap > 0 && scan_lds_bytes(count, kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --kcap;
+  if (!sh.gtile) while (sh.kcap > 0 && scan_lds_bytes(sh.count, sh.kcap) + 4 * kThreads * sizeof(int) + 1024 > 160 * 1024) --sh.kcap;
+  sh.tile_bytes = scan_lds_bytes(sh.count, sh.kcap, sh.wide ? 4 : 2);
+  sh.grid = kGTileGrid;
+  if (sh.gtile) {
+    const size_t slice = (sh.tile_bytes + 255) & ~size_t(255);
+    if (slice * (size_t)sh.grid > kGTileBudget) sh.grid = (int)std::max<size_t>(1, kGTileBudget / slice);
+  }
+  return sh;
 }
 size_t scan_tile_workspace_bytes(int Lmax) {
-  int count, kcap; bool gtile;
-  scan_tile_shape(Lmax, count, kcap, gtile);
-  return gtile ? (size_t)kGTileGrid * ((scan_lds_bytes(count, kcap) + 255) & ~size_t(255)) : 0;
+  const ScanShape sh = scan_tile_shape(Lmax);
+  return sh.gtile ? (size_t)sh.grid * ((sh.tile_bytes + 255) & ~size_t(255)) : 0;
 }
 void launch_rsi_scan(const float* T, const int32_t* medint, const ScanParams& sp_in, const double* thr_del, const double* thr_dup,
                      const ScanThr* inl, uint32_t* first_del, uint32_t* first_dup, uint32_t* counters, uint32_t* tiles, void* tile_ws,
                      hipStream_t stream) {
   ScanParams sp = sp_in;
-  int count, kcap; bool gtile;
-  scan_tile_shape(sp.Lmax, count, kcap, gtile);
-  sp.kcap = kcap;
-  const size_t tile_bytes = scan_lds_bytes(count, kcap);
+  const ScanShape sh = scan_tile_shape(sp.Lmax);
+  const bool gtile = sh.gtile;
+  sp.kcap = (int16_t)sh.kcap;
+  const size_t tile_bytes = sh.tile_bytes;
   const size_t lds = gtile ? 0 : tile_bytes;
   const unsigned long long gbytes = (tile_bytes + 255) & ~size_t(255);
   const int64_t ntiles = (sp.nb + kScanTile - 1) / kScanTile;
   static const ScanThr none{};
   // RSI_HOT_SCAN_DETECT=0: no detection pass, every tile through the exact sweep in one piece (A/B runs; same marks)
   const char* det_env = getenv("RSI_HOT_SCAN_DETECT");
-  const bool detect = tiles != nullptr && !(det_env && atoi(det_env) == 0);
+  // the detection pass stages its stretch and the float thresholds in LDS: up to Lmax = 13 000 or so; longer scans send every
+  // tile through the exact sweep
+  const size_t dlds = detect_lds_bytes(sp.Lmax);
+  const bool detect = tiles != nullptr && !(det_env && atoi(det_env) == 0) && dlds + kThreads * 8 + 64 <= 160 * 1024;
   int parts = 1;
-  if (detect) {
+  if (detect || gtile) {
     // Lengths of a listed tile over several workgroups: whole groups of kScanPad lengths, up to kScanPartsMax shares
     const int groups = (sp.Lmax + kScanPad - 1) / kScanPad;
     parts = groups < kScanPartsMax ? groups : kScanPartsMax;
     if (const char* pe = getenv("RSI_HOT_SCAN_PARTS")) { const int v = atoi(pe); if (v >= 1 && v <= groups) parts = v; }
-    const size_t dlds = detect_lds_bytes(sp.Lmax);
+  }
+  if (detect) {
     const int dgrid = (int)((sp.nb + kDetBins - 1) / kDetBins);
     if (inl) { RSI_ALLOW_FULL_LDS(k_scan_detect<true>); RSI_LAUNCH(k_scan_detect<true>, dim3(dgrid), dim3(kThreads), dlds, stream, T, sp.nb, sp.Lmax, nullptr, nullptr, tiles, counters, *inl); }
     else { RSI_ALLOW_FULL_LDS(k_scan_detect<false>); RSI_LAUNCH(k_scan_detect<false>, dim3(dgrid), dim3(kThreads), dlds, stream, T, sp.nb, sp.Lmax, thr_del, thr_dup, tiles, counters, none); }
   }
   // workgroups pull (tile, share) tasks from a counter: as many as can be resident, never more than there can be tasks
   int64_t grid = ntiles * parts;
-  const int64_t resident = gtile ? kGTileGrid : 256 * (int64_t)(lds > 80 * 1024 ? 1 : lds > 52 * 1024 ? 2 : lds > 39 * 1024 ? 3 : 4);
+  const int64_t resident = gtile ? sh.grid : 256 * (int64_t)(lds > 80 * 1024 ? 1 : lds > 52 * 1024 ? 2 : lds > 39 * 1024 ? 3 : 4);
   if ((detect || gtile) && grid > resident) grid = resident;
   const uint32_t* list = detect ? tiles : nullptr;
   unsigned char* gws = static_cast<unsigned char*>(tile_ws);
-#define RSI_SCAN(INL_, GT_, ...) do { RSI_ALLOW_FULL_LDS((k_rsi_scan<INL_, GT_>));                                                     \
-    RSI_LAUNCH((k_rsi_scan<INL_, GT_>), dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, __VA_ARGS__, first_del, first_dup, \
+#define RSI_SCAN(INL_, GT_, WIDE_, ...) do { RSI_ALLOW_FULL_LDS((k_rsi_scan<INL_, GT_, WIDE_>));                                             \
+    RSI_LAUNCH((k_rsi_scan<INL_, GT_, WIDE_>), dim3((unsigned)grid), dim3(kThreads), lds, stream, T, medint, sp, __VA_ARGS__, first_del, first_dup, \
                counters, list, parts, inl ? *inl : none, gws, gbytes); } while (0)
-  if (gtile) { if (inl) RSI_SCAN(true, true, nullptr, nullptr); else RSI_SCAN(false, true, thr_del, thr_dup); }
-  else { if (inl) RSI_SCAN(true, false, nullptr, nullptr); else RSI_SCAN(false, false, thr_del, thr_dup); }
+  if (gtile && sh.wide) RSI_SCAN(false, true, true, thr_del, thr_dup);   // (thresholds ride in the arguments up to Lmax = 223 only)
+  else if (gtile) { if (inl) RSI_SCAN(true, true, false, nullptr, nullptr); else RSI_SCAN(false, true, false, thr_del, thr_dup); }
+  else { if (inl) RSI_SCAN(true, false, false, nullptr, nullptr); else RSI_SCAN(false, false, false, thr_del, thr_dup); }
 #undef RSI_SCAN
 }
 void launch_level_stop(const uint32_t* first_del, const uint32_t* first_dup, int64_t nb, int32_t Lmax, uint32_t* work, void* both,
                        unsigned int* counter, void* host_copy, size_t host_bytes, hipStream_t stream) {
-  RSI_ALLOW_FULL_LDS(k_level_stop);   // (Lmax + 1) * 8 bytes: 80 KB at -m 1
-  RSI_LAUNCH(k_level_stop, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), (size_t)(Lmax + 1) * 8, stream, first_del, first_dup, nb,
-                     Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
+  const size_t lds = (size_t)(Lmax + 1) * 8;   // 80 KB at -m 1
+  if (lds + 256 <= 160 * 1024) {
+    RSI_ALLOW_FULL_LDS(k_level_stop<false>);
+    RSI_LAUNCH(k_level_stop<false>, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), lds, stream, first_del, first_dup, nb,
+                       Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
+  } else {
+    RSI_LAUNCH(k_level_stop<true>, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, first_del, first_dup, nb,
+                       Lmax, work, static_cast<uint2*>(both), counter, host_copy, (unsigned int)host_bytes);
+  }
 }
 void launch_resolve_runs(const uint32_t* first_del, const uint32_t* first_dup, const uint32_t* levels, int64_t nb, int32_t* status,
                          int32_t* copy, uint64_t* runs, uint32_t* count, uint32_t cap, unsigned int* counter, void* host_copy,

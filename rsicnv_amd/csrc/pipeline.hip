@@ -446,8 +446,12 @@ class DeviceTester : public rsih::NeighbourTester {
 // first-L arrays, the work block and the boundary counter were cleared by the last launch of the quantile chain in front.
 // What the host wants from the pass lands in the pinned mailbox: *work_slot = [ScanPassOut | per-L counts], *runs_slot =
 // [count | first boundaries].
+// A scan longer than kMaxL (a computed length, rsi.cpp:1286-1289, beyond 10 400 bins: a large -threshold, a very noisy chromosome)
+// takes the same launches with its work block in a buffer of its own (the resident one is sized for kMaxL), cleared here, and
+// -- where the pinned mailbox cannot hold the per-L counts -- brought back by a copy into `spill`.
 int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint, int64_t nb, double RDmedian, double tmedian,
-              double tlamda, int Lmax, int32_t* d_status, int32_t* d_copy, const uint32_t** work_slot, const uint32_t** runs_slot) {
+              double tlamda, int Lmax, int32_t* d_status, int32_t* d_copy, const uint32_t** work_slot, const uint32_t** runs_slot,
+              std::vector<uint32_t>* spill) {
   uint8_t* small = ctx->small.as<uint8_t>();
   std::vector<double> del, dup;
   scan_thresholds(tmedian, tlamda, Lmax, del, dup);
@@ -466,20 +470,30 @@ int scan_pass(rsi_ctx* ctx, int pass, const float* d_T, const int32_t* d_medint,
     HIPCHK(copy_h2d(ctx, d_del, del.data(), 2 * nthr * 8));
   }
   uint32_t* work = reinterpret_cast<uint32_t*>(small + kOffScanPass + (size_t)pass * kScanPassBytes);
+  if (Lmax > kMaxL) {
+    const size_t dev_bytes = (64 + 2 * (size_t)scan_level_stride(Lmax) * 4 + 255) & ~size_t(255);
+    HIPCHK(ctx->scan_work_big.ensure(2 * dev_bytes));
+    work = reinterpret_cast<uint32_t*>(ctx->scan_work_big.as<uint8_t>() + (size_t)pass * dev_bytes);
+    HIPCHK(hipMemsetAsync(work, 0, dev_bytes, ctx->stream));
+    if (pass == 0) ctx->phases.push_back({"scan.long (Lmax > 10400)", 1.0});
+  }
   uint32_t* d_first_del = ctx->first_del.as<uint32_t>();
   uint32_t* d_first_dup = d_first_del + ((nb + 3) & ~int64_t(3));
   unsigned int* d_done = reinterpret_cast<unsigned int*>(small + kOffDone) + kDoneBinSlot;
   uint32_t* d_count = reinterpret_cast<uint32_t*>(small + kOffCounters) + 4;
   const size_t work_bytes = 64 + ((size_t)scan_level_stride(Lmax) + (size_t)Lmax + 1) * 4;
   if (scan_tile_workspace_bytes(Lmax)) HIPCHK(ctx->scan_ws.ensure(scan_tile_workspace_bytes(Lmax)));   // scans too long for an LDS tile
-  uint32_t* wslot = static_cast<uint32_t*>(mb_alloc(ctx, work_bytes));
   uint32_t* rslot = static_cast<uint32_t*>(mb_alloc(ctx, 8 + (size_t)kEagerBounds * 8));
-  if (!wslot || !rslot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+  uint32_t* wslot = static_cast<uint32_t*>(work_bytes <= kMailboxBytes / 8 ? mb_alloc(ctx, work_bytes) : nullptr);
+  const bool spilled = !wslot && Lmax > kMaxL && spill;
+  if (spilled) spill->assign((work_bytes + 3) / 4, 0u);
+  if ((!wslot && !spilled) || !rslot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
   ScanParams sp;
   sp.nb = nb; sp.Lmax = Lmax; sp.pad = 0; sp.tmedian = tmedian;
   sp.lim_del = RDmedian * 0.75; sp.lim_dup = RDmedian * 1.25;
   { Timer t(ctx, "rsi_scan"); launch_rsi_scan(d_T, d_medint, sp, d_del, d_dup, use_inl ? &inl : nullptr, d_first_del, d_first_dup, work, ctx->scan_tiles.as<uint32_t>(), ctx->scan_ws.p, ctx->stream); }
-  { Timer t(ctx, "level_stop"); launch_level_stop(d_first_del, d_first_dup, nb, Lmax, work, ctx->runs.p, d_done + 2, wslot, work_bytes, ctx->stream); }
+  { Timer t(ctx, "level_stop"); launch_level_stop(d_first_del, d_first_dup, nb, Lmax, work, ctx->runs.p, d_done + 2, wslot, wslot ? work_bytes : 0, ctx->stream); }
+  if (spilled) { HIPCHK(hipMemcpyAsync(spill->data(), work, work_bytes, hipMemcpyDeviceToHost, ctx->stream)); wslot = spill->data(); }
   { Timer t(ctx, "resolve_runs"); launch_resolve_runs(d_first_del, d_first_dup, work + 2, nb, d_status, d_copy, ctx->runs.as<uint64_t>(), d_count, kMaxRunEntries, d_done + 3, rslot, kEagerBounds, ctx->stream); }
   *work_slot = wslot; *runs_slot = rslot;
   return RSI_OK;
@@ -552,7 +566,13 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   // gets there without having stopped is what the reference exits on.
   const bool clipped = Lmax > nb;
   if (clipped) Lmax = (int)nb;
-  if (Lmax > kMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond 10400 (the reference's own ceiling without a larger computed length is 10000, at -m 1)");
+  // Up to kMaxL (the reference's own ceiling without a larger computed length is 10000, at -m 1) everything the scan needs is
+  // resident; beyond, the scan takes its long form (scan_pass; kernels_bin.hip: device-memory tiles, 32-bit staged indices past
+  // 32 000, per-L counts in device memory past 20 000) and filterstatus' level sums run on the host.  kHardMaxL bounds the
+  // scratch (a tile of 4 M bins is 440 MB per workgroup); the reference itself would need years for such a sweep.
+  if (Lmax > kHardMaxL) return fail(ctx, RSI_ERR_UNSUPPORTED, "scan length Lmax beyond 4194304 bins");
+  const bool long_scan = Lmax > kMaxL;
+  std::vector<uint32_t> spill1, spill2;
   auto sweeps_stopped = [&](const uint32_t* w) -> bool {   // both sweeps of a pass ended by the 20 % rule (w: the pass's work block)
     for (int k = 0; k < 2; ++k) {
       const uint32_t* cnt = w + 16 + (size_t)k * scan_level_stride(Lmax);
@@ -568,16 +588,16 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   int32_t* d_st2 = ctx->status2.as<int32_t>();
   const uint32_t* wslot = nullptr;
   const uint32_t* rslot = nullptr;
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, d_st1f, &wslot, &rslot)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 0, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st1, d_st1f, &wslot, &rslot, &spill1)) != RSI_OK) return rc; }
 
   Phase ph_filter(ctx, "scan.filterstatus");
   // ---- filterstatus (rsi.cpp:948-1047): the per-level sums are float accumulations in index order (App. A Q13) -- computed
   // on the device by an exact parallel form of the sequential loop (kernels_fs.hip), so neither the transformed bins nor
   // the status array travel to the host; the edge trimming runs on the device too, one thread per run ----
   const int nlev = 2 * Lmax + 1;
-  uint32_t* fs_slot = static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
-  if (!fs_slot) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
-  {
+  uint32_t* fs_slot = long_scan ? nullptr : static_cast<uint32_t*>(mb_alloc(ctx, (size_t)nlev * 8));
+  if (!fs_slot && !long_scan) return fail(ctx, RSI_ERR_INTERNAL, "out of pinned mailbox memory");
+  if (!long_scan) {
     GateShared gs(ctx);
     Timer t(ctx, "level_sums");
     launch_level_sums(d_T, d_st1, nb, Lmax, ctx->fs_ws.p, kMaxL, kFsListCap, ctx->fs_out.as<float>(),
@@ -595,9 +615,11 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
     // the counts afterwards.
     std::vector<float> wsum((size_t)nlev, 0.0f);
     std::vector<int> wcnt((size_t)nlev, 0);
-    memcpy(wsum.data(), fs_slot, (size_t)nlev * 4);
-    memcpy(wcnt.data(), fs_slot + nlev, (size_t)nlev * 4);
-    if (wcnt[(size_t)Lmax] < 0) {   // the device declined (negative / non-finite values, too many marked bins): the loop itself
+    if (fs_slot) {
+      memcpy(wsum.data(), fs_slot, (size_t)nlev * 4);
+      memcpy(wcnt.data(), fs_slot + nlev, (size_t)nlev * 4);
+    }
+    if (long_scan || wcnt[(size_t)Lmax] < 0) {   // a long scan, or the device declined (negative / non-finite values, too many marked bins): the loop itself
       Phase phc(ctx, "fs.copy");
       HIPCHK(ctx->h_T.ensure((size_t)nb * 4));
       HIPCHK(ctx->h_status.ensure((size_t)nb * 4));
@@ -675,7 +697,7 @@ int run_scan(rsi_ctx* ctx, const rsi_params& P, bool use_med, const float* d_T, 
   }
   out.tmedian2 = tmedian; out.tsigma2 = tsigma; out.tlamda2 = tlamda;
   ph_q2.stop();
-  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 1, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, nullptr, &wslot, &rslot)) != RSI_OK) return rc; }
+  { Phase ph(ctx, "scan.pass"); GateShared gs(ctx); if ((rc = scan_pass(ctx, 1, d_T, d_medint, nb, RDmedian, tmedian, tlamda, Lmax, d_st2, nullptr, &wslot, &rslot, &spill2)) != RSI_OK) return rc; }
   Phase ph_seg(ctx, "scan.segments");
   GateShared gs_seg(ctx);
 
@@ -1753,7 +1775,7 @@ int rsi_hot_debug_level_sums(rsi_ctx* ctx, const float* T, const int32_t* status
 // run reaches in test time (-m 1: the stages behind the scan take the reference, and this library's host side, hours).
 int rsi_hot_debug_scan(rsi_ctx* ctx, const float* T, const int32_t* medint, int64_t nb, double RDmedian, double tmedian, double tlamda,
                        int Lmax, int32_t* status, int32_t* info /* [4]: tiles listed, trim escapes, inexact, 0 */) {
-  if (!ctx || !T || !medint || !status || nb <= 0 || nb >= (1ll << 31) - 4096 || Lmax < 1 || Lmax > kMaxL || Lmax > nb) return fail(ctx, RSI_ERR_BAD_ARG, "bad argument");
+  if (!ctx || !T || !medint || !status || nb <= 0 || nb >= (1ll << 31) - 4096 || Lmax < 1 || Lmax > kHardMaxL || Lmax > nb) return fail(ctx, RSI_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx_enter(ctx)) return RSI_ERR_HIP;
   mailbox_reset(ctx);
@@ -1779,8 +1801,9 @@ int rsi_hot_debug_scan(rsi_ctx* ctx, const float* T, const int32_t* medint, int6
   }
   const uint32_t* wslot = nullptr;
   const uint32_t* rslot = nullptr;
+  std::vector<uint32_t> spill;
   const int rc = scan_pass(ctx, 0, ctx->tnb.as<float>(), ctx->binmed.as<int32_t>(), nb, RDmedian, tmedian, tlamda, Lmax, ctx->status1.as<int32_t>(),
-                           ctx->status1f.as<int32_t>(), &wslot, &rslot);
+                           ctx->status1f.as<int32_t>(), &wslot, &rslot, &spill);
   if (rc != RSI_OK) return rc;
   HIPCHK(hipMemcpyAsync(status, ctx->status1.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(CTX_SYNC());

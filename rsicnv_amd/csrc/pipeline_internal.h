@@ -172,6 +172,7 @@ struct rsi_ctx {
   // wall-clock per pipeline phase of the last run (host view, includes waits), for bench.py
   std::vector<std::pair<const char*, double>> phases;
   // when the context belongs to a pool: arbitration of the GPU between workers
+  DevBuf scan_work_big;   // work blocks of a scan longer than kMaxL (scan_pass)
   PinBuf h_T, h_status, h_status2, h_medint;   // pinned host copies of the bin arrays (filterstatus, block tests)
   // pinned host mailbox: small transfers in both directions go through it (see copy_d2h / copy_h2d)
   char* mailbox = nullptr;
@@ -350,6 +351,7 @@ constexpr size_t kSmallBytes = kOffBreaks + 2 * 4100 * 8;
 constexpr int kMaxRegions = 4096;
 constexpr uint32_t kMaxRunEntries = 1u << 20;
 constexpr int kMaxL = kMaxScanL;
+constexpr int kHardMaxL = 1 << 22;   // the long form of the scan (pipeline.hip, run_scan) up to here
 
 struct Timer {   // optional HIP-event bracket around one launch
   rsi_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;

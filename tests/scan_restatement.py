@@ -60,21 +60,22 @@ def rsistatus_numpy(T, medint, RDmedian, tmedian, tlamda, Lmax, exact_median):
     return st
 
 
-def long_scan_case():
+def long_scan_case(nb=36_000, Lmax=10_000, plateau=(18_000, 23_000), quiet=(11_000, 30_000)):
     """Bins for one scan pass at Lmax = 10000: noise of one sigma at both ends with a short deletion and a short duplication
     (hits at 6 .. 15 bins), a quiet stretch in between with a shallow plateau of 5000 bins that only windows of about its own
     length detect (hits at 4980 .. 5020 bins: the sweep's longest prefixes, a few hundred hits instead of the millions a
-    deep event makes at this bin size).  Returns T, medint, RDmedian, tmedian, tlamda, Lmax."""
-    nb, Lmax = 36_000, 10_000
+    deep event makes at this bin size).  Returns T, medint, RDmedian, tmedian, tlamda, Lmax.
+    The arguments stretch the same picture for the scans beyond 10 400 lengths (a computed length, rsi.cpp:1286-1289)."""
     rng = np.random.default_rng(0x5CA5)
     T = np.full(nb, 40.0, dtype=np.float32)
-    noisy = np.r_[0:11_000, 30_000:nb]
+    noisy = np.r_[0:quiet[0], quiet[1]:nb]
     T[noisy] += rng.standard_normal(noisy.size).astype(np.float32)
     medint = np.full(nb, 40, dtype=np.int32)
     T[3000:3040] -= 3.0
     medint[3000:3040] = 20
     T[7000:7050] += 3.0
     medint[7000:7050] = 60
-    T[18_000:23_000] = np.float32(40.0) - np.float32(10.45 / np.sqrt(4980.0))
-    medint[18_000:23_000] = 29
+    width = plateau[1] - plateau[0]
+    T[plateau[0]:plateau[1]] = np.float32(40.0) - np.float32(10.45 / np.sqrt(width - 20.0))
+    medint[plateau[0]:plateau[1]] = 29
     return T, medint, 40.0, 40.0, 10.45, Lmax

@@ -457,6 +457,63 @@ def test_scan_of_ten_thousand_lengths(hot, oracle_cls):
     assert np.array_equal(got3, exp3) and not np.array_equal(exp3, exp)
 
 
+@pytest.mark.parametrize("nb,Lmax,plateau,quiet", [
+    (44_000, 12_000, (17_000, 28_000), (11_000, 38_000)),     # device-memory tiles behind the detection pass, beyond the resident work block
+    (64_000, 24_000, (20_000, 43_000), (11_000, 58_000)),     # no detection pass (its LDS stretch ends near 13 000), per-L counts in device memory
+    (80_000, 33_000, (22_000, 54_000), (11_000, 74_000)),     # 32-bit staged indices (the staged stretch passes 32 768 bins)
+], ids=["L12000", "L24000", "L33000"])
+@pytest.mark.timeout(1500)
+def test_scan_beyond_the_resident_length(hot, oracle_cls, nb, Lmax, plateau, quiet):
+    """a scan longer than 10 400 lengths (the reference takes Lmax = max(10000 / m, cal_max), rsi.cpp:1286-1289,
+    1830-1831: a large -threshold or a very noisy chromosome computes such a length) used to be refused.  The scan pass alone
+    (rsi_hot_debug_scan) against the restatement of rsistatus, at three lengths that each switch one more piece of the long form on."""
+    from scan_restatement import long_scan_case, rsistatus_numpy
+    T, medint, RDmedian, tmedian, tlamda, Lmax = long_scan_case(nb, Lmax, plateau, quiet)
+    exp = rsistatus_numpy(T, medint, RDmedian, tmedian, tlamda, Lmax, oracle_cls().exact_median)
+    width = plateau[1] - plateau[0]
+    first_len = -int(exp[plateau[0] + width // 2])       # the plateau is first seen by windows of about its own length (float rounding moves it a bin or two)
+    assert abs(first_len - (width - 20)) <= 3 and np.count_nonzero(exp == -first_len) > 4000 and (exp[3000:3040] < 0).all() and (exp[7000:7050] > 0).all()
+    got, info = hot.debug_scan(T, medint, RDmedian, tmedian, tlamda, Lmax)
+    assert np.array_equal(got, exp), f"{np.count_nonzero(got != exp)} bins differ; first at {np.nonzero(got != exp)[0][:5]}"
+    assert info[1] == 0 and info[2] == 0
+    assert (info[0] > 0) == (Lmax <= 13_000)      # the detection pass listed tiles where it ran
+
+
+@pytest.mark.parametrize("threshold,n,lmax", [(27.0, 1_450_001, 11_663), (46.0, 4_100_001, 33_854)], ids=["cal_max_11663", "cal_max_33854"])
+@pytest.mark.timeout(1500)
+def test_whole_run_with_a_computed_scan_length_beyond_10400(hot, hotlib, oracle_cls, threshold, n, lmax):
+    """VERDICT r4 item 8, the whole path: -MED with a large -threshold computes cal_max = (4 threshold)^2 (rsi.cpp:1286-1289 in
+    rsicnvmed's form) -- 11 663 and 33 854 lengths -- which the library used to refuse.  The events are short (30 bins of no
+    coverage, 40 bins at 1.5 x): the second pass, which drops -threshold (rsi.cpp:1462-1466) but keeps Lmax, then hits at a
+    few hundred lengths only; an event of a thousand bins would hit at every length up to Lmax and cost the reference (and
+    the oracle) hours in window medians.  Status arrays, scan parameters and calls against the oracle."""
+    import oracle
+    from rsicnv_amd import api, synth
+    m = 101
+    plan = synth.make_plan(n=n, seed=0x5CB1, model=0, mean=40.0, n_events=0, gaps=0, max_len=1000, end_n=1000)
+    fasta, depth = synth.generate_host(hotlib, plan)
+    depth = depth.copy()
+    depth[400_000:400_000 + 30 * m] = 0
+    depth[1_000_000:1_000_000 + 40 * m] = (depth[1_000_000:1_000_000 + 40 * m] * 3) // 2
+    flags = dict(m=m, trans=1, threshold=threshold)
+    O = oracle_cls()
+    O.run(oracle.make_params(**flags), depth, fasta)
+    sc = O.f64("scan_med")
+    assert int(sc[7]) == lmax
+    res = hot.run(api.make_params(**flags), depth, fasta)
+    st = res.stats
+    assert st["Lmax"] == lmax and "scan.long (Lmax > 10400)" in dict(hot.phase_times())
+    np.testing.assert_allclose([st[k] for k in ("tmedian1", "tsigma1", "tlamda1", "tmedian2", "tsigma2", "tlamda2")], sc[:6], rtol=1e-12)
+    assert st["trim_escapes"] == int(sc[9]) and st["inexact_sums"] == 0
+    for mine, theirs in (("status1", "med_status1"), ("status1f", "med_status1f"), ("status2", "med_status2")):
+        assert np.array_equal(hot.fetch(mine), O.i32(theirs)), mine
+    assert np.count_nonzero(O.i32("med_status2")) > 50
+    for which, exp in (("segs", O.calls("segs_med")), ("calls_raw", O.calls("calls_raw")), ("calls", O.calls("calls"))):
+        ok, why = calls_equal(res.calls(which), exp)
+        assert ok, f"{which}: {why}"
+    assert len(res.calls("calls")) >= 1
+
+
 def test_many_n_runs(hot, hotlib, oracle_cls):
     """About a thousand N runs (2000 run boundaries: more than the 1024 the first round trip brings back): regions,
     compaction and calls against the oracle."""
