@@ -827,8 +827,33 @@ struct PerBase {
   size_t res_vals = 0;               // values covered by the residue-class histogram
   std::vector<uint32_t> hres_all;    // BinAccum header + [value][MAD residue class] counts of the compacted depth
   double RDmedian = 0;
+  bool host_stats = false;           // depths of 65 536 and more in the compacted array: the statistics came from the array itself
+  double mads[31] = {};              // ... and so did the 31 subsamples' MADs (bin_level_stages)
 };
 constexpr size_t kResHead = 256;     // BinAccum sits in a header of the residue-class histogram: cleared and fetched with it
+
+// ---- statistics of an int32 array on the host: the slow, exact path for depths the histograms do not cover --------------------
+// The device's integer statistics are walks over directly indexed histograms of 65 536 values (kHistValues).  A chromosome
+// whose median depth lies above that (or, without a cap, any value) used to be refused; now the array itself comes to the host
+// -- 4 bytes per base over PCIe, a selection instead of a histogram walk: seconds for a large chromosome, and exact.
+// value at which the cumulated count first reaches `rank` (partition_stat_tp's walk with dy = 1, wufunctions.cpp:398-420, as
+// hist_quantiles_int restates it): the rank-th smallest, the minimum for rank 0 or when all values are equal
+static double rank_value_i32(std::vector<int32_t>& v, uint64_t rank) {
+  if (v.empty()) return 0.0;
+  const auto mm = std::minmax_element(v.begin(), v.end());
+  const int32_t lo = *mm.first, hi = *mm.second;
+  if ((double)hi - (double)lo < 1.0 || rank == 0) return (double)lo;
+  const size_t k = (size_t)std::min<uint64_t>(rank, v.size()) - 1;
+  std::nth_element(v.begin(), v.begin() + k, v.end());
+  return (double)v[k];
+}
+// the device array d_src[0 .. n) on the host
+static int fetch_i32(rsi_ctx* ctx, const int32_t* d_src, int64_t n, std::vector<int32_t>& out) {
+  out.resize((size_t)n);
+  HIPCHK(hipMemcpyAsync(out.data(), d_src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(CTX_SYNC());
+  return RSI_OK;
+}
 
 // The GC-rescaled int32 array (what the reference leaves in RD after checkgccontent, gccontent.cpp:95): the run streams the
 // byte copy and never writes it, so it is built when somebody asks -- rsi_hot_fetch("rd_gc"), or K4 on the configurations K4'
@@ -1132,10 +1157,19 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   if (want_cap) {
     if (aux.negatives) return fail(ctx, RSI_ERR_UNSUPPORTED, "negative depth values");
     if (vm.inrange + aux.big != (uint64_t)n) return fail(ctx, RSI_ERR_INTERNAL, "value histogram does not add up to n");
-    if ((uint64_t)n / 2 > vm.inrange) return fail(ctx, RSI_ERR_UNSUPPORTED, "median depth above 65535");
     rsih::Quantiles q;   // hist_quantiles_int's result for the median (hostmath.h), from the device's walk
     q.med = (double)vm.lo;
     if (vm.lo <= vm.hi && (double)vm.hi - (double)vm.lo >= 1.0 && vm.med >= 0) q.med = (double)vm.med;
+    if ((uint64_t)n / 2 > vm.inrange) {
+      // the median lies above the histogram's 65 536 values (loaddata.cpp:233 takes it from the whole rescaled array): from the
+      // array itself -- the rescaled int32 array the deep-coverage pass left, or the raw depth under -NOGC
+      Phase ph_m(ctx, "a4.median on the host (depth > 65535)");
+      if (P.gcadjust) { const int rcm = materialize_rd_gc(ctx); if (rcm != RSI_OK) return rcm; }
+      std::vector<int32_t> all;
+      const int rcf = fetch_i32(ctx, P.gcadjust ? ctx->rd_gc.as<int32_t>() : d_depth, n, all);
+      if (rcf != RSI_OK) return rcf;
+      q.med = rank_value_i32(all, (uint64_t)n / 2);
+    }
     S.cap_median = q.med;
     capval = (int32_t)(q.med * P.cap);   // RD[i] = RDmedian*cap, truncated (loaddata.cpp:238)
   }
@@ -1283,7 +1317,29 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   if (exp_slot) memcpy(hres_all.data(), exp_slot, exp_bytes);
   memcpy(&bacc, hres_all.data(), sizeof(bacc));
   const uint32_t* hres = hres_all.data() + kResHead / 4;
-  if (bacc.big) return fail(ctx, RSI_ERR_UNSUPPORTED, "depth values above 65535 without a cap");
+  if (bacc.big) {
+    // Compacted depths of 65 536 and more (no cap, or a cap above that: a median depth beyond 16 000 at -cap 4) are not in the
+    // residue-class histogram.  The statistics it serves -- chromosome median and SD (rsi.cpp:2202-2203), the 31 subsamples' MADs
+    // (rsi.cpp:1127-1143) -- come from the compacted array itself, on the host.
+    Phase ph_h(ctx, "a6.statistics on the host (depth > 65535)");
+    if (ctx->rdc_is_bytes) return fail(ctx, RSI_ERR_INTERNAL, "values beyond the histogram on the byte path");
+    std::vector<int32_t> rd;
+    const int rcf = fetch_i32(ctx, ctx->rdc.as<int32_t>(), ncompact, rd);
+    if (rcf != RSI_OK) return rcf;
+    S.RDsd = sqrt(rsih::variance_pop(rd.data(), (size_t)ncompact));   // the reference's own loop: double sums in index order (wufunctions.cpp:766-809)
+    const uint64_t sublen = (uint64_t)(ncompact / 31);
+    std::vector<int32_t> sub((size_t)sublen);
+    std::vector<int32_t> sorted = rd;
+    const double RDmed = rank_value_i32(sorted, (uint64_t)ncompact / 2);
+    for (int j = 0; j < 31 && sublen > 0; ++j) {
+      for (uint64_t k = 0; k < sublen; ++k) sub[(size_t)k] = (int)fabs((float)rd[(size_t)(j + 31 * k)] - RDmed);   // rsi.cpp:1134
+      pb.mads[j] = rank_value_i32(sub, sublen / 2);
+    }
+    S.RDmedian = RDmed;
+    pb.host_stats = true;
+    pb.ncompact = ncompact; pb.nb = nb; pb.res_vals = 0; pb.RDmedian = RDmed;
+    return RSI_OK;
+  }
   // chromosome median / SD (rsi.cpp:2202-2203)
   std::vector<uint64_t> hall(res_vals, 0);
   for (size_t v = 0; v < res_vals; ++v) for (int c = 0; c < kResClasses; ++c) hall[v] += hres[v * kResClasses + c];
@@ -1325,6 +1381,7 @@ int bin_level_stages(rsi_ctx* ctx, const rsi_params& P, int64_t n, rsi_result* r
     const uint64_t sublen = (uint64_t)(ncompact / 31);
     if (sublen == 0) return fail(ctx, RSI_ERR_TOO_SMALL, "fewer than 31 bases");
     for (int j = 0; j < 31; ++j) {
+      if (pb.host_stats) { mads[j] = pb.mads[j]; continue; }
       std::vector<uint64_t> hd(res_vals + 1, 0);
       for (size_t v = 0; v < res_vals; ++v) {
         const uint32_t c = hres[v * kResClasses + j];

@@ -533,6 +533,43 @@ def test_many_n_runs(hot, hotlib, oracle_cls):
         assert ok, f"{which}: {why}"
 
 
+@pytest.mark.parametrize("flags", [dict(), dict(gcadjust=0), dict(cap=-1.0), dict(m=51, trans=1)], ids=["default", "nogc", "nocap", "m51_med"])
+def test_median_depth_beyond_65535(hot, hotlib, oracle_cls, flags):
+    """a chromosome whose median depth lies above the 65 536 values of the device's integer histograms (here
+    about 120 000) used to be refused.  The cap median (loaddata.cpp:233), the chromosome median / SD (rsi.cpp:2202-2203) and
+    the MAD subsamples (rsi.cpp:1127-1143) then come from the arrays themselves on the host; everything else takes the
+    deep-coverage kernels.  All stages against the oracle."""
+    import oracle
+    from rsicnv_amd import api
+    _, fasta, depth = make_case(hotlib, dict(n=1_200_007, seed=0xDEEA, model=0, n_events=6, gaps=1, max_len=40000, end_n=4000, gap_len=9000))
+    fill = np.random.default_rng(0xDEEA).integers(0, 4000, size=depth.size, dtype=np.int32)
+    depth = np.where(depth > 0, depth * 4000 + fill, 0).astype(np.int32)
+    assert np.median(depth[depth > 0]) > 100_000
+    O = oracle_cls()
+    O.run(oracle.make_params(**flags), depth, fasta)
+    res = hot.run(api.make_params(**flags), depth, fasta)
+    st = res.stats
+    phases = dict(hot.phase_times())
+    assert "a6.statistics on the host (depth > 65535)" in phases
+    assert ("a4.median on the host (depth > 65535)" in phases) == (flags.get("cap", 4.0) > 1)
+    if flags.get("gcadjust", 1):
+        assert np.array_equal(hot.fetch("rd_gc"), O.i32("rd_gc"))
+    assert np.array_equal(hot.fetch("rd_concat"), O.i32("rd_concat"))
+    assert st["RDmedian"] == O.f64("chrom")[0] and st["RDsd"] == O.f64("chrom")[1]
+    if flags.get("cap", 4.0) > 1:
+        assert st["cap_median"] == O.f64("chrom")[2] > 65535
+    assert np.array_equal(hot.fetch("binmedint"), O.i32("binmedint"))
+    nbs = O.f64("nb")
+    assert st["nb_mad"] == nbs[1] and st["nb_r"] == nbs[2]
+    pre = "med" if flags.get("trans", 0) == 1 else "nb"
+    for mine, theirs in (("status1", f"{pre}_status1"), ("status1f", f"{pre}_status1f"), ("status2", f"{pre}_status2")):
+        assert np.array_equal(hot.fetch(mine), O.i32(theirs)), mine
+    for which in ("blocks", "calls_raw", "calls"):
+        ok, why = calls_equal(res.calls(which), O.calls(which))
+        assert ok, f"{which}: {why}"
+    assert len(res.calls("calls")) >= 1
+
+
 @pytest.mark.gpu
 def test_deep_coverage_sends_tests_to_the_host_walk(hot, hotlib, oracle_cls):
     """At 12000x the values of a candidate span more integer buckets than the device
