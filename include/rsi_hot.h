@@ -32,7 +32,7 @@ typedef enum rsi_status {
   RSI_ERR_BAD_ARG = -2,
   RSI_ERR_HIP = -3,          /* a HIP runtime call failed */
   RSI_ERR_TOO_SMALL = -4,    /* chromosome shorter than 20*202 bases under GC adjust (gccontent.cpp:66-71) */
-  RSI_ERR_UNSUPPORTED = -5,  /* e.g. negative depth, Lmax beyond the LDS tile, N-run list overflow */
+  RSI_ERR_UNSUPPORTED = -5,  /* e.g. negative depth, a scan longer than 4 M lengths, N-run list overflow */
   RSI_ERR_INTERNAL = -6
 } rsi_status;
 

@@ -482,9 +482,8 @@ def test_scan_beyond_the_resident_length(hot, oracle_cls, nb, Lmax, plateau, qui
 @pytest.mark.parametrize("threshold,n,lmax", [(27.0, 1_450_001, 11_663), (46.0, 4_100_001, 33_854)], ids=["cal_max_11663", "cal_max_33854"])
 @pytest.mark.timeout(1500)
 def test_whole_run_with_a_computed_scan_length_beyond_10400(hot, hotlib, oracle_cls, threshold, n, lmax):
-    """VERDICT r4 item 8, the whole path: -MED with a large -threshold computes cal_max = (4 threshold)^2 (rsi.cpp:1286-1289 in
-    rsicnvmed's form) -- 11 663 and 33 854 lengths -- which the library used to refuse.  The events are short (30 bins of no
-    coverage, 40 bins at 1.5 x): the second pass, which drops -threshold (rsi.cpp:1462-1466) but keeps Lmax, then hits at a
+    """VERDICT r4 item 8, the whole path: -MED with a large -threshold computes cal_max = (4 threshold)^2 (rsi.cpp:1432-1433) -- 11 663 and 33 854 lengths -- which the library used to refuse.  The events are short (30 bins of no
+    coverage, 40 bins at 1.5 x): the second pass, which drops -threshold (rsi.cpp:1457-1469) but keeps Lmax, then hits at a
     few hundred lengths only; an event of a thousand bins would hit at every length up to Lmax and cost the reference (and
     the oracle) hours in window medians.  Status arrays, scan parameters and calls against the oracle."""
     import oracle
