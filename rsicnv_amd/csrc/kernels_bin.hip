@@ -1247,6 +1247,7 @@ __global__ __launch_bounds__(kThreads) void k_best_subsegment(const SegItem* __r
 
 }  // namespace
 
+static int bounded_grid(int64_t n, int per_block, int cap) { const int g = grid_for(n, per_block); return g > cap ? cap : g; }
 void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, double r, float* raw, uint32_t* rawmin_bits,
                    hipStream_t stream) {
   int grid = grid_for(nb, kThreads * 4);
@@ -1256,12 +1257,14 @@ void launch_nb_raw(const int64_t* binsum, int64_t nb, int m, int64_t ncompact, d
 void launch_nb_scale_minmax(float* x, int64_t nb, const uint32_t* rawmin_bits, double med_raw, double del_raw, double dup_raw,
                             double RDmedian, const GridChain& c, GridMedian* out, hipStream_t stream) {
   NbLevels lv{med_raw, del_raw, dup_raw, RDmedian};
-  RSI_LAUNCH(k_nb_scale_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, x, nb, rawmin_bits, lv, c.mm, c.counters, c.cap,
+  // a bounded grid: every workgroup ends in three atomics on the same words (min, max, arrival); 2400 workgroups for the bins of a
+  // 250 Mb chromosome spent 170 of the kernel's 180 us queueing there (9 us for the 590 of a 60 Mb one)
+  RSI_LAUNCH(k_nb_scale_mm, dim3(bounded_grid(nb, kThreads * 4, 512)), dim3(kThreads), 0, stream, x, nb, rawmin_bits, lv, c.mm, c.counters, c.cap,
                      c.hist, out);
 }
 void launch_i32_to_f32_minmax(const int32_t* in, float* out_f, int64_t nb, double center, const GridChain& c, GridMedian* out,
                               hipStream_t stream) {
-  RSI_LAUNCH(k_i32_to_f32_mm, dim3(grid_for(nb, kThreads * 4)), dim3(kThreads), 0, stream, in, out_f, nb, center, c.mm, c.counters, c.cap,
+  RSI_LAUNCH(k_i32_to_f32_mm, dim3(bounded_grid(nb, kThreads * 4, 512)), dim3(kThreads), 0, stream, in, out_f, nb, center, c.mm, c.counters, c.cap,
                      c.hist, out);
 }
 void launch_minmax_f32(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, MinMaxF* mm,
@@ -1280,7 +1283,7 @@ void launch_hist_f32(const float* x, const int32_t* mask, int64_t nb, int use_ab
 }
 void launch_minmax_plan(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,
                         const GridChain& c, GridMedian* out, hipStream_t stream) {
-  RSI_LAUNCH(k_minmax_plan, dim3(grid_for(nb, kThreads * 16)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, d_center, c.mm,
+  RSI_LAUNCH(k_minmax_plan, dim3(bounded_grid(nb, kThreads * 16, 256)), dim3(kThreads), 0, stream, x, mask, nb, use_abs, center, d_center, c.mm,
                      c.counters, c.cap, c.hist, out);
 }
 void launch_hist_walk(const float* x, const int32_t* mask, int64_t nb, int use_abs, double center, const double* d_center,

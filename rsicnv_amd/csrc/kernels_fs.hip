@@ -78,10 +78,40 @@ __device__ inline StepFn fs_step(float x, int ue) {
   return f;
 }
 
-// Pass 1: per chunk, the exact-enough double sum and the count of the unmarked bins, the count of the marked ones.
+// Exclusive prefixes over the chunks' sums and marked counts, by one workgroup (the launch's last one to finish: the values were
+// written by the others with write-through stores and are read past this CU's cache).
+__device__ inline void fs_chunk_scan_block(double* __restrict__ csum, int32_t* __restrict__ cmark, int nchunks, int32_t* __restrict__ total_marked) {
+  __shared__ double s_sd[kThreads / 64];
+  __shared__ int s_sm[kThreads / 64];
+  double cd = 0.0;
+  int cm = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t0 = 0; t0 < nchunks; t0 += kThreads) {
+    const int t = t0 + (int)threadIdx.x;
+    const double v = t < nchunks ? __longlong_as_double((long long)ld_cg(reinterpret_cast<const unsigned long long*>(csum) + t)) : 0.0;
+    const int m = t < nchunks ? ld_cg(cmark + t) : 0;
+    double id = v; int im = m;   // inclusive wave scans (the double sums are bounds for the candidate binades, not results)
+    for (int d = 1; d < 64; d <<= 1) { const double ud = __shfl_up(id, d); const int um = __shfl_up(im, d); if (lane >= d) { id += ud; im += um; } }
+    __syncthreads();   // the previous batch's totals have been read
+    if (lane == 63) { s_sd[wave] = id; s_sm[wave] = im; }
+    __syncthreads();
+    double pd = 0.0, td = 0.0; int pm = 0, tm = 0;
+    for (int w = 0; w < kThreads / 64; ++w) { if (w < wave) { pd += s_sd[w]; pm += s_sm[w]; } td += s_sd[w]; tm += s_sm[w]; }
+    if (t < nchunks) {   // written through, as the values they replace were (one dirty copy of a line per launch)
+      st_cg(reinterpret_cast<unsigned long long*>(csum) + t, (unsigned long long)__double_as_longlong(cd + pd + id - v));
+      st_cg(reinterpret_cast<unsigned int*>(cmark) + t, (unsigned int)(cm + pm + im - m));
+    }
+    cd += td; cm += tm;
+  }
+  if (threadIdx.x == 0) st_cg(reinterpret_cast<unsigned int*>(total_marked), (unsigned int)cm);
+}
+
+// Pass 1: per chunk, the exact-enough double sum and the count of the unmarked bins, the count of the marked ones; the last
+// workgroup to finish turns them into exclusive prefixes (a launch of its own until round 5).
 __global__ __launch_bounds__(kThreads) void k_fs_chunk_sums(const float* __restrict__ T, const int32_t* __restrict__ status, int64_t nb,
                                                             double* __restrict__ csum, int32_t* __restrict__ cmark,
-                                                            int32_t* __restrict__ total /* [1]: values the integer-step form cannot take */) {
+                                                            int32_t* __restrict__ total /* [0]: marked bins; [1]: values the integer-step form cannot take */,
+                                                            unsigned int* __restrict__ counter) {
   __shared__ double s_d[kThreads / 64];
   __shared__ int s_m[kThreads / 64];
   const int64_t i0 = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * kPerThread;
@@ -103,33 +133,11 @@ __global__ __launch_bounds__(kThreads) void k_fs_chunk_sums(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < kThreads / 64; ++w) { acc += s_d[w]; marked += s_m[w]; }
-    csum[blockIdx.x] = acc; cmark[blockIdx.x] = marked;
+    st_cg(reinterpret_cast<unsigned long long*>(csum) + blockIdx.x, (unsigned long long)__double_as_longlong(acc));
+    st_cg(reinterpret_cast<unsigned int*>(cmark) + blockIdx.x, (unsigned int)marked);
   }
-}
-
-// Pass 2 (one workgroup): exclusive prefixes over the chunks.
-__global__ __launch_bounds__(kThreads) void k_fs_chunk_scan(double* __restrict__ csum, int32_t* __restrict__ cmark, int nchunks,
-                                                            int32_t* __restrict__ total_marked) {
-  __shared__ double s_d[kThreads / 64];
-  __shared__ int s_m[kThreads / 64];
-  double cd = 0.0;
-  int cm = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t0 = 0; t0 < nchunks; t0 += kThreads) {
-    const int t = t0 + (int)threadIdx.x;
-    const double v = t < nchunks ? csum[t] : 0.0;
-    const int m = t < nchunks ? cmark[t] : 0;
-    double id = v; int im = m;   // inclusive wave scans (the double sums are bounds for the candidate binades, not results)
-    for (int d = 1; d < 64; d <<= 1) { const double ud = __shfl_up(id, d); const int um = __shfl_up(im, d); if (lane >= d) { id += ud; im += um; } }
-    __syncthreads();   // the previous batch's totals have been read
-    if (lane == 63) { s_d[wave] = id; s_m[wave] = im; }
-    __syncthreads();
-    double pd = 0.0, td = 0.0; int pm = 0, tm = 0;
-    for (int w = 0; w < kThreads / 64; ++w) { if (w < wave) { pd += s_d[w]; pm += s_m[w]; } td += s_d[w]; tm += s_m[w]; }
-    if (t < nchunks) { csum[t] = cd + pd + id - v; cmark[t] = cm + pm + im - m; }
-    cd += td; cm += tm;
-  }
-  if (threadIdx.x == 0) total_marked[0] = cm;
+  if (!last_block_done(counter)) return;
+  fs_chunk_scan_block(csum, cmark, (int)gridDim.x, total);
 }
 
 // Pass 3: per chunk, the step functions of its unmarked bins for the two candidate binades of the sum that reaches it, and
@@ -410,8 +418,7 @@ void launch_level_sums(const float* T, const int32_t* status, int64_t nb, int Lm
   int32_t* cmark = reinterpret_cast<int32_t*>(p); p += ((size_t)nchunks * 4 + 15) & ~size_t(15);
   int32_t* clist_s = reinterpret_cast<int32_t*>(p); p += (size_t)clist_cap * 4;
   float* clist_t = reinterpret_cast<float*>(p);
-  RSI_LAUNCH(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total);
-  RSI_LAUNCH(k_fs_chunk_scan, dim3(1), dim3(kThreads), 0, stream, csum, cmark, nchunks, total);
+  RSI_LAUNCH(k_fs_chunk_sums, dim3(nchunks), dim3(kThreads), 0, stream, T, status, nb, csum, cmark, total, counter);   // (the counter is back at zero when the launch ends)
   RSI_ALLOW_FULL_LDS(k_fs_chunk_fns);   // (2 Lmax + 1) * 4 bytes: 80 KB at -m 1
   RSI_LAUNCH(k_fs_chunk_fns, dim3(nchunks), dim3(kThreads), (size_t)(2 * Lmax + 1) * 4, stream, T, status, nb, csum, cmark, fns, clist_s, clist_t, clist_cap, Lmax, level_count);
   RSI_LAUNCH(k_fs_level_sums, dim3((2 * Lmax + 1 + kThreads / 64 - 1) / (kThreads / 64) + 1), dim3(kThreads), 0, stream, T, status, nb, nchunks, fns, clist_s, clist_t, total, level_count,

@@ -40,8 +40,8 @@ constexpr int kS4Sub = 2048;                    // compacted positions per wave 
                                                 // addresses -- was more instructions than the bases' own)
 constexpr int kS4GcWords = 38;                  // staged mask words per wave: (63 + 2048 + 201 + 32) / 64 + 1 = 37, + 1 that stays zero
 constexpr int kS4Cols = 64;                     // columns of the LDS histogram while the value range is <= 128 (see below)
-constexpr int kS4Grid = 256 * 4;
-constexpr int kS4MaxTrips = 20;                 // sub-tiles per wave the marks in LDS have room for: 268 Mb with 8192 waves (longer chromosomes: K4j)
+constexpr int kS4Grid = 256 * 3, kS4GridLong = 256 * 4;
+constexpr int kS4MaxTrips = 20;                 // sub-tiles per wave the marks in LDS have room for: 335 Mb with 8192 waves (longer chromosomes: K4j)
 constexpr int kM4Threads = 256;
 constexpr int kM4Grid = 256 * 8;
 #ifndef K4S_ABL
@@ -604,7 +604,14 @@ static int k4s_vr(int32_t capval) {
 static int k4s_grid(int64_t ncompact) {
   const int64_t nsub = (ncompact + kS4Sub - 1) / kS4Sub;
   int64_t g = (nsub + kS4Waves - 1) / kS4Waves;
-  g = g < 1 ? 1 : (g > kS4Grid ? kS4Grid : g);
+  // Three workgroups per CU are resident (80 registers: six waves per SIMD), so 768 workgroups are one round of the chip; a
+  // fourth per CU would wait for a slot -- and so would every small kernel of the pool's other chromosomes, behind it (768
+  // against 1024: the same time alone, 2 % on the pooled step).  Chromosomes too long for twenty trips per wave take 1024.
+  const char* ge = getenv("RSI_HOT_K4S_GRID");   // (timing runs)
+  const int gv = ge ? atoi(ge) : 0;
+  int cap = gv >= 64 && gv <= 4096 ? gv : kS4Grid;
+  if (!gv && (nsub + (int64_t)cap * kS4Waves - 1) / ((int64_t)cap * kS4Waves) > kS4MaxTrips) cap = kS4GridLong;
+  g = g < 1 ? 1 : (g > cap ? cap : g);
   return (int)g;
 }
 

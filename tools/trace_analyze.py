@@ -65,7 +65,7 @@ if gaps:
     q = lambda f: gaps[min(len(gaps) - 1, int(f * len(gaps)))]
     print(f"{len(byq)} queues; {pairs} consecutive pairs, {over} where the next kernel's start precedes the previous one's end; gap end -> next start (us): "
           f"p10 {q(0.1):.1f} p50 {q(0.5):.1f} p90 {q(0.9):.1f} mean {sum(gaps)/len(gaps):.1f}")
-    for nm in ("k_trim_runs", "k_fs_chunk_scan", "k_run_prefix", "k_hist_walk", "k_minmax_plan", "k_n_transitions", "k_gc_joint_hist", "k_rescale_compact_bin8"):
+    for nm in ("k_trim_runs", "k_fs_chunk_sums", "k_run_prefix", "k_hist_walk", "k_minmax_plan", "k_n_transitions", "k_gc_joint_hist", "k_rescale_compact_bin8"):
         if small[nm]:
             g = sorted(x[0] for x in small[nm]); d = sorted(x[1] for x in small[nm])
             print(f"  {nm:26s} gap before: p50 {g[len(g)//2]:7.1f} us   duration: p50 {d[len(d)//2]:7.1f} us  (n={len(g)})")
