@@ -119,7 +119,9 @@ size_t gc_rescale_slab_bytes(int64_t n);   // scratch for the per-workgroup hist
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
-                       hipStream_t stream, uint8_t* out8 = nullptr);
+                       hipStream_t stream, uint8_t* out8 = nullptr,
+                       PhaseParams* pp = nullptr /* the launch's last workgroup leaves the cap there (median x cap_mult, or -1) for a K4 queued behind it */,
+                       double cap_mult = 0.0);
 // Only the rescaled array: out[] as the launch above leaves it, nothing else touched (rsi_hot_fetch of "rd_gc" when the run
 // itself streamed the byte copy and never wrote the int32 array).
 void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, int32_t* out,

@@ -652,14 +652,15 @@ __device__ inline void publish_hist_hi(int lane_hi, ValueHistAux* __restrict__ a
 // write-back, the walk to the median apply_cap needs (loaddata.cpp:233), and the chromosome's header (GC accumulators,
 // counters, median, the first N-run entries) into mapped host memory: what used to be three launches and a device -> host
 // copy behind the kernel.  All threads of every workgroup call it.
-template <bool ADJUST>
+template <bool ADJUST, bool WITH_CAP = false>
 __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __restrict__ depth, const uint64_t* __restrict__ gcbits,
                                          int64_t n, const double* __restrict__ table, int32_t* __restrict__ out,
                                          uint32_t* __restrict__ ghist, ValueHistAux* __restrict__ aux,
                                          unsigned int* __restrict__ hist_slabs, unsigned int* __restrict__ gsum, int per_group,
                                          unsigned int* __restrict__ counters, ValueMedian* __restrict__ vm, const void* head_src,
                                          void* head_dst, unsigned int head_bytes, int vb = 0 /* first value of the LDS window */,
-                                         int width = kValLds, int phsh = 5) {
+                                         int width = kValLds, int phsh = 5, PhaseParams* __restrict__ pp = nullptr /* the cap for a K4 queued behind this launch */,
+                                         double cap_mult = 0.0) {
   const int phases = 1 << phsh;
   unsigned int mine[kDeepWidth / kThreads];   // all reads of the [value][phase] counters come before the first write of a total
 #pragma unroll
@@ -688,6 +689,18 @@ __device__ inline void value_hist_finish(unsigned int* s_hist, const int32_t* __
     range = range < vb + width ? vb + width : range;
     range = (range + kThreads - 1) / kThreads * kThreads;
     value_median_block<kThreads>(ghist, (unsigned long long)n, vm, range > kHistValues ? kHistValues : range);
+  }
+  sync_drained();
+  if (WITH_CAP && pp && threadIdx.x == 0) {
+    // the cap as apply_cap takes it (loaddata.cpp:233-238), as K2j's tail leaves it: for a K4s / K4m queued right behind this launch
+    // (-NOGC); the host derives the same number from the header and checks everything else
+    const int lo = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->lo)), hi = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->hi));
+    const int med = (int)ld_cg(reinterpret_cast<const unsigned int*>(&vm->med));
+    double qm = (double)lo;
+    if (lo <= hi && (double)hi - (double)lo >= 1.0 && med >= 0) qm = (double)med;
+    const unsigned long long inr = ld_cg(&vm->inrange);
+    const bool ok = cap_mult > 1.0 && inr + ld_cg(&aux->big) == (unsigned long long)n && (unsigned long long)n / 2 <= inr && ld_cg(&aux->negatives) == 0u;
+    st_cg(reinterpret_cast<unsigned int*>(&pp->capval), (unsigned int)(ok ? (int32_t)(qm * cap_mult) : -1));
   }
   sync_drained();
   export_words(head_dst, head_src, head_bytes);
@@ -1404,9 +1417,13 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
                                                          int per_group, unsigned int* __restrict__ counters,
                                                          ValueMedian* __restrict__ vm, const void* head_src, void* head_dst,
                                                          unsigned int head_bytes, int materialize /* 1: only out[] is produced */,
-                                                         uint8_t* __restrict__ out8 /* optional: the values as bytes, saturated at kByteSat (-NOGC: what K4' compacts) */) {
+                                                         uint8_t* __restrict__ out8 /* optional: the values as bytes, saturated at kByteSat (-NOGC: what K4' compacts) */,
+                                                         PhaseParams* __restrict__ pp /* optional: the cap for a K4 queued behind this launch */, double cap_mult) {
   __shared__ GcTile gt;
   __shared__ __align__(16) unsigned char s_g[ADJUST ? kTileBases : 16];
+  if (pp && blockIdx.x == 0 && threadIdx.x == 0) {   // until the median is known (and when it will not be: the queued K4 then declines)
+    st_cg(reinterpret_cast<unsigned int*>(&pp->capval), 0xffffffffu); st_cg(reinterpret_cast<unsigned int*>(&pp->redo), 0u);
+  }
   __shared__ double s_table[kGcLevels];
   __shared__ unsigned int s_hist[kValLds * 32];
   for (int e = threadIdx.x; e < kValLds * 32; e += kThreads) s_hist[e] = 0;
@@ -1485,7 +1502,7 @@ __global__ __launch_bounds__(kThreads) void k_gc_rescale(const int32_t* __restri
   }
   if (materialize) return;   // the tail quirks are applied to out[] by a launch of their own (k_gc_tail_fixup_out)
   publish_hist_hi(lane_hi, aux);
-  value_hist_finish<ADJUST>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, vb, width, phsh);
+  value_hist_finish<ADJUST, true>(s_hist, depth, gcbits, n, table, out, ghist, aux, hist_slabs, gsum, per_group, counters, vm, head_src, head_dst, head_bytes, vb, width, phsh, pp, cap_mult);
 }
 
 
@@ -2741,7 +2758,7 @@ __global__ void k_gc_tail_fixup_out(const int32_t* __restrict__ depth, const uin
 void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table,
                        int adjust, int32_t* out, uint32_t* hist, ValueHistAux* aux, void* slabs, void* gsum,
                        unsigned int* counters, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
-                       hipStream_t stream, uint8_t* out8) {
+                       hipStream_t stream, uint8_t* out8, PhaseParams* pp, double cap_mult) {
   const int grid = grid_for(n, kTileBases);
   const dim3 g(grid), b(kThreads);
   unsigned int* sl = static_cast<unsigned int*>(slabs);
@@ -2750,9 +2767,9 @@ void launch_gc_rescale(const int32_t* depth, const uint64_t* gcbits, int64_t n, 
   // adjust = 1 (rescaled array + histogram in one pass) is the deep-coverage path; adjust = 0, out = NULL the -NOGC histogram.
   // The tail cells of out[] get their quirks from a launch of their own (see k_gc_tail_fixup_out).
   if (adjust) {
-    RSI_LAUNCH(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, static_cast<uint8_t*>(nullptr));
+    RSI_LAUNCH(k_gc_rescale<true>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, static_cast<uint8_t*>(nullptr), pp, cap_mult);
     if (out) RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
-  } else RSI_LAUNCH(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, out8);
+  } else RSI_LAUNCH(k_gc_rescale<false>, g, b, 0, stream, depth, gcbits, n, n / 64 + 1, table, out, hist, aux, sl, gs, pg, counters, vm, head_src, head_dst, (unsigned int)head_bytes, 0, out8, pp, cap_mult);
 }
 // The tail quirks in out[] as a launch of its own: the cells it rewrites were written by other workgroups of the streaming
 // launch, and two stores to one address from different XCDs within one launch have no defined order.
@@ -2764,7 +2781,7 @@ void launch_gc_materialize(const int32_t* depth, const uint64_t* gcbits, int64_t
                            unsigned int* counter, hipStream_t stream) {
   const int grid = grid_for(n, kTileBases);
   RSI_LAUNCH(k_gc_rescale<true>, dim3(grid), dim3(kThreads), 0, stream, depth, gcbits, n, n / 64 + 1, table, out, nullptr, nullptr, nullptr,
-                     nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1, static_cast<uint8_t*>(nullptr));
+                     nullptr, 1, counter, nullptr, nullptr, nullptr, 0u, 1, static_cast<uint8_t*>(nullptr), static_cast<PhaseParams*>(nullptr), 0.0);
   RSI_LAUNCH(k_gc_tail_fixup_out, dim3(1), dim3(64), 0, stream, depth, gcbits, n, table, out);
 }
 static int value_hist8_grid(int64_t n) {

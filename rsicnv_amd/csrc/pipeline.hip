@@ -922,6 +922,8 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // the three-pass chain (K2, K3', K4'), which is also where a chromosome goes whose joint counters wrapped.
   const char* joint_env = getenv("RSI_HOT_JOINT");
   const bool joint = P.gcadjust && want_cap && !(joint_env && atoi(joint_env) == 0);
+  // -NOGC with a cap: the histogram pass leaves the depth as bytes and (round 5) the cap on the device, so that K4s / K4m can be queued behind it
+  const bool nogc_bytes = !P.gcadjust && want_cap && !(getenv("RSI_HOT_NOGC_BYTES") && atoi(getenv("RSI_HOT_NOGC_BYTES")) == 0);
   // one buffer: the folded pair counters (cleared by K1) | the workgroups' escape lists | the levels' fixed-point ratios for K4j
   const size_t joint_list_off = (gc_joint_totals_bytes() + 255) & ~size_t(255), joint_lut_off = joint_list_off + ((gc_joint_esc_list_bytes() + 255) & ~size_t(255));
   if (joint) HIPCHK(ctx->joint_tot.ensure(joint_lut_off + (size_t)kGcLevels * 4 + 64));
@@ -944,7 +946,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   PhaseParams* d_pp = reinterpret_cast<PhaseParams*>(small + kOffPhase);
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, n, std::max(50, P.m / 4), joint ? d_pp : nullptr, d_cbreak, d_cum, d_done + 4 * kDoneStride + 8, st); }
+  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, n, std::max(50, P.m / 4), (joint || nogc_bytes) ? d_pp : nullptr, d_cbreak, d_cum, d_done + 4 * kDoneStride + 8, st); }
   constexpr uint32_t kEagerRuns = 1024;
   uint32_t n_trans = 0;
   std::vector<uint64_t> trans_raw(kEagerRuns);
@@ -984,8 +986,10 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   // K4 as three launches (kernels_k4s.hip: streaming half at eight waves per SIMD, the odd chunks exactly, the bin medians without
   // LDS) wherever K2j's verified ratios exist; RSI_HOT_K4SPLIT=0: K4j, the one-kernel form
   const bool k4_split = !(getenv("RSI_HOT_K4SPLIT") && atoi(getenv("RSI_HOT_K4SPLIT")) == 0);
-  const bool spec = joint && !(spec_env && atoi(spec_env) == 0) && !k4j_fix_off && ctx->spec_capval >= 1 && ctx->spec_m == P.m && ctx->spec_cap == (double)P.cap &&
-                    cap_compact8_applies(P.m, ctx->spec_capval);
+  const bool spec_ok = !(spec_env && atoi(spec_env) == 0) && ctx->spec_capval >= 1 && ctx->spec_m == P.m && ctx->spec_cap == (double)P.cap &&
+                       ctx->spec_gc == (P.gcadjust != 0) && cap_compact8_applies(P.m, ctx->spec_capval);
+  const bool spec_nogc = nogc_bytes && spec_ok && k4_split && rescale_compact_split_applies(P.m, ctx->spec_capval, n, 0);   // (the split form only)
+  const bool spec = (joint && spec_ok && !k4j_fix_off) || spec_nogc;
   constexpr uint32_t kSpecMagic = 0x5bec5bec;
   uint32_t* spec_slot = nullptr;
   size_t spec_bytes = 0;
@@ -1004,6 +1008,15 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     K4Regions none;
     memset(&none, 0, sizeof(none));
     Timer t(ctx, "cap_compact_bin", true);
+    if (spec_nogc) {   // -NOGC: the bytes are the values (no ratios, no escapes: the histogram pass saturates them at 254, above any cap of this path)
+      launch_rescale_compact_stream(ctx->rescaled8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, d_cbreak, d_cum, none, 0, n, guess, P.m,
+                                    ctx->rdc8.as<uint8_t>(), reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p,
+                                    d_done + 2 * kDoneStride, ctx->hist_res.p, spec_slot, spec_bytes, nullptr, nullptr, d_pp, st);
+      t.~Timer();
+      new (&t) Timer(ctx, "bin_median", true);
+      launch_bin_median8(ctx->rdc8.as<uint8_t>(), n, guess, P.m, ctx->binmed.as<int32_t>(), ctx->binsum.as<int64_t>(), d_pp, st);
+      return RSI_OK;
+    }
     if (k4_split && rescale_compact_split_applies(P.m, guess, n, 0)) {
       launch_rescale_compact_stream(ctx->depth8.as<uint8_t>(), d_depth, ctx->gcbits.as<uint64_t>(), n, d_table, d_cbreak, d_cum, none, 0, n, guess, P.m,
                                     ctx->rdc8.as<uint8_t>(), reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->hist_res.p) + kResHead), ctx->slabs.p,
@@ -1033,7 +1046,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
       // instead of 4 + 4 (loaddata.cpp:229-240, 48-85 without gccontent.cpp in front)
       HIPCHK(ctx->slabs.ensure(gc_rescale_slab_bytes(n)));
       HIPCHK(ctx->rescaled8.ensure((size_t)n + 2048));
-      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st, ctx->rescaled8.as<uint8_t>()); }
+      { Timer t(ctx, "value_hist", true); launch_gc_rescale(d_depth, ctx->gcbits.as<uint64_t>(), n, nullptr, 0, nullptr, ctx->hist_val.as<uint32_t>(), d_aux, ctx->slabs.p, ctx->gsum.p, d_done + kDoneStride, d_vm, small, head, head_bytes, st, ctx->rescaled8.as<uint8_t>(), nogc_bytes ? d_pp : nullptr, (double)P.cap); }
     } else {
       HIPCHK(copy_d2h(ctx, head, small, head_bytes));   // no kernel behind K1b to hand the header over: a plain copy
     }
@@ -1218,7 +1231,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     while (vr_g < 256 && vr_g <= ctx->spec_capval) vr_g <<= 1;
     while (vr_c < 256 && vr_c <= capval) vr_c <<= 1;
     const bool ran = spec_slot[3] != kSpecMagic;
-    spec_done = ran && joint_ok && !deep && !jinfo.esc_pending && hpp.regions_ok == 1 && hpp.capval == capval && hpp.nreg == (int32_t)noncode.size() &&
+    spec_done = ran && (P.gcadjust ? (joint_ok && !deep && !jinfo.esc_pending) : spec_nogc) && hpp.regions_ok == 1 && hpp.capval == capval && hpp.nreg == (int32_t)noncode.size() &&
                 hpp.ncompact == ncompact && cap_compact8_applies(P.m, capval) && vr_g == vr_c && (ctx->spec_capval <= 127) == (capval <= 127) &&
                 (int)noncode.size() <= kMaxRegions;
     if (ran && !spec_done) HIPCHK(hipMemsetAsync(ctx->hist_res.p, 0, kResHead + (size_t)256 * kResClasses * 4, st));   // it added its histogram to the rows: clean again
@@ -1227,6 +1240,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   uint32_t* exp_slot = spec_done ? spec_slot : (exp_bytes <= kMailboxMaxCopy ? static_cast<uint32_t*>(mb_alloc(ctx, exp_bytes)) : nullptr);
   if (spec_done) {
     ctx->rdc_is_bytes = true;   // all done by the queued launch
+    if (!P.gcadjust) ctx->phases.push_back({"a5.nogc byte path", 1.0});
   } else if (P.gcadjust && want_cap && !deep && cap_compact8_applies(P.m, capval)) {
     // K4': from the byte copy of the raw depth, rescaling on the way -- the rescaled int32 array is never written or read
     HIPCHK(ctx->slabs.ensure(cap_compact8_slab_bytes(P.m, capval, ncompact)));
@@ -1313,7 +1327,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   std::vector<uint32_t> hres_all(kResHead / 4 + res_vals * kResClasses);
   if (!exp_slot) HIPCHK(copy_d2h(ctx, hres_all.data(), ctx->hist_res.p, hres_all.size() * 4));
   if (!spec_done) HIPCHK(CTX_SYNC());
-  if (joint_ok && want_cap && cap_compact8_applies(P.m, capval)) { ctx->spec_capval = capval; ctx->spec_m = P.m; ctx->spec_cap = (double)P.cap; }
+  if ((joint_ok || nogc_bytes) && want_cap && cap_compact8_applies(P.m, capval)) { ctx->spec_capval = capval; ctx->spec_m = P.m; ctx->spec_cap = (double)P.cap; ctx->spec_gc = P.gcadjust != 0; }
   if (exp_slot) memcpy(hres_all.data(), exp_slot, exp_bytes);
   memcpy(&bacc, hres_all.data(), sizeof(bacc));
   const uint32_t* hres = hres_all.data() + kResHead / 4;

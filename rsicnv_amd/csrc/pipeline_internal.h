@@ -159,7 +159,7 @@ struct rsi_ctx {
   DevBuf joint_tot;           // K2j's folded joint histogram [GC count][depth byte] + escapes
   // K4j queued behind K2j without a host round trip needs its launch configuration before the cap is known: the cap of the
   // context's previous chromosome under the same flags (one sample: one depth), checked on the device and again by the host
-  int32_t spec_capval = -1; int32_t spec_m = 0; double spec_cap = 0.0;
+  int32_t spec_capval = -1; int32_t spec_m = 0; double spec_cap = 0.0; bool spec_gc = true;   // ... and whether that chromosome ran with the GC adjustment (the queued K4 of a -NOGC run takes the raw bytes)
   int sharpen_ws_jobs = 0;    // jobs it is laid out for
   // host mirrors kept for rsi_hot_fetch_* (what the last run left on the device)
   int64_t n = 0, ncompact = 0, nb = 0;

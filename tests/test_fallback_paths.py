@@ -93,9 +93,20 @@ def test_nogc_takes_the_byte_kernels_and_the_int32_ones_behind_the_switch(hot, h
     """-NOGC: the histogram pass for the cap median leaves a byte copy and K4' compacts from it (round 4); RSI_HOT_NOGC_BYTES=0 is the
     int32 K4 it used before, which a cap of 254 and more still takes.  Both against the reference's golden file, twice each."""
     hot.set_timing(1)
-    for _ in range(2):
+    for second in (False, True):
         gu.check_hip_against_golden(hot, hotlib, "poisson_nogc")
-        assert "a5.nogc byte path" in dict(hot.phase_times())
+        phases = dict(hot.phase_times())
+        assert "a5.nogc byte path" in phases
+        # the second run under the same flags: K4s (raw bytes) + K4m queued behind the histogram pass, the cap handed over on the device
+        # (round 5, as behind K2j); the first one has no cap to size the launch with
+        assert ("spec.k4j accepted" in phases) == second, phases
+    os.environ["RSI_HOT_SPEC"] = "0"
+    try:
+        gu.check_hip_against_golden(hot, hotlib, "poisson_nogc")
+        phases = dict(hot.phase_times())
+        assert "a5.nogc byte path" in phases and "spec.k4j accepted" not in phases and "spec.k4j rejected" not in phases
+    finally:
+        del os.environ["RSI_HOT_SPEC"]
     os.environ["RSI_HOT_NOGC_BYTES"] = "0"
     try:
         for _ in range(2):

@@ -15,3 +15,7 @@ echo "pooled trace done"
 bash tools/gpu_trace.sh ${TAG}_w1 --workers 1 --inflight 1 --steps 15 --warmup 2 --no-single --no-cpu-baseline > $OUT/trace_w1.log 2>&1
 cp gpurun_out/trace_${TAG}_w1/kernel_stats.csv $OUT/kernel_stats_3Gb_w1.csv
 echo "one-worker trace done"
+timeout -k 10 300 python bench.py --config 5 --no-cpu-baseline --no-single > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+echo "config 5 done"
+timeout -k 10 400 python tools/rank_probe.py > $OUT/rank_probe.txt 2> $OUT/rank_probe.err
+echo "rank probe done"

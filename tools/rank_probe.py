@@ -1,5 +1,5 @@
 """What one rank of a sharded-genome run does, measured on ONE GPU: for world sizes 2 / 4 / 8 every rank's share of the
-24-chromosome genome (rsicnv_amd.dist.lpt_assign) goes through the same 16-worker pool, one share after the other, queued
+24-chromosome genome (rsicnv_amd.dist.lpt_assign) goes through the same pool (20 workers, bench.py's default on a 16-core box), one share after the other, queued
 the way bench.py queues its steps (as many genomes in flight as keep the workers busy: 2 for a whole genome, up to 6 for a
 rank's share); the slowest share is the step time an N-GPU run would see (without the all_gather, ~0.1 ms).  --serial: one
 run at a time (the latency of a share, what bench.py measured before round 3).  Usage:
@@ -14,7 +14,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--env", nargs="*", default=[])
-    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--workers", type=int, default=20)
     ap.add_argument("--serial", action="store_true")
     args = ap.parse_args()
     for kv in args.env:
