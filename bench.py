@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=60.0, help="size of the CPU-baseline sample chromosome")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (single chromosomes, host-buffer runs, command line)")
-    ap.add_argument("--workers", type=int, default=0, help="host threads / HIP streams per GPU (chromosomes in flight); 0 = min(20, max(4, 2 x the "
+    ap.add_argument("--workers", type=int, default=0, help="host threads / HIP streams per GPU (chromosomes in flight); 0 = min(20 on one GPU / 16 per rank of several, max(4, 2 x the "
                     "host cores this rank may use)): sixteen on a box with eight cores and more per rank, fewer where eight ranks share sixteen cores")
     ap.add_argument("--inflight", type=int, default=0, help="steps (genomes) queued in the pool at once (rsi_pool_submit): the next genome's first "
                     "chromosomes run beside the last ones of the current genome.  0 = as many as keep the pool's workers busy with this rank's "
@@ -160,7 +160,10 @@ def main():
     except (AttributeError, OSError):
         allowed, forced = None, 0
     if args.workers <= 0:
-        args.workers = 20 if cores_per_rank is None else min(20, max(4, 2 * cores_per_rank))
+        # 20 on one GPU; 16 per rank when there are several: a process gets 24 hardware queues, the 22nd worker stream already shares one
+        # with something else (21 workers 11.7 ms per genome, 22 workers 14-17, tools/gpu_env_sweep.sh), and RCCL brings streams of its own
+        top = 20 if world == 1 else 16
+        args.workers = top if cores_per_rank is None else min(top, max(4, 2 * cores_per_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
