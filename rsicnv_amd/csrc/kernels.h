@@ -47,6 +47,9 @@ struct PhaseParams {
   int32_t redo;        // set by K4j: launched with a configuration that does not fit the cap -- nothing written, launch again
   int32_t pad[2];
 };
+// K1b's arguments, for the launch that does its work on the way (K2j, round 5): the N mask, the boundary list and its count (zero before),
+// the padding of get_noseq_regions (loaddata.cpp:243-273), where the compacted break points and removed lengths go
+struct NRuns { const uint64_t* nbits; uint64_t* list; uint32_t* count; uint32_t cap; int32_t dx; int64_t* cbreak; int64_t* cum; };
 // ---- K1b: run boundaries of the N bitmask -> unordered list of (pos << 1 | is_end) ----
 // pp != NULL: the last workgroup also builds cbreak[4100] / cum[4097] (regions padded by dx, merged) and fills pp's region fields;
 // counter: an arrival counter, zero before and after.
@@ -106,7 +109,8 @@ size_t gc_joint_esc_list_bytes();
 void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
                           unsigned int* counters, uint8_t* depth8 /* n + 2048 bytes */, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
                           const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
-                          PhaseParams* pp /* capval (and redo = 0) for a K4j queued behind */, double cap_mult, hipStream_t stream);
+                          PhaseParams* pp /* capval (and redo = 0) for a K4j queued behind */, double cap_mult, hipStream_t stream,
+                          const NRuns* nruns = nullptr /* K1b's work inside this launch (see NRuns) */);
 void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
                         ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,
                         hipStream_t stream);

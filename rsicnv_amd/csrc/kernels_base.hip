@@ -65,15 +65,13 @@ __global__ __launch_bounds__(kThreads) void k_fasta_classify(const uint8_t* __re
 // and removed lengths (cbreak / cum) -- so that K4j can be queued behind K2j without the host in between; the host builds
 // the same regions from the same list for its own stages.  Lists of more than kRegSortMax entries are left to the host.
 constexpr int kRegSortMax = 1024;
-__global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __restrict__ nbits, int64_t nwords,
-                                                            uint64_t* __restrict__ list, uint32_t* __restrict__ count,
-                                                            uint32_t cap, int64_t n, int dx, PhaseParams* __restrict__ pp,
-                                                            int64_t* __restrict__ cbreak, int64_t* __restrict__ cum,
-                                                            unsigned int* __restrict__ counter) {
+// run starts / ends in the words this workgroup takes (a grid-stride loop over the mask words): appended unordered to list[]
+__device__ inline void n_transitions_scan(const uint64_t* __restrict__ nbits, int64_t nwords, uint64_t* __restrict__ list,
+                                          uint32_t* __restrict__ count, uint32_t cap) {
   // four of a thread's strided words per trip, their eight loads in flight together (256 workgroups: sixty dependent trips per
   // thread on a 250 Mb chromosome otherwise)
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t w0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; w0 < nwords; w0 += 4 * stride) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w0 < nwords; w0 += 4 * stride) {
     uint64_t curv[4], prevv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -83,34 +81,37 @@ __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __re
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-    const int64_t w = w0 + e * stride;
-    if (w >= nwords) break;
-    const uint64_t cur = curv[e];
-    const uint64_t prev_top = prevv[e] >> 63;
-    const uint64_t shifted = (cur << 1) | prev_top;
-    uint64_t starts = cur & ~shifted, ends = ~cur & shifted;
-    while (starts) {
-      const int b = __ffsll((long long)starts) - 1;
-      starts &= starts - 1;
-      const uint32_t k = atomicAdd(count, 1u);
-      if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1));
-    }
-    while (ends) {
-      const int b = __ffsll((long long)ends) - 1;
-      ends &= ends - 1;
-      const uint32_t k = atomicAdd(count, 1u);
-      if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1) | 1ull);
-    }
+      const int64_t w = w0 + e * stride;
+      if (w >= nwords) break;
+      const uint64_t cur = curv[e];
+      const uint64_t prev_top = prevv[e] >> 63;
+      const uint64_t shifted = (cur << 1) | prev_top;
+      uint64_t starts = cur & ~shifted, ends = ~cur & shifted;
+      while (starts) {
+        const int b = __ffsll((long long)starts) - 1;
+        starts &= starts - 1;
+        const uint32_t k = atomicAdd(count, 1u);
+        if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1));
+      }
+      while (ends) {
+        const int b = __ffsll((long long)ends) - 1;
+        ends &= ends - 1;
+        const uint32_t k = atomicAdd(count, 1u);
+        if (k < cap) st_cg(reinterpret_cast<unsigned long long*>(&list[k]), ((unsigned long long)(w * 64 + b) << 1) | 1ull);
+      }
     }
   }
-  if (!pp) return;
-  if (!last_block_done(counter)) return;
-  __shared__ unsigned long long s_e[kRegSortMax], s_s[kRegSortMax];
+}
+// the whole list is there (the caller is the launch's last workgroup, all of its threads): sorted, padded by dx, merged -> cbreak / cum
+// / pp's region fields.  s_e, s_s: kRegSortMax words of LDS each.
+__device__ inline void n_regions_build(const uint64_t* __restrict__ list, const uint32_t* __restrict__ count, int64_t n, int dx,
+                                       PhaseParams* __restrict__ pp, int64_t* __restrict__ cbreak, int64_t* __restrict__ cum,
+                                       unsigned long long* s_e, unsigned long long* s_s) {
   const unsigned int cnt = ld_cg(count);
   if (cnt > (unsigned int)kRegSortMax || (cnt & 1u)) { if (threadIdx.x == 0) { pp->regions_ok = 0; pp->nreg = 0; pp->ncompact = n; } return; }
-  for (unsigned int k = threadIdx.x; k < cnt; k += kThreads) s_e[k] = ld_cg(reinterpret_cast<const unsigned long long*>(&list[k]));
+  for (unsigned int k = threadIdx.x; k < cnt; k += blockDim.x) s_e[k] = ld_cg(reinterpret_cast<const unsigned long long*>(&list[k]));
   __syncthreads();
-  for (unsigned int k = threadIdx.x; k < cnt; k += kThreads) {   // rank sort: the entries are distinct
+  for (unsigned int k = threadIdx.x; k < cnt; k += blockDim.x) {   // rank sort: the entries are distinct
     const unsigned long long e = s_e[k];
     unsigned int rank = 0;
     for (unsigned int j = 0; j < cnt; ++j) rank += s_e[j] < e;
@@ -134,6 +135,17 @@ __global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __re
     if (open) { cbreak[nreg] = cur_s - removed; removed += cur_e - cur_s + 1; ++nreg; cum[nreg] = removed; }
     pp->nreg = nreg; pp->ncompact = n - removed; pp->regions_ok = ok;
   }
+}
+__global__ __launch_bounds__(kThreads) void k_n_transitions(const uint64_t* __restrict__ nbits, int64_t nwords,
+                                                            uint64_t* __restrict__ list, uint32_t* __restrict__ count,
+                                                            uint32_t cap, int64_t n, int dx, PhaseParams* __restrict__ pp,
+                                                            int64_t* __restrict__ cbreak, int64_t* __restrict__ cum,
+                                                            unsigned int* __restrict__ counter) {
+  n_transitions_scan(nbits, nwords, list, count, cap);
+  if (!pp) return;
+  if (!last_block_done(counter)) return;
+  __shared__ unsigned long long s_e[kRegSortMax], s_s[kRegSortMax];
+  n_regions_build(list, count, n, dx, pp, cbreak, cum, s_e, s_s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,7 +795,8 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
     GcAccum* __restrict__ acc, double* __restrict__ table, uint8_t* __restrict__ d8, uint32_t* __restrict__ ghist,
     ValueHistAux* __restrict__ aux, ValueMedian* __restrict__ vm, const void* head_src, void* head_dst, unsigned int head_bytes, int dbg,
     unsigned int* __restrict__ esc_list /* gridDim.x lists of 1 + kJEscPerWg words */, unsigned int* __restrict__ rtab /* [202] */,
-    JointInfo* __restrict__ info, unsigned int escape_limit, PhaseParams* __restrict__ pp, double cap_mult) {
+    JointInfo* __restrict__ info, unsigned int escape_limit, PhaseParams* __restrict__ pp, double cap_mult,
+    NRuns nr /* K1b's work inside this launch (round 5): nr.list == NULL: the caller ran k_n_transitions */) {
   __shared__ __align__(16) unsigned int s_j[kJSlabWords];
   __shared__ unsigned int s_nesc;
   __shared__ WaveGc s_gc[kJWaves];
@@ -793,6 +806,9 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
   if (threadIdx.x < 32) s_bits[threadIdx.x] = 0u;
   if (threadIdx.x == 0) s_nesc = 0u;
   __syncthreads();
+  // K1b's scan of the N mask, spread over this launch's workgroups (one launch less in the per-base phase: in a pool a launch costs
+  // the phase 0.1-0.2 ms whatever it does); the list is complete when the last workgroup runs the tail
+  if (nr.list) n_transitions_scan(nr.nbits, nwords, nr.list, nr.count, nr.cap);
   unsigned int* const my_list = esc_list + (size_t)blockIdx.x * (1 + kJEscPerWg);
   unsigned int* s_zero = s_j + kJOffZero;
   unsigned int* s_esc_cnt = s_j + kJOffEscCnt;
@@ -1061,6 +1077,11 @@ __global__ __launch_bounds__(kJThreads) void k_gc_joint_hist(
 
   if (dbg & 8) { export_words(head_dst, head_src, head_bytes); return; }   // DEBUG ablation: no tail
   // ================= the launch's last workgroup: GC table, rescaled-value histogram, cap median, header =================
+  if (nr.list) {   // the removed regions K4s compacts with (K1b's tail): before anything below can return
+    __shared__ unsigned long long s_re[kRegSortMax], s_rs[kRegSortMax];
+    n_regions_build(nr.list, nr.count, n, nr.dx, pp, nr.cbreak, nr.cum, s_re, s_rs);
+    __syncthreads();
+  }
   // scratch in the (now free) slab image
   unsigned long long* r_sum = reinterpret_cast<unsigned long long*>(s_j);            // [202]
   unsigned long long* r_cnt = r_sum + kGcLevels;                                     // [202]
@@ -2737,13 +2758,15 @@ size_t gc_joint_esc_list_bytes() { return (size_t)256 * (1 + kJEscPerWg) * 4; }
 void launch_gc_joint_hist(const int32_t* depth, const uint64_t* gcbits, int64_t n, GcAccum* acc, double* table, void* slabs, void* totals,
                           unsigned int* counters, uint8_t* depth8, uint32_t* hist, ValueHistAux* aux, ValueMedian* vm,
                           const void* head_src, void* head_dst, size_t head_bytes, void* esc_list, unsigned int* rtab, JointInfo* info,
-                          PhaseParams* pp, double cap_mult, hipStream_t stream) {
+                          PhaseParams* pp, double cap_mult, hipStream_t stream, const NRuns* nruns) {
   const int grid = gc_joint_grid(n);
+  NRuns nr{};
+  if (nruns) nr = *nruns;
   RSI_ALLOW_FULL_LDS(k_gc_joint_hist);
   RSI_LAUNCH(k_gc_joint_hist, dim3((unsigned)grid), dim3(kJThreads), 0, stream, depth, gcbits, n, n / 64 + 1, static_cast<unsigned int*>(slabs),
              static_cast<unsigned int*>(totals), fold_per_group(grid), counters, acc, table, depth8, hist, aux, vm, head_src, head_dst,
              (unsigned int)head_bytes, getenv("RSI_HOT_K2J_DBG") ? atoi(getenv("RSI_HOT_K2J_DBG")) : 0, static_cast<unsigned int*>(esc_list), rtab, info,
-             byte_escape_limit(n), pp, cap_mult);
+             byte_escape_limit(n), pp, cap_mult, nr);
 }
 void launch_escape_hist(const uint8_t* depth8, const int32_t* depth, const uint64_t* gcbits, int64_t n, const double* table, uint32_t* hist,
                         ValueHistAux* aux, unsigned int* counter, ValueMedian* vm, const void* head_src, void* head_dst, size_t head_bytes,

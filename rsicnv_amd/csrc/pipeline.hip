@@ -946,7 +946,10 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   PhaseParams* d_pp = reinterpret_cast<PhaseParams*>(small + kOffPhase);
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, n, std::max(50, P.m / 4), (joint || nogc_bytes) ? d_pp : nullptr, d_cbreak, d_cum, d_done + 4 * kDoneStride + 8, st); }
+  // K1b: the N runs' boundaries and the removed regions -- inside K2j's launch where there is one (RSI_HOT_K1B_INSIDE=0: its own launch, as until round 5)
+  const bool k1b_inside = joint && !(getenv("RSI_HOT_K1B_INSIDE") && atoi(getenv("RSI_HOT_K1B_INSIDE")) == 0);
+  const NRuns k1b_args{ctx->nbits.as<uint64_t>(), d_ntrans, d_ncount, (uint32_t)kMaxTransitions, std::max(50, P.m / 4), d_cbreak, d_cum};
+  if (!k1b_inside) { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, n, std::max(50, P.m / 4), (joint || nogc_bytes) ? d_pp : nullptr, d_cbreak, d_cum, d_done + 4 * kDoneStride + 8, st); }
   constexpr uint32_t kEagerRuns = 1024;
   uint32_t n_trans = 0;
   std::vector<uint64_t> trans_raw(kEagerRuns);
@@ -973,7 +976,7 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
     launch_gc_joint_hist(d_depth, ctx->gcbits.as<uint64_t>(), n, d_acc, d_table, ctx->slabs.p, ctx->joint_tot.p, d_done, ctx->depth8.as<uint8_t>(),
                          ctx->hist_val.as<uint32_t>(), d_aux, d_vm, small, head, head_bytes, ctx->joint_tot.as<uint8_t>() + joint_list_off,
                          reinterpret_cast<unsigned int*>(ctx->joint_tot.as<uint8_t>() + joint_lut_off), reinterpret_cast<JointInfo*>(small + kOffJointInfo),
-                         d_pp, (double)P.cap, st);
+                         d_pp, (double)P.cap, st, k1b_inside ? &k1b_args : nullptr);
     return RSI_OK;
   };
   // K4j right behind K2j, no host in between (one wait per per-base phase instead of two): regions, length and cap reach it

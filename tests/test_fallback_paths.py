@@ -340,8 +340,15 @@ def _check_k4split_off(hot, res, second):
     assert "k4.split" not in phases and "bin_median" not in kernels and "cap_compact_bin" in kernels, (phases, kernels)
 
 
+def _check_k1b_outside(hot, res, second):
+    """K1b (the N runs' boundaries and the removed regions) as a launch of its own instead of inside K2j's (round 5)."""
+    phases, kernels = _ran(hot)
+    assert "n_transitions" in kernels and "gc_joint_hist" in kernels, kernels
+
+
 SWITCHES = {"RSI_HOT_JOINT": _check_joint_off, "RSI_HOT_SPEC": _check_spec_off, "RSI_HOT_K4J_FIX": _check_fix_off,
-            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off, "RSI_HOT_K4SPLIT": _check_k4split_off}
+            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off, "RSI_HOT_K4SPLIT": _check_k4split_off,
+            "RSI_HOT_K1B_INSIDE": _check_k1b_outside}
 
 
 @pytest.mark.parametrize("switch", sorted(SWITCHES))
@@ -366,6 +373,7 @@ def test_alternative_paths_behind_the_switches(hot, hotlib, switch):
     res = gu.check_hip_against_golden(hot, hotlib, SWITCH_CASES[1])     # second run under the same flags: a K4j is queued
     phases, kernels = _ran(hot)
     assert "gc_joint_hist" in kernels and "gc_hist" not in kernels
+    assert "n_transitions" not in kernels     # K1b's work rides in K2j's launch
     assert "spec.k4j accepted" in phases, phases
     assert "k4j.float rescale" not in phases
     assert "bin_median" in kernels            # K4 as K4s + K4m (the queued launch too)
