@@ -946,8 +946,9 @@ int per_base_phase(rsi_ctx* ctx, const rsi_params& P, const int32_t* d_depth, co
   PhaseParams* d_pp = reinterpret_cast<PhaseParams*>(small + kOffPhase);
   int64_t* d_cbreak = reinterpret_cast<int64_t*>(small + kOffBreaks);
   int64_t* d_cum = d_cbreak + 4100;
-  // K1b: the N runs' boundaries and the removed regions -- inside K2j's launch where there is one (RSI_HOT_K1B_INSIDE=0: its own launch, as until round 5)
-  const bool k1b_inside = joint && !(getenv("RSI_HOT_K1B_INSIDE") && atoi(getenv("RSI_HOT_K1B_INSIDE")) == 0);
+  // K1b: the N runs' boundaries and the removed regions -- inside K2j's launch where there is one (RSI_HOT_K1B_INSIDE=1; measured: 0.7 % on the pooled step, 13 us of a lone
+  // chromosome -- and 10 us MORE for K2j itself, the kernel the roofline is quoted on: off by default)
+  const bool k1b_inside = joint && getenv("RSI_HOT_K1B_INSIDE") && atoi(getenv("RSI_HOT_K1B_INSIDE")) == 1;
   const NRuns k1b_args{ctx->nbits.as<uint64_t>(), d_ntrans, d_ncount, (uint32_t)kMaxTransitions, std::max(50, P.m / 4), d_cbreak, d_cum};
   if (!k1b_inside) { Timer t(ctx, "n_transitions"); launch_n_transitions(ctx->nbits.as<uint64_t>(), nwords, d_ntrans, d_ncount, kMaxTransitions, n, std::max(50, P.m / 4), (joint || nogc_bytes) ? d_pp : nullptr, d_cbreak, d_cum, d_done + 4 * kDoneStride + 8, st); }
   constexpr uint32_t kEagerRuns = 1024;

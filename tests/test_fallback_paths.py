@@ -340,15 +340,8 @@ def _check_k4split_off(hot, res, second):
     assert "k4.split" not in phases and "bin_median" not in kernels and "cap_compact_bin" in kernels, (phases, kernels)
 
 
-def _check_k1b_outside(hot, res, second):
-    """K1b (the N runs' boundaries and the removed regions) as a launch of its own instead of inside K2j's (round 5)."""
-    phases, kernels = _ran(hot)
-    assert "n_transitions" in kernels and "gc_joint_hist" in kernels, kernels
-
-
 SWITCHES = {"RSI_HOT_JOINT": _check_joint_off, "RSI_HOT_SPEC": _check_spec_off, "RSI_HOT_K4J_FIX": _check_fix_off,
-            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off, "RSI_HOT_K4SPLIT": _check_k4split_off,
-            "RSI_HOT_K1B_INSIDE": _check_k1b_outside}
+            "RSI_HOT_SCAN_DETECT": _check_detect_off, "RSI_HOT_CAND_SPLIT": _check_split_off, "RSI_HOT_K4SPLIT": _check_k4split_off}
 
 
 @pytest.mark.parametrize("switch", sorted(SWITCHES))
@@ -373,9 +366,28 @@ def test_alternative_paths_behind_the_switches(hot, hotlib, switch):
     res = gu.check_hip_against_golden(hot, hotlib, SWITCH_CASES[1])     # second run under the same flags: a K4j is queued
     phases, kernels = _ran(hot)
     assert "gc_joint_hist" in kernels and "gc_hist" not in kernels
-    assert "n_transitions" not in kernels     # K1b's work rides in K2j's launch
+    assert "n_transitions" in kernels         # (K1b inside K2j's launch is behind RSI_HOT_K1B_INSIDE=1, below)
     assert "spec.k4j accepted" in phases, phases
     assert "k4j.float rescale" not in phases
     assert "bin_median" in kernels            # K4 as K4s + K4m (the queued launch too)
     assert res.stats["scan_tiles_listed"] > 0
     assert "candidate_test" in kernels and "candidate_test_one_wg" not in kernels
+
+
+def test_k1b_inside_k2j_behind_its_switch(hot, hotlib):
+    """RSI_HOT_K1B_INSIDE=1: the N mask's boundary scan as a prologue of K2j's workgroups and the removed regions built by K2j's last
+    workgroup (kernels_base.hip: n_transitions_scan / n_regions_build) instead of K1b's own launch -- the same lists, the same
+    regions (readref.cpp:88, loaddata.cpp:243-273): four golden cases, each twice (the second run has K4s + K4m queued behind K2j,
+    which then compact with the regions K2j built)."""
+    hot.set_timing(1)
+    os.environ["RSI_HOT_K1B_INSIDE"] = "1"
+    try:
+        for name in SWITCH_CASES:
+            for second in (False, True):
+                gu.check_hip_against_golden(hot, hotlib, name)
+                phases, kernels = _ran(hot)
+                assert "n_transitions" not in kernels and "gc_joint_hist" in kernels, kernels
+                if second:
+                    assert "spec.k4j accepted" in phases, phases
+    finally:
+        del os.environ["RSI_HOT_K1B_INSIDE"]
